@@ -1,0 +1,491 @@
+/*
+ * md_entity.h -- per-entity (one vehicle / one agent) scalar step logic: action sanitising +
+ * kinematic integration, observation/reward/done assembly, IDM decision.  These routines are
+ * inherently serial per entity; the HIP kernels run one GPU thread per entity over them and the
+ * CPU oracle loops over entities, so both share this one spelling (same rationale as md_geom.h).
+ * The phases whose GPU form is genuinely different -- lidar (wave per agent-sector with ballot
+ * culling), lane localisation and contact tests (wave per vehicle over grid cells), traffic
+ * trigger (wave min-reduce) -- are written twice: brute force in oracle/md_oracle.c, wave-parallel
+ * in metadrive_ped_amd/csrc/mdstep.hip.
+ *
+ * Reference citations are relative to /root/reference/metadrive.
+ */
+#ifndef MD_ENTITY_H
+#define MD_ENTITY_H
+
+#include "md_geom.h"
+
+MD_HD int md_kind_of(int flags) { return flags & MD_KIND_MASK; }
+MD_HD int md_is_circle_kind(int k) { return k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_PEDESTRIAN; }
+/* present: has a body in the world (seen by lidar, can be hit).  Traffic spawned for a block that
+ * is not triggered yet is present but parked (manager/traffic_manager.py:230-277 spawns every
+ * vehicle at reset; only triggered ones enter _traffic_vehicles and act, :80-91). */
+MD_HD int md_present(int flags) { return (flags & MD_F_ALIVE) && md_kind_of(flags) != MD_KIND_NONE; }
+/* drives: is stepped this frame (agent, or triggered traffic) */
+MD_HD int md_drives(int flags) {
+    return md_present(flags) && md_kind_of(flags) == MD_KIND_VEHICLE && !(flags & (MD_F_STATIC | MD_F_PENDING));
+}
+
+MD_HD float md_sanitize(float a) { /* utils/math.py:16-26 safe_clip_for_small_array(.., -1, 1) */
+    if (a != a) return 0.0f;
+    if (a > 3.0e38f) return 1.0f;
+    if (a < -3.0e38f) return -1.0f;
+    return md_clip(a, -1.0f, 1.0f);
+}
+
+MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
+    MdShape* sh = &s->shape[n];
+    if (!md_drives(sh->flags)) return;
+    MdDyn* d = &s->dyn[n];
+    float steer = md_sanitize(s->action[2 * n]);
+    float thr = md_sanitize(s->action[2 * n + 1]);
+    s->action[2 * n] = steer;
+    s->action[2 * n + 1] = thr;
+    d->last_x = sh->cx;
+    d->last_y = sh->cy;
+    d->last_c = sh->c;
+    d->last_s = sh->s;
+    d->steering = steer;
+    d->throttle = thr;
+    float x = sh->cx, y = sh->cy, psi = d->heading, v = d->speed;
+    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, steer, thr, &s->param[n], c->dt);
+    sh->cx = x;
+    sh->cy = y;
+    d->heading = psi;
+    d->speed = v;
+    md_sincos(psi, &sh->s, &sh->c);
+}
+
+
+MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, int just_reset) {
+    int n = e * c->cap + a;
+    int ai = e * c->agents_per_env + a;
+    float* obs = s->obs + (size_t)ai * c->obs_dim;
+    float* info = s->step_info + (size_t)ai * 8;
+    MdShape* sh = &s->shape[n];
+    MdDyn* d = &s->dyn[n];
+    MdNav* nav = &s->nav[n];
+    if (!md_drives(sh->flags) || nav->lane < 0) {
+        for (int i = 0; i < 19; ++i) obs[i] = 0.0f;
+        s->reward[ai] = 0.0f;
+        s->cost[ai] = 0.0f;
+        for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+        return;
+    }
+    int m = w->env_map[e];
+    const MdLane* lanes = w->lanes + w->lane_off[m];
+    const MdRoad* roads = w->roads + w->road_off[m];
+    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
+    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    int has_next = nav->ck1 != nav->ck0;
+    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : cur_road;
+    const MdLane* lane = &lanes[nav->lane];
+    const MdLane* ref0 = &lanes[cur_road->first_lane];
+    const MdLane* ref_last = &lanes[cur_road->first_lane + cur_road->n_lanes - 1];
+    float cur_w = lane->width; /* get_current_lane_width = current_lane.width */
+    float cur_n = (float)cur_road->n_lanes;
+    float x = sh->cx, y = sh->cy;
+
+    /* dist to left/right of the route (base_vehicle.py:491-499) */
+    float s0, lat0;
+    md_lane_local(ref0, x, y, &s0, &lat0);
+    float to_left = lat0 + cur_w / 2.0f;
+    float to_right = cur_w * cur_n - to_left;
+    uint32_t fl = s->flags[n] & (MD_FL_CRASH_VEHICLE | MD_FL_CRASH_OBJECT | MD_FL_CRASH_HUMAN | MD_FL_CRASH_BUILDING |
+                                 MD_FL_CRASH_SIDEWALK | MD_FL_ON_WHITE_CONT | MD_FL_ON_YELLOW_CONT | MD_FL_ON_BROKEN |
+                                 MD_FL_ON_CROSSWALK | MD_FL_ON_LANE);
+    if (to_right < 0.0f || to_left < 0.0f) fl |= MD_FL_OUT_OF_ROUTE;
+
+    /* ---- state obs (obs/state_obs.py:64-151) ---- */
+    float speed_kmh = md_fabs(d->speed) * 3.6f;
+    const MdParam* P = &s->param[n];
+    obs[0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
+    obs[1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
+    obs[2] = md_heading_diff(ref_last, x, y, sh->c, sh->s);
+    obs[3] = md_clip((speed_kmh + 1.0f) / (P->max_speed_kmh + 1.0f), 0.0f, 1.0f);
+    obs[4] = md_clip((d->steering / 60.0f + 1.0f) / 2.0f, 0.0f, 1.0f); /* MAX_STEERING = 60 (base_vehicle.py:80) */
+    obs[5] = md_clip((s->action[2 * n] + 1.0f) / 2.0f, 0.0f, 1.0f);
+    obs[6] = md_clip((s->action[2 * n + 1] + 1.0f) / 2.0f, 0.0f, 1.0f);
+    {
+        float cosb = (sh->c * d->last_c + sh->s * d->last_s) / (md_norm(sh->c, sh->s) * md_norm(d->last_c, d->last_s));
+        float beta = md_acos(md_clip(cosb, 0.0f, 1.0f));
+        obs[7] = md_clip(beta / 0.1f, 0.0f, 1.0f);
+    }
+    float ls, llat;
+    md_lane_local(lane, x, y, &ls, &llat);
+    obs[8] = md_clip((llat * 2.0f / c->max_lane_width + 1.0f) / 2.0f, 0.0f, 1.0f);
+
+    /* ---- navi (node_network_navigation.py:160-168, 243-292) ---- */
+    float later_middle = (cur_n / 2.0f - 0.5f) * cur_w;
+    md_navi_for_checkpoint(ref0, later_middle, x, y, sh->c, sh->s, cur_n, cur_w, c->curve_radius_max, c->curve_angle_max,
+                           obs + 9);
+    md_navi_for_checkpoint(&lanes[next_road->first_lane], later_middle, x, y, sh->c, sh->s, cur_n, cur_w,
+                           c->curve_radius_max, c->curve_angle_max, obs + 14);
+
+    /* ---- arrive destination (metadrive_env.py:213-227) ---- */
+    const MdLane* fin = &lanes[s->final_lane[n]];
+    float fs, flat;
+    md_lane_local(fin, x, y, &fs, &flat);
+    int arrive = (fin->length - 5.0f < fs) && (fs < fin->length + 5.0f) && (cur_w / 2.0f >= flat) &&
+                 (flat >= (0.5f - cur_n) * cur_w);
+    /* ---- out of road (metadrive_env.py:229-237) ---- */
+    int out_of_road = !(fl & MD_FL_ON_LANE);
+    if (c->out_of_route_done) out_of_road = out_of_road || (fl & MD_FL_OUT_OF_ROUTE);
+    else if (c->on_continuous_line_done)
+        out_of_road = out_of_road || (fl & (MD_FL_ON_YELLOW_CONT | MD_FL_ON_WHITE_CONT | MD_FL_CRASH_SIDEWALK));
+    if (arrive) fl |= MD_FL_ARRIVE_DEST;
+    if (out_of_road) fl |= MD_FL_OUT_OF_ROAD;
+
+    /* ---- reward (metadrive_env.py:239-279) ---- */
+    const MdLane* rl;
+    float positive_road = 1.0f;
+    if (lane->road == rroads[nav->ck0]) rl = lane;
+    else {
+        rl = ref0;
+        positive_road = cur_road->negative ? -1.0f : 1.0f;
+    }
+    float long_last, tmp, long_now, lateral_now;
+    md_lane_local(rl, d->last_x, d->last_y, &long_last, &tmp);
+    md_lane_local(rl, x, y, &long_now, &lateral_now);
+    float lateral_factor = 1.0f;
+    if (c->use_lateral_reward) lateral_factor = md_clip(1.0f - 2.0f * md_fabs(lateral_now) / cur_w, 0.0f, 1.0f);
+    float reward = 0.0f;
+    reward += c->driving_reward * (long_now - long_last) * lateral_factor * positive_road;
+    reward += c->speed_reward * (speed_kmh / P->max_speed_kmh) * positive_road;
+    float step_reward = reward;
+    if (arrive) reward = c->success_reward;
+    else if (out_of_road) reward = -c->out_of_road_penalty;
+    else if (fl & MD_FL_CRASH_VEHICLE) reward = -c->crash_vehicle_penalty;
+    else if (fl & MD_FL_CRASH_OBJECT) reward = -c->crash_object_penalty;
+
+    /* ---- cost (metadrive_env.py:201-211) ---- */
+    float cost = 0.0f;
+    if (out_of_road) cost = c->out_of_road_cost;
+    else if (fl & MD_FL_CRASH_VEHICLE) cost = c->crash_vehicle_cost;
+    else if (fl & MD_FL_CRASH_OBJECT) cost = c->crash_object_cost;
+
+    /* ---- done (metadrive_env.py:128-199, base_env.py:586-612) ---- */
+    if (!just_reset) nav->steps += 1;
+    int max_step = (c->horizon > 0) && (nav->steps >= c->horizon);
+    int done = 0;
+    if (arrive) done = 1;
+    if (out_of_road) done = 1;
+    if ((fl & MD_FL_CRASH_VEHICLE) && c->crash_vehicle_done) done = 1;
+    if ((fl & MD_FL_CRASH_OBJECT) && c->crash_object_done) done = 1;
+    if (fl & MD_FL_CRASH_BUILDING) done = 1;
+    if ((fl & MD_FL_CRASH_HUMAN) && c->crash_human_done) done = 1;
+    if (max_step) {
+        fl |= MD_FL_MAX_STEP;
+        if (c->truncate_as_terminate) done = 1;
+    }
+    if (just_reset) {
+        /* _get_reset_return (base_env.py:560-584): obs only; no reward, nothing terminates */
+        reward = 0.0f;
+        cost = 0.0f;
+        step_reward = 0.0f;
+        nav->done = 0;
+    } else {
+        nav->done = nav->done || done;
+        if (nav->done) fl |= MD_FL_TERMINATED;
+        if (max_step) fl |= MD_FL_TRUNCATED;
+    }
+    s->flags[n] = fl;
+    s->reward[ai] = reward;
+    s->cost[ai] = cost;
+
+    /* ---- info (base_vehicle.py:243-271) ---- */
+    float dist_km = md_norm(d->last_x - x, d->last_y - y) / 1000.0f;
+    float step_energy = 3.25f * md_exp(0.01f * speed_kmh) * dist_km / 100.0f * 1000.0f;
+    if (just_reset) step_energy = 0.0f;
+    s->pid[n].energy += step_energy;
+    info[0] = step_reward;
+    info[1] = md_fabs(d->speed);
+    info[2] = step_energy;
+    info[3] = s->pid[n].energy;
+    info[4] = just_reset ? 0.0f : info[4] + reward;
+    info[5] = llat;
+    info[6] = ls;
+    info[7] = (float)nav->steps;
+    if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[e] = 1;
+}
+
+
+typedef struct {
+    int front[3], back[3];
+    float front_d[3], back_d[3];
+    int exist[3];
+} FrontBack;
+
+#define IDM_MAX_LONG_DIST 30.0f
+#define IDM_SAFE_LANE_CHANGE 15.0f
+#define IDM_LANE_CHANGE_FREQ 50
+#define IDM_LANE_CHANGE_SPEED_INC 10.0f
+#define IDM_NORMAL_SPEED 30.0f
+#define IDM_CREEP_SPEED 5.0f
+#define IDM_MAX_SPEED 100.0f
+
+MD_HD void md_find_front_back(const MdState* s, const MdConfig* c, const MdLane* lanes, int base, int self_slot,
+                            const unsigned char* cand, int lane_id, int use_ref, const MdRoad* ref_road, float px,
+                            float py, FrontBack* fb) {
+    int ids[3] = {-1, lane_id, -1};
+    if (use_ref) {
+        int idx = lanes[lane_id].idx;
+        if (idx > 0) ids[0] = ref_road->first_lane + idx - 1;
+        if (idx + 1 < ref_road->n_lanes) ids[2] = ref_road->first_lane + idx + 1;
+    }
+    for (int i = 0; i < 3; ++i) {
+        fb->front[i] = fb->back[i] = -1;
+        fb->exist[i] = ids[i] >= 0;
+        fb->front_d[i] = fb->back_d[i] = IDM_MAX_LONG_DIST;
+        if (ids[i] < 0) continue;
+        const MdLane* L = &lanes[ids[i]];
+        float cur_long, tmp;
+        md_lane_local(L, px, py, &cur_long, &tmp);
+        float left_long = L->length - cur_long;
+        /* The reference walks a Python set (arbitrary order) and lets an object on the successor /
+         * predecessor lane compete only while no same-lane object has been found yet
+         * (idm_policy.py:110-130).  Canonical, order-independent form used here: same-lane objects
+         * first; connected-lane objects only when the same lane offered none. Ties -> lowest slot. */
+        int found_front = 0, found_back = 0;
+        for (int j = 0; j < c->cap; ++j) {
+            if (j == self_slot || !cand[j]) continue;
+            const MdShape* o = &s->shape[base + j];
+            int ol = (md_kind_of(o->flags) == MD_KIND_VEHICLE && !(o->flags & MD_F_STATIC)) ? s->nav[base + j].lane : o->aux;
+            if (ol != ids[i]) continue;
+            float os, ot;
+            md_lane_local(L, o->cx, o->cy, &os, &ot);
+            float lg = os - cur_long;
+            if (fb->front_d[i] > lg && lg > 0.0f) {
+                fb->front_d[i] = lg;
+                fb->front[i] = j;
+                found_front = 1;
+            }
+            if (lg < 0.0f && md_fabs(lg) < fb->back_d[i]) {
+                fb->back_d[i] = md_fabs(lg);
+                fb->back[i] = j;
+                found_back = 1;
+            }
+        }
+        if (found_front && found_back) continue;
+        for (int j = 0; j < c->cap; ++j) {
+            if (j == self_slot || !cand[j]) continue;
+            const MdShape* o = &s->shape[base + j];
+            int ol = (md_kind_of(o->flags) == MD_KIND_VEHICLE && !(o->flags & MD_F_STATIC)) ? s->nav[base + j].lane : o->aux;
+            if (ol < 0 || ol == ids[i]) continue;
+            const MdLane* OL = &lanes[ol];
+            if (!found_front && md_lane_is_previous_of(L, OL)) {
+                float os, ot;
+                md_lane_local(OL, o->cx, o->cy, &os, &ot);
+                float lg = os + left_long;
+                if (fb->front_d[i] > lg && lg > 0.0f) {
+                    fb->front_d[i] = lg;
+                    fb->front[i] = j;
+                }
+            } else if (!found_back && md_lane_is_previous_of(OL, L)) {
+                float os, ot;
+                md_lane_local(OL, o->cx, o->cy, &os, &ot);
+                float lg = OL->length - os + cur_long;
+                if (fb->back_d[i] > lg) {
+                    fb->back_d[i] = lg;
+                    fb->back[i] = j;
+                }
+            }
+        }
+    }
+}
+
+MD_HD int md_road_connects(const MdWorld* w, int m, int from_node, int to_node) {
+    /* BaseRoadNetwork.has_connection (road_network/base_road_network.py:106-113): graph[from][to] exists */
+    int nb = w->node_off[m];
+    for (int k = w->node_adj_off[nb + from_node]; k < w->node_adj_off[nb + from_node + 1]; ++k)
+        if (w->node_adj[2 * k] == to_node) return 1;
+    return 0;
+}
+
+MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot) {
+    int base = e * c->cap;
+    int n = base + slot;
+    MdShape* sh = &s->shape[n];
+    MdNav* nav = &s->nav[n];
+    MdPid* pid = &s->pid[n];
+    MdDyn* d = &s->dyn[n];
+    int m = w->env_map[e];
+    const MdLane* lanes = w->lanes + w->lane_off[m];
+    const MdRoad* roads = w->roads + w->road_off[m];
+    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
+    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    int has_next = nav->ck1 != nav->ck0;
+    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : 0;
+    float px = sh->cx, py = sh->cy;
+    float speed_kmh = md_fabs(d->speed) * 3.6f;
+
+    /* ---- move_to_next_road (idm_policy.py:269-291) ---- */
+    int success;
+    int veh_lane = nav->lane;
+    int in_cur = (veh_lane >= 0) && (lanes[veh_lane].road == rroads[nav->ck0]);
+    if (nav->target_lane < 0) {
+        nav->target_lane = veh_lane;
+        success = in_cur;
+    } else if (lanes[nav->target_lane].road != rroads[nav->ck0]) {
+        success = 0;
+        const MdLane* T = &lanes[nav->target_lane];
+        int t_end = roads[T->road].end_node;
+        for (int k = 0; k < cur_road->n_lanes; ++k) {
+            const MdLane* L = &lanes[cur_road->first_lane + k];
+            if (md_lane_is_previous_of(T, L) || md_road_connects(w, m, t_end, cur_road->end_node)) {
+                nav->target_lane = cur_road->first_lane + k;
+                success = 1;
+                break;
+            }
+        }
+    } else if (in_cur && nav->target_lane != veh_lane) {
+        nav->target_lane = veh_lane;
+        nav->timer = s->idm_rand[(size_t)n * MD_IDM_RAND + (nav->rand_cursor % MD_IDM_RAND)];
+        nav->rand_cursor += 1;
+        success = 1;
+    } else {
+        success = 1;
+    }
+
+    /* ---- lidar.get_surrounding_objects(v): bodies touching the r=50 ghost cylinder (lidar.py:170-186) ---- */
+    unsigned char cand[MD_MAX_CAP];
+    for (int j = 0; j < c->cap; ++j) {
+        cand[j] = 0;
+        if (j == slot) continue;
+        const MdShape* o = &s->shape[base + j];
+        if (!md_present(o->flags)) continue;
+        int k = md_kind_of(o->flags);
+        if (md_is_circle_kind(k)) {
+            float dx = o->cx - px, dy = o->cy - py, rr = 50.0f + o->hl;
+            cand[j] = (dx * dx + dy * dy) <= rr * rr;
+        } else {
+            cand[j] = (unsigned char)md_obb_circle(o->cx, o->cy, o->c, o->s, o->hl, o->hw, px, py, 50.0f);
+        }
+    }
+
+    int front_obj = -1;
+    float front_dist = 5.0f;
+    int steer_lane = nav->target_lane;
+    int fail = (nav->target_lane < 0);
+    if (!fail) {
+        FrontBack fb;
+        if (success && c->enable_idm_lane_change) {
+            /* ---- lane_change_policy (idm_policy.py:330-402) ---- */
+            md_find_front_back(s, c, lanes, base, slot, cand, nav->target_lane, 1, cur_road, px, py, &fb);
+            int ncur = cur_road->n_lanes;
+            int avail_lo = 0, avail_hi = ncur - 1;
+            int lane_num_diff = has_next ? (ncur - next_road->n_lanes) : 0;
+            int tidx = lanes[nav->target_lane].idx;
+            int decided = 0;
+            if (lane_num_diff > 0) {
+                if (md_lane_is_previous_of(&lanes[cur_road->first_lane], &lanes[next_road->first_lane])) {
+                    avail_lo = 0;
+                    avail_hi = next_road->n_lanes - 1;
+                } else {
+                    avail_lo = lane_num_diff;
+                    avail_hi = ncur - 1;
+                }
+                if (tidx < avail_lo || tidx > avail_hi) {
+                    if (tidx > avail_hi) { /* change to left */
+                        if (!fb.exist[0]) fail = 1;
+                        else if (fb.back_d[0] < IDM_SAFE_LANE_CHANGE || fb.front_d[0] < 5.0f) {
+                            pid->target_speed = IDM_CREEP_SPEED;
+                            front_obj = fb.front[1]; front_dist = fb.front_d[1]; steer_lane = nav->target_lane;
+                        } else {
+                            pid->target_speed = IDM_NORMAL_SPEED;
+                            front_obj = fb.front[0]; front_dist = fb.front_d[0];
+                            steer_lane = cur_road->first_lane + tidx - 1;
+                        }
+                    } else { /* change to right */
+                        if (!fb.exist[2]) fail = 1;
+                        else if (fb.back_d[2] < IDM_SAFE_LANE_CHANGE || fb.front_d[2] < 5.0f) {
+                            pid->target_speed = IDM_CREEP_SPEED;
+                            front_obj = fb.front[1]; front_dist = fb.front_d[1]; steer_lane = nav->target_lane;
+                        } else {
+                            pid->target_speed = IDM_NORMAL_SPEED;
+                            front_obj = fb.front[2]; front_dist = fb.front_d[2];
+                            steer_lane = cur_road->first_lane + tidx + 1;
+                        }
+                    }
+                    decided = 1;
+                }
+            }
+            if (!decided && !fail) {
+                int overtake = 0;
+                if (md_fabs(speed_kmh - IDM_NORMAL_SPEED) > 3.0f && fb.front[1] >= 0) {
+                    float fsp = md_fabs(s->dyn[base + fb.front[1]].speed) * 3.6f;
+                    if (md_fabs(fsp - IDM_NORMAL_SPEED) > 3.0f && nav->timer > IDM_LANE_CHANGE_FREQ) overtake = 1;
+                }
+                if (overtake) {
+                    /* speeds of neighbours; -1 encodes None */
+                    float right_sp = -1.0f, left_sp = -1.0f;
+                    if (fb.front[2] >= 0) right_sp = md_fabs(s->dyn[base + fb.front[2]].speed) * 3.6f;
+                    else if (fb.exist[2] && fb.front_d[2] > IDM_SAFE_LANE_CHANGE && fb.back_d[2] > IDM_SAFE_LANE_CHANGE)
+                        right_sp = IDM_MAX_SPEED;
+                    float front_sp = md_fabs(s->dyn[base + fb.front[1]].speed) * 3.6f;
+                    if (fb.front[0] >= 0) left_sp = md_fabs(s->dyn[base + fb.front[0]].speed) * 3.6f;
+                    else if (fb.exist[0] && fb.front_d[0] > IDM_SAFE_LANE_CHANGE && fb.back_d[0] > IDM_SAFE_LANE_CHANGE)
+                        left_sp = IDM_MAX_SPEED;
+                    if (left_sp >= 0.0f && left_sp - front_sp > IDM_LANE_CHANGE_SPEED_INC) {
+                        int ex = tidx - 1;
+                        if (ex >= avail_lo && ex <= avail_hi) {
+                            front_obj = fb.front[0]; front_dist = fb.front_d[0];
+                            steer_lane = cur_road->first_lane + ex;
+                            decided = 1;
+                        }
+                    }
+                    if (!decided && right_sp >= 0.0f && right_sp - front_sp > IDM_LANE_CHANGE_SPEED_INC) {
+                        int ex = tidx + 1;
+                        if (ex >= avail_lo && ex <= avail_hi) {
+                            front_obj = fb.front[2]; front_dist = fb.front_d[2];
+                            steer_lane = cur_road->first_lane + ex;
+                            decided = 1;
+                        }
+                    }
+                }
+                if (!decided) {
+                    pid->target_speed = IDM_NORMAL_SPEED;
+                    nav->timer += 1;
+                    front_obj = fb.front[1]; front_dist = fb.front_d[1]; steer_lane = nav->target_lane;
+                }
+            }
+        } else {
+            md_find_front_back(s, c, lanes, base, slot, cand, nav->target_lane, 0, cur_road, px, py, &fb);
+            front_obj = fb.front[1];
+            front_dist = fb.front_d[1];
+            steer_lane = nav->target_lane;
+        }
+    }
+    if (fail) { /* bare except fallback (idm_policy.py:254-260) */
+        front_obj = -1;
+        front_dist = 5.0f;
+        steer_lane = nav->target_lane;
+    }
+    if (steer_lane < 0) { /* never localised: coast straight */
+        s->action[2 * n] = 0.0f;
+        s->action[2 * n + 1] = 0.0f;
+        return;
+    }
+    /* ---- steering_control (idm_policy.py:293-301) ---- */
+    const MdLane* TL = &lanes[steer_lane];
+    float tl_s, tl_lat;
+    md_lane_local(TL, px, py, &tl_s, &tl_lat);
+    float lane_heading = md_lane_heading_at(TL, tl_s + 1.0f);
+    float steering = md_pid(&pid->hp, &pid->hi, &pid->hd, 1.7f, 0.01f, 3.5f, -md_wrap_to_pi(lane_heading - d->heading));
+    steering += md_pid(&pid->lp, &pid->li, &pid->ld, 0.3f, 0.002f, 0.05f, -tl_lat);
+    /* ---- acceleration (idm_policy.py:303-320) ---- */
+    float dv = 0.0f;
+    if (front_obj >= 0) {
+        const MdShape* fo = &s->shape[base + front_obj];
+        float fv = (md_kind_of(fo->flags) == MD_KIND_VEHICLE) ? s->dyn[base + front_obj].speed : 0.0f;
+        float evx = d->speed * sh->c * 3.6f, evy = d->speed * sh->s * 3.6f;
+        float fvx = fv * fo->c * 3.6f, fvy = fv * fo->s * 3.6f;
+        dv = (evx - fvx) * sh->c + (evy - fvy) * sh->s;
+    }
+    float acc = md_idm_acceleration(speed_kmh, pid->target_speed, front_obj >= 0, front_dist, dv);
+    s->action[2 * n] = steering;
+    s->action[2 * n + 1] = acc;
+}
+
+
+#endif /* MD_ENTITY_H */

@@ -1,0 +1,317 @@
+/*
+ * mdstep.h -- C-ABI of libmdstep.so: the MI355X (gfx950) batched MetaDrive step() hot path.
+ *
+ * The reference (zhuhaozh/metadrive_ped, MetaDrive v0.4.2.2) has no FFI: its hot path is Python
+ * calling Bullet through the panda3d binding.  Each entry point below names the reference call
+ * site(s) it replaces (paths relative to /root/reference/metadrive).  INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Every data pointer is a DEVICE pointer owned by the
+ *    caller (PyTorch-ROCm tensors); the library borrows it for the duration of the call, never
+ *    allocates, never frees, never synchronises.  Launches are asynchronous on `stream`
+ *    (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *  - The MdWorld / MdState / MdConfig structs themselves live in HOST memory and are copied by
+ *    value into the kernel arguments.
+ *  - Return value: MD_OK (0) or a negative MD_E* code.  No exceptions cross the boundary.
+ *    md_last_error() returns a static, thread-local description of the last failure.
+ *  - Layout: E environments, each with `cap` mover slots.  Mover n = env * cap + slot.  Slots
+ *    [0, agents_per_env) are the controlled agents (BaseVehicle driven by EnvInputPolicy), the rest are
+ *    traffic vehicles (IDMPolicy) and static props.  All per-mover arrays are indexed by n.
+ *  - Coordinates follow the reference's 2-D convention: x forward / y left, heading counter-
+ *    clockwise in radians (utils/coordinates_shift.py:8-31); lane lateral is positive to the RIGHT
+ *    (component/lane/straight_lane.py:46,69-74).
+ */
+#ifndef MDSTEP_H
+#define MDSTEP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MD_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------------- */
+#define MD_OK 0
+#define MD_EINVAL (-1)   /* bad argument (null pointer, non-positive size, cap too large ...) */
+#define MD_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError reported a failure               */
+#define MD_ENODEV (-3)   /* no usable gfx950 device                                           */
+#define MD_EABI (-4)     /* struct size mismatch between caller and library                   */
+
+/* ---- limits ------------------------------------------------------------------------------ */
+#define MD_MAX_CAP 128        /* mover slots per env the kernels are built for                  */
+#define MD_MAX_BEAMS 1024     /* lidar beams per agent                                          */
+#define MD_ROUTE_LEN 24       /* checkpoints (road nodes) per route                             */
+#define MD_IDM_RAND 8         /* pre-drawn lane-change timer values per traffic vehicle         */
+
+/* ---- mover kinds (MdShape.flags bits 0..3) ------------------------------------------------ */
+#define MD_KIND_NONE 0
+#define MD_KIND_VEHICLE 1     /* box  W x L   component/vehicle/base_vehicle.py:588              */
+#define MD_KIND_CONE 2        /* circle r=0.2 component/static_object/traffic_object.py:43-84    */
+#define MD_KIND_WARNING 3     /* circle r=0.5 component/static_object/traffic_object.py:87-127   */
+#define MD_KIND_BARRIER 4     /* box 0.3x2.0  component/static_object/traffic_object.py:130-177  */
+#define MD_KIND_PEDESTRIAN 5  /* circle r=.35 component/traffic_participants/pedestrian.py:12-30 */
+#define MD_KIND_CYCLIST 6     /* box          component/traffic_participants/cyclist.py:28       */
+#define MD_KIND_MASK 0xF
+#define MD_F_ALIVE 0x10       /* present in the world this step                                 */
+#define MD_F_AGENT 0x20       /* slot is a controlled agent                                     */
+#define MD_F_PENDING 0x40     /* traffic vehicle waiting for its block's trigger road            */
+#define MD_F_STATIC 0x80      /* never integrated (props, broken-down vehicles)                 */
+#define MD_F_CRASHED_ONCE 0x100 /* COST_ONCE object already counted (traffic_object.py)         */
+
+/* ---- per-step flag word (MdState.flags) --------------------------------------------------- */
+#define MD_FL_CRASH_VEHICLE 0x0001
+#define MD_FL_CRASH_OBJECT 0x0002
+#define MD_FL_CRASH_HUMAN 0x0004
+#define MD_FL_CRASH_BUILDING 0x0008
+#define MD_FL_CRASH_SIDEWALK 0x0010
+#define MD_FL_ON_WHITE_CONT 0x0020
+#define MD_FL_ON_YELLOW_CONT 0x0040
+#define MD_FL_ON_BROKEN 0x0080
+#define MD_FL_ON_CROSSWALK 0x0100
+#define MD_FL_ON_LANE 0x0200
+#define MD_FL_OUT_OF_ROUTE 0x0400
+#define MD_FL_OUT_OF_ROAD 0x0800
+#define MD_FL_ARRIVE_DEST 0x1000
+#define MD_FL_MAX_STEP 0x2000
+#define MD_FL_TERMINATED 0x4000
+#define MD_FL_TRUNCATED 0x8000
+
+/* ---- static quad kinds (MdWorld.quad_kind) ------------------------------------------------ */
+#define MD_Q_LINE_WHITE_CONT 1   /* LINE_SOLID_SINGLE_WHITE  block/base_block.py:487-492         */
+#define MD_Q_LINE_YELLOW_CONT 2  /* LINE_SOLID_SINGLE_YELLOW                                     */
+#define MD_Q_LINE_BROKEN 3       /* LINE_BROKEN_SINGLE_*                                         */
+#define MD_Q_SIDEWALK 4          /* BOUNDARY_SIDEWALK strip   pgblock/pg_block.py:294-332        */
+#define MD_Q_CROSSWALK 5
+
+/* 32-byte shape record: what lidar and contact tests read.  One per mover. */
+typedef struct MdShape {
+    float cx, cy;   /* centre                                                     */
+    float c, s;     /* cos / sin of heading                                       */
+    float hl, hw;   /* half length (along heading) / half width; circle: hl=hw=r  */
+    int32_t flags;  /* MD_KIND_* | MD_F_*                                         */
+    int32_t aux;    /* lane id (map-local) the object sits on, -1 if unknown      */
+} MdShape;
+
+/* 32-byte dynamic record. */
+typedef struct MdDyn {
+    float heading;  /* psi, radians                                               */
+    float speed;    /* signed forward speed, m/s                                  */
+    float steering; /* last applied steering action in [-1,1] (vehicle.steering)  */
+    float throttle; /* last applied throttle/brake action in [-1,1]               */
+    float last_x, last_y;  /* position before this step (vehicle.last_position)   */
+    float last_c, last_s;  /* heading dir before this step (last_heading_dir)     */
+} MdDyn;
+
+/* 32-byte vehicle parameter record (kinematic stand-in for btRaycastVehicle). */
+typedef struct MdParam {
+    float max_steer;     /* rad: config max_steering deg -> rad  (pg_space.py:226-272)          */
+    float accel_gain;    /* m/s^2 at throttle=1: 4*max_engine_force/mass                        */
+    float brake_gain;    /* m/s^2 at brake=1:    4*max_brake_force/(mass*substep_dt), capped    */
+    float roll_decel;    /* m/s^2 idle brake 2.0 (base_vehicle.py:473)                          */
+    float max_speed_kmh; /* engine cut above this (base_vehicle.py:474)                         */
+    float lf, lr;        /* FRONT_WHEELBASE / REAR_WHEELBASE (vehicle_type.py)                  */
+    float fric_decel;    /* wheel_friction * g cap on brake decel                               */
+} MdParam;
+
+/* 64-byte navigation / policy integer state. */
+typedef struct MdNav {
+    int32_t lane;        /* current lane (map-local id) or -1 (vehicle.lane)                    */
+    int32_t ck0, ck1;    /* _target_checkpoints_index (node_network_navigation.py:99)           */
+    int32_t route_len;   /* number of checkpoints (nodes) in the route                          */
+    int32_t target_lane; /* IDMPolicy.routing_target_lane or -1  (idm_policy.py:226)            */
+    int32_t timer;       /* IDMPolicy.overtake_timer                                            */
+    int32_t trigger_road;/* traffic: road id whose entry by an agent activates this vehicle     */
+    int32_t trigger_order;/* traffic: block index; blocks are triggered in ascending order      */
+    int32_t steps;       /* episode_lengths[agent]                                              */
+    int32_t rand_cursor; /* next entry of MdState.idm_rand to consume                           */
+    int32_t done;        /* sticky BaseEnv.dones[agent] (envs/base_env.py:600)                  */
+    int32_t spare[5];
+} MdNav;
+
+/* 32-byte IDM controller state (PID_controller.py:1-22, idm_policy.py:226-233). */
+typedef struct MdPid {
+    float hp, hi, hd;    /* heading PID p/i/d errors                                            */
+    float lp, li, ld;    /* lateral PID p/i/d errors                                            */
+    float target_speed;  /* km/h (NORMAL_SPEED 30 / CREEP_SPEED 5)                              */
+    float energy;        /* episode energy consumption                                          */
+} MdPid;
+
+/* 128-byte lane record (component/lane/straight_lane.py, circular_lane.py). */
+typedef struct MdLane {
+    int32_t type;        /* 0 straight, 1 circular                                              */
+    int32_t road;        /* map-local road id                                                   */
+    int32_t idx;         /* index inside the road (0 = leftmost)                                */
+    int32_t n_in_road;   /* lanes in that road                                                  */
+    float ax, ay;        /* straight: start ; circular: centre                                  */
+    float bx, by;        /* straight: unit direction ; circular: radius, start_phase (wrapped)  */
+    float length, width;
+    float end_phase;     /* circular: start_phase -/+ angle (not wrapped)                       */
+    float dirsign;       /* circular: -1 clockwise, +1 counter-clockwise ; straight: 0          */
+    float angle;         /* circular: swept angle (rad)                                         */
+    float heading;       /* straight: atan2(dir)                                                */
+    float sx, sy, ex, ey;/* centre-line start / end points                                      */
+    float x0, y0, x1, y1;/* AABB of the lane's convex hull                                      */
+    int32_t hull_off;    /* offset (vertices) into MdWorld.hull_xy                              */
+    int32_t hull_n;      /* vertices in the hull (CCW)                                          */
+    float end_phase_w;   /* circular: wrap_to_pi(end_phase)                                     */
+    float spare0;
+    float elx, ely;      /* unit lateral (right-hand) vector at the lane end: position(L, lat) = e + lat*el */
+    float spare[4];
+} MdLane;
+
+/* 32-byte road record (component/road_network/road.py). */
+typedef struct MdRoad {
+    int32_t first_lane;  /* map-local id of lane 0                                              */
+    int32_t n_lanes;
+    int32_t start_node, end_node; /* map-local node ids                                         */
+    int32_t negative;    /* Road.is_negative_road()                                             */
+    int32_t block;       /* block index that created the road                                   */
+    int32_t spare[2];
+} MdRoad;
+
+/* 32-byte grid header per map: uniform grid over static geometry (lanes' hulls and quads). */
+typedef struct MdGrid {
+    float x0, y0;        /* lower-left corner                                                   */
+    float inv_cell;      /* 1 / cell size                                                       */
+    int32_t nx, ny;
+    int32_t cell_base;   /* offset of this map's (nx*ny+1) entries in MdWorld.cell_start        */
+    int32_t spare[2];
+} MdGrid;
+
+/* Static world: everything fixed between resets. */
+typedef struct MdWorld {
+    int32_t n_maps;
+    int32_t n_envs;
+    const int32_t* env_map;    /* [n_envs] map id per env                                       */
+    const int32_t* lane_off;   /* [n_maps+1] CSR into lanes                                     */
+    const MdLane* lanes;
+    const float* hull_xy;      /* [2 * n_hull_vertices]                                         */
+    const int32_t* road_off;   /* [n_maps+1] CSR into roads                                     */
+    const MdRoad* roads;
+    const int32_t* quad_off;   /* [n_maps+1] CSR into quads                                     */
+    const float* quads;        /* [n_quads][8] four CCW vertices x0,y0..x3,y3                    */
+    const int32_t* quad_kind;  /* [n_quads] MD_Q_*                                              */
+    const MdGrid* grid;        /* [n_maps]                                                      */
+    const int32_t* cell_start; /* CSR per cell into cell_items                                  */
+    const int32_t* cell_items; /* item = lane id (>=0, map-local) or ~quad id (<0, map-local)   */
+    const int32_t* node_adj_off;   /* [total_nodes+1] CSR: out-neighbours of each node (per map, via node_off) */
+    const int32_t* node_adj;       /* [..] pairs flattened: (to_node, road_id)                  */
+    const int32_t* node_off;       /* [n_maps+1] offset of each map's nodes in node_adj_off     */
+    const float* beam_cs;      /* [n_beams][2] cos/sin of (2*pi*i/n_beams + phase)              */
+} MdWorld;
+
+/* Dynamic state: one entry per mover unless noted. */
+typedef struct MdState {
+    MdShape* shape;
+    MdDyn* dyn;
+    const MdParam* param;
+    MdNav* nav;
+    MdPid* pid;
+    float* action;             /* [N][2] steering, throttle_brake in [-1,1] (agents: caller-written) */
+    const int32_t* route_nodes;/* [N][MD_ROUTE_LEN] checkpoints as map-local node ids            */
+    const int32_t* route_roads;/* [N][MD_ROUTE_LEN] road id of (node j, node j+1), -1 past end   */
+    const int32_t* final_lane; /* [N] map-local id of navigation.final_lane                      */
+    const int32_t* idm_rand;   /* [N][MD_IDM_RAND] pre-drawn np_random.randint(0, 25) values of each IDMPolicy
+                                  (policy/idm_policy.py:285), consumed cyclically                 */
+    uint32_t* flags;           /* [N] MD_FL_*                                                    */
+    float* obs;                /* [n_envs*agents_per_env][obs_dim]                               */
+    float* reward;             /* [n_envs*agents_per_env]                                        */
+    float* cost;               /* [n_envs*agents_per_env]                                        */
+    float* step_info;          /* [n_envs*agents_per_env][8] step_reward, velocity, step_energy, episode_energy, episode_reward, lateral, long, spare */
+    int32_t* need_reset;       /* [n_envs] 1 = restore the env from the snapshot before stepping  */
+    /* reset snapshot (same layouts) restored by md_step when need_reset[e] != 0                  */
+    const MdShape* shape0;
+    const MdDyn* dyn0;
+    const MdNav* nav0;
+    const MdPid* pid0;
+} MdState;
+
+typedef struct MdConfig {
+    int32_t struct_size;       /* sizeof(MdConfig) as the caller sees it (ABI check)             */
+    int32_t n_envs;
+    int32_t agents_per_env;
+    int32_t cap;               /* mover slots per env                                            */
+    int32_t n_beams;           /* lidar num_lasers (0 = lidar off)                               */
+    int32_t obs_dim;           /* 19 + n_beams                                                   */
+    int32_t substeps;          /* decision_repeat (envs/base_env.py:186)  = 5                     */
+    int32_t horizon;           /* 0 = None                                                       */
+    float dt;                  /* physics_world_step_size (envs/base_env.py:185) = 0.02          */
+    float lidar_range;         /* vehicle_config.lidar.distance = 50                             */
+    /* reward scheme (envs/metadrive_env.py:69-77) */
+    float success_reward, out_of_road_penalty, crash_vehicle_penalty, crash_object_penalty;
+    float driving_reward, speed_reward;
+    /* cost scheme (envs/metadrive_env.py:79-82) */
+    float crash_vehicle_cost, crash_object_cost, out_of_road_cost;
+    /* termination scheme (envs/metadrive_env.py:84-89, base_env.py:80-81) */
+    int32_t use_lateral_reward;
+    int32_t out_of_route_done, on_continuous_line_done;
+    int32_t crash_vehicle_done, crash_object_done, crash_human_done;
+    int32_t truncate_as_terminate;
+    int32_t traffic_mode;      /* 0 trigger, 1 respawn, 2 hybrid (manager/traffic_manager.py:20-29) */
+    int32_t enable_idm_lane_change;
+    int32_t auto_reset;        /* 1: md_step restores envs whose need_reset flag is set          */
+    float max_lane_width;      /* BaseMap.MAX_LANE_WIDTH 4.5                                     */
+    float total_width;         /* (MAX_LANE_NUM+1)*MAX_LANE_WIDTH = 18 (state_obs.py:92)          */
+    float curve_radius_max;    /* BlockParameterSpace.CURVE radius max = 60                      */
+    float curve_angle_max;     /* BlockParameterSpace.CURVE angle max = 135 (deg)                */
+} MdConfig;
+
+/* ---- entry points ------------------------------------------------------------------------- */
+
+/* ABI self-description: fills sizes[0..9] = sizeof(MdShape, MdDyn, MdParam, MdNav, MdPid, MdLane,
+ * MdRoad, MdGrid, MdWorld, MdState, MdConfig)[i]; returns MD_ABI_VERSION. */
+int md_abi(int32_t* sizes, int n);
+const char* md_last_error(void);
+
+/* Lidar: Lidar.perceive / perceive()  component/sensors/lidar.py:49-73,
+ * component/sensors/distance_detector.py:27-85, utils/math.py:76-81.
+ * For agent a of env e: out[(e*A+a)*out_stride + out_offset + i] = closest hit fraction in [0,1]
+ * of beam i against the env's alive movers except its own chassis; 1.0 = no hit. */
+int md_lidar(const MdWorld* w, const MdState* s, const MdConfig* c, float* out, int out_stride, int out_offset,
+             void* stream);
+
+/* Side / lane-line detectors: DistanceDetector.perceive with the static line boxes as targets
+ * (component/sensors/distance_detector.py:194-209; obs/state_obs.py:77-86,129-140).
+ * kind_mask selects MD_Q_* kinds (bit k set = kind k is a target). beam table = beam_cs. */
+int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c, const float* beam_cs, int n_beams,
+                     float range, uint32_t kind_mask, float* out, int out_stride, int out_offset, void* stream);
+
+/* Dynamics: BaseVehicle.before_step/_set_action/_apply_throttle_brake (component/vehicle/
+ * base_vehicle.py:211-232,447-484) + EngineCore.step_physics_world x decision_repeat
+ * (engine/core/engine_core.py:350-352, engine/base_engine.py:417-445). Kinematic bicycle. */
+int md_integrate(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* Lane localisation + checkpoint advance: ray_localization (utils/pg/utils.py:151-203),
+ * NodeNetworkNavigation._get_current_lane/_update_current_lane/_update_target_checkpoints
+ * (component/navigation_module/node_network_navigation.py:181-241,294-304). */
+int md_localize(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* Contacts: collision_callback (engine/core/collision_callback.py:5-42) + BaseVehicle._state_check
+ * (component/vehicle/base_vehicle.py:700-767) + rect_region_detection (utils/pg/utils.py:213-256). */
+int md_contacts(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* Observation(19 dims) + reward + cost + done: StateObservation.vehicle_state (obs/state_obs.py:64-151),
+ * _get_info_for_checkpoint (node_network_navigation.py:243-292), MetaDriveEnv.reward_function /
+ * cost_function / done_function (envs/metadrive_env.py:128-279), _get_step_return
+ * (envs/base_env.py:586-623). */
+int md_observe(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* IDM traffic policy + trigger activation: PGTrafficManager.before_step
+ * (manager/traffic_manager.py:74-92), IDMPolicy.act (policy/idm_policy.py:235-402). */
+int md_idm(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* Traffic removal after the step: PGTrafficManager.after_step (manager/traffic_manager.py:94-122). */
+int md_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* One whole env.step() for all envs: BaseEnv.step (envs/base_env.py:426-463,586-623) =
+ * [auto-reset] -> idm -> integrate -> localize -> contacts -> traffic_after_step -> observe -> lidar,
+ * fused into ONE launch (one workgroup per env, state staged in LDS). */
+int md_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDSTEP_H */

@@ -1,0 +1,145 @@
+"""Configuration of the batched envs: the reference's config keys for this path, same defaults.
+
+Mirrors the layering BASE_DEFAULT_CONFIG -> METADRIVE_DEFAULT_CONFIG -> user dict
+(metadrive/envs/base_env.py:32-266, envs/metadrive_env.py:16-99) and the Config class's contract
+(utils/config.py:23-38,125): an unknown key raises KeyError, a value whose type differs from the
+default's raises TypeError.  Keys of the reference that belong to subsystems outside the hot path
+(rendering, cameras, recording ...) are accepted only at their default "off" value and rejected
+loudly otherwise, so a reference config either behaves the same or fails -- never silently differs.
+Batched-engine extras are grouped at the end.
+"""
+import copy
+
+from metadrive_ped_amd.mapgen.pg import BlockDist
+
+DEFAULT_AGENT = "default_agent"
+
+BASE_DEFAULT_CONFIG = dict(
+    # ===== agent =====
+    random_agent_model=False,
+    num_agents=1,
+    is_multi_agent=False,
+    allow_respawn=False,
+    delay_done=0,
+    # ===== action =====
+    discrete_action=False,
+    use_multi_discrete=False,
+    discrete_steering_dim=5,
+    discrete_throttle_dim=5,
+    action_check=False,
+    # ===== termination =====
+    horizon=None,
+    truncate_as_terminate=False,
+    # ===== vehicle =====
+    vehicle_config=dict(
+        vehicle_model="default",
+        enable_reverse=False,
+        spawn_lane_index=None,
+        destination=None,
+        spawn_longitude=5.0,
+        spawn_lateral=0.0,
+        lidar=dict(num_lasers=240, distance=50, num_others=0, gaussian_noise=0.0, dropout_prob=0.0,
+                   add_others_navi=False),
+        side_detector=dict(num_lasers=0, distance=50, gaussian_noise=0.0, dropout_prob=0.0),
+        lane_line_detector=dict(num_lasers=0, distance=20, gaussian_noise=0.0, dropout_prob=0.0),
+    ),
+    # ===== engine =====
+    use_render=False,
+    image_observation=False,
+    physics_world_step_size=2e-2,
+    decision_repeat=5,
+    map_region_size=1024,
+    log_level=20,
+)
+
+METADRIVE_DEFAULT_CONFIG = dict(
+    start_seed=0,
+    num_scenarios=1,
+    map=3,
+    block_dist_config=None,  # None -> BLOCK_TYPE_DISTRIBUTION_V2
+    random_lane_width=False,
+    random_lane_num=False,
+    map_config=dict(type="block_num", config=None, lane_width=3.5, lane_num=3, exit_length=50),
+    store_map=True,
+    traffic_density=0.1,
+    need_inverse_traffic=False,
+    traffic_mode="trigger",
+    random_traffic=False,
+    accident_prob=0.0,
+    static_traffic_object=True,
+    random_spawn_lane_index=True,
+    agent_configs={DEFAULT_AGENT: dict(spawn_lane_index=(">", ">>", 0))},
+    success_reward=10.0,
+    out_of_road_penalty=5.0,
+    crash_vehicle_penalty=5.0,
+    crash_object_penalty=5.0,
+    driving_reward=1.0,
+    speed_reward=0.1,
+    use_lateral_reward=False,
+    crash_vehicle_cost=1.0,
+    crash_object_cost=1.0,
+    out_of_road_cost=1.0,
+    out_of_route_done=False,
+    on_continuous_line_done=True,
+    crash_vehicle_done=True,
+    crash_object_done=True,
+    crash_human_done=True,
+    enable_idm_lane_change=True,
+)
+
+# batched-engine keys (no counterpart in the reference: it steps one world per process)
+BATCH_DEFAULT_CONFIG = dict(
+    num_envs=1,             # E: environments stepped in lockstep by this process (this GPU's shard)
+    env_seed_offset=0,      # global index of this shard's first env (seed = start_seed + (offset + e) % num_scenarios)
+    mover_capacity=64,      # slots per env: agents + traffic + props
+    auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
+    device="cuda:0",
+)
+
+_OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False, discrete_action=False,
+                 use_multi_discrete=False, random_lane_width=False, random_lane_num=False,
+                 need_inverse_traffic=False, random_traffic=False, accident_prob=0.0)
+
+
+def _merge(dst, src, path=""):
+    for k, v in src.items():
+        if k not in dst:
+            raise KeyError("'{}{}' does not exist in existing config. Please use config.update(..., allow_add_new_key="
+                           "True) to allow new keys -- unknown config key".format(path, k))
+        if isinstance(dst[k], dict) and isinstance(v, dict) and k != "agent_configs":
+            _merge(dst[k], v, path + k + ".")
+        else:
+            old = dst[k]
+            if old is not None and v is not None and not isinstance(old, dict):
+                ok = isinstance(v, type(old)) or (isinstance(old, float) and isinstance(v, int)) or \
+                    (k == "map" and isinstance(v, (int, str))) or (k == "horizon")
+                if not ok:
+                    raise TypeError("Attempting to update '{}{}' with type {}, expected {}".format(
+                        path, k, type(v).__name__, type(old).__name__))
+            dst[k] = v
+
+
+def make_config(user=None):
+    cfg = copy.deepcopy(BASE_DEFAULT_CONFIG)
+    cfg.update(copy.deepcopy(METADRIVE_DEFAULT_CONFIG))
+    cfg.update(copy.deepcopy(BATCH_DEFAULT_CONFIG))
+    _merge(cfg, dict(user or {}))
+    for k, off in _OFF_ONLY.items():
+        if cfg[k] != off:
+            raise NotImplementedError("config['{}']={!r}: this option lies outside the batched step() path built so far "
+                                      "(only {!r} is accepted)".format(k, cfg[k], off))
+    # parse_map_config (component/map/pg_map.py:17-36): `map` shorthand fills map_config
+    m = cfg["map"]
+    if isinstance(m, int):
+        cfg["map_config"]["type"], cfg["map_config"]["config"] = "block_num", m
+    elif isinstance(m, str):
+        cfg["map_config"]["type"], cfg["map_config"]["config"] = "block_sequence", m
+    else:
+        raise ValueError("Unknown easy map config: {}".format(m))
+    if cfg["block_dist_config"] is None:
+        cfg["block_dist_config"] = BlockDist()
+    elif isinstance(cfg["block_dist_config"], dict):
+        cfg["block_dist_config"] = BlockDist(cfg["block_dist_config"])
+    if cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]:
+        raise ValueError("mover_capacity must be in [num_agents, 128]")
+    return cfg

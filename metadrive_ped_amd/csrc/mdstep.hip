@@ -1,0 +1,649 @@
+// mdstep.hip -- gfx950 (MI355X / CDNA4) kernels + C-ABI launchers of the batched MetaDrive step().
+//
+// One workgroup (256 threads = 4 wave64) owns one environment for the whole step; phases are
+// separated by workgroup barriers and never talk to other workgroups, so a step is ONE launch with
+// no inter-workgroup traffic, no atomics and no grid-level synchronisation:
+//
+//   reset -> IDM(+trigger) -> integrate -> localize -> contacts -> traffic removal -> observe -> lidar
+//
+// Work shapes (wave64-native, none of this is a warp-32 tiling):
+//   * lidar     : one wave per (agent, 64-beam sector).  Each LANE first loads ONE mover record
+//                 (32 B, coalesced), culls it against range + the sector's cone, the survivors are
+//                 collected with a 64-bit ballot and broadcast lane->wave with v_readlane; each lane
+//                 then tests ITS beam against the surviving shapes.  No LDS, no atomics.
+//   * localize  : one wave per vehicle; candidate lanes come from the static grid cell under the
+//                 vehicle; the convex-hull containment test spreads hull edges over the 64 lanes and
+//                 votes with a ballot.
+//   * contacts  : one wave per vehicle; lanes = the other movers (SAT each), then lanes = quads of
+//                 the grid cells under the chassis AABB; flag words are OR-combined by ballots.
+//   * trigger   : wavefront min-reduce (DPP shuffles) over the pending traffic blocks.
+//   * integrate / observe / IDM : one thread per entity over include/md_entity.h.
+//
+// There is no dense contraction anywhere on this path, hence no MFMA.  The arithmetic formulas are
+// the shared include/md_geom.h / md_entity.h ones (bit-exact vs the CPU oracle, -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "md_entity.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+enum Phase : int {
+    PH_RESET = 1,
+    PH_IDM = 2,
+    PH_INTEGRATE = 4,
+    PH_LOCALIZE = 8,
+    PH_CONTACTS = 16,
+    PH_TRAFFIC = 32,
+    PH_OBSERVE = 64,
+    PH_LIDAR = 128,
+    PH_ALL = 255,
+};
+
+thread_local char g_err[256] = "ok";
+
+__device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lidar for one (agent, sector) work item, executed by one wave.
+// ------------------------------------------------------------------------------------------------
+__device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int a, int sec, int lane,
+                           float* __restrict__ out_row) {
+    const int base = e * c.cap;
+    const MdShape me = s.shape[base + a];  // wave-uniform
+    const int beam = sec * 64 + lane;
+    const bool valid = beam < c.n_beams;
+    if (!md_present(me.flags)) {
+        if (valid) out_row[beam] = 1.0f;
+        return;
+    }
+    float bc = 1.0f, bs = 0.0f;
+    if (valid) {
+        bc = w.beam_cs[2 * beam];
+        bs = w.beam_cs[2 * beam + 1];
+    }
+    const float dirx = (bc * me.c - bs * me.s) * c.lidar_range;
+    const float diry = (bs * me.c + bc * me.s) * c.lidar_range;
+
+    // sector cone: axis = direction of the middle of the sector, half-span h (conservative cull only)
+    const int nb = min(64, c.n_beams - sec * 64);
+    const int first = sec * 64, last = first + nb - 1;
+    // axis from the sum of the first and last beam directions (exact bisector), ego frame -> world
+    float ax = w.beam_cs[2 * first] + w.beam_cs[2 * last];
+    float ay = w.beam_cs[2 * first + 1] + w.beam_cs[2 * last + 1];
+    float cos_h;  // cos of half-span
+    {
+        float dotfl = w.beam_cs[2 * first] * w.beam_cs[2 * last] + w.beam_cs[2 * first + 1] * w.beam_cs[2 * last + 1];
+        // span = angle(first,last) could exceed pi: count beams instead
+        float span = MD_TWO_PI_F * (float)(nb - 1) / (float)c.n_beams;
+        float sh_, ch_;
+        md_sincos(0.5f * span, &sh_, &ch_);
+        cos_h = ch_;
+        if (span > MD_PI_F) {  // bisector of first/last points the wrong way
+            ax = -ax;
+            ay = -ay;
+        }
+        (void)dotfl;
+        float an = md_norm(ax, ay);
+        if (an < 1e-6f) {  // span == pi exactly: use the middle beam
+            int mid = (first + last) / 2;
+            ax = w.beam_cs[2 * mid];
+            ay = w.beam_cs[2 * mid + 1];
+            an = 1.0f;
+        }
+        ax /= an;
+        ay /= an;
+    }
+    const float sin_h = md_sqrt(md_max(0.0f, 1.0f - cos_h * cos_h));
+    const float half_span = MD_TWO_PI_F * (float)(nb - 1) / (float)c.n_beams * 0.5f;
+    const float wax = ax * me.c - ay * me.s;  // axis in world frame
+    const float way = ay * me.c + ax * me.s;
+
+    float best = 1.0f;
+    for (int j0 = 0; j0 < c.cap; j0 += 64) {
+        const int j = j0 + lane;
+        MdShape o;
+        o.flags = 0;
+        if (j < c.cap) o = s.shape[base + j];
+        bool keep = (j < c.cap) && (j != a) && md_present(o.flags);
+        if (keep) {
+            const float ddx = o.cx - me.cx, ddy = o.cy - me.cy;
+            const float dist = md_norm(ddx, ddy);
+            const int k = md_kind_of(o.flags);
+            const float rb = (md_is_circle_kind(k) ? o.hl : md_norm(o.hl, o.hw)) + 0.01f;
+            if (dist > c.lidar_range + rb) keep = false;
+            else if (dist > rb) {
+                // cone test: angle(d, axis) <= half_span + asin(rb/dist)
+                const float sin_a = rb / dist;
+                const float cos_a = md_sqrt(md_max(0.0f, 1.0f - sin_a * sin_a));
+                const float asin_a = md_asin(sin_a);
+                if (half_span + asin_a < MD_PI_F - 0.01f) {
+                    const float cos_lim = cos_h * cos_a - sin_h * sin_a;  // cos(h + alpha)
+                    const float cos_t = (ddx * wax + ddy * way) / dist;
+                    if (cos_t < cos_lim - 2e-3f) keep = false;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(keep);
+        while (mask) {
+            const int k = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float ocx = bcast_f(o.cx, k), ocy = bcast_f(o.cy, k);
+            const float oc = bcast_f(o.c, k), os = bcast_f(o.s, k);
+            const float ohl = bcast_f(o.hl, k), ohw = bcast_f(o.hw, k);
+            const int ofl = bcast_i(o.flags, k);
+            const float t = md_ray_shape(me.cx, me.cy, dirx, diry, ocx, ocy, oc, os, ohl, ohw, md_kind_of(ofl));
+            if (t < best) best = t;
+        }
+    }
+    if (valid) out_row[beam] = best;
+}
+
+__device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, float* out,
+                            int out_stride, int out_offset) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nsec = (c.n_beams + 63) >> 6;
+    const int items = c.agents_per_env * nsec;
+    for (int it = wave; it < items; it += kWaves) {
+        const int a = it / nsec, sec = it - a * nsec;
+        float* row = out + (size_t)(e * c.agents_per_env + a) * out_stride + out_offset;
+        lidar_item(w, s, c, e, a, sec, lane, row);
+    }
+}
+
+// Side / lane-line detector: beams vs static quads of the env's map (brute force over the map's
+// quads, lanes = beams).  Off in the headline configs; kept simple.
+__global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdState s, MdConfig c,
+                                                               const float* __restrict__ beam_cs, int n_beams,
+                                                               float range, uint32_t kind_mask, float* out,
+                                                               int out_stride, int out_offset) {
+    const int e = blockIdx.x;
+    const int m = w.env_map[e];
+    const int q0 = w.quad_off[m], q1 = w.quad_off[m + 1];
+    for (int it = threadIdx.x; it < c.agents_per_env * n_beams; it += kBlock) {
+        const int a = it / n_beams, i = it - a * n_beams;
+        const MdShape me = s.shape[e * c.cap + a];
+        float best = 1.0f;
+        if (md_present(me.flags)) {
+            const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+            const float dirx = (bc * me.c - bs * me.s) * range;
+            const float diry = (bs * me.c + bc * me.s) * range;
+            for (int q = q0; q < q1; ++q) {
+                if (!((kind_mask >> w.quad_kind[q]) & 1u)) continue;
+                const float t = md_ray_quad(me.cx, me.cy, dirx, diry, w.quads + 8 * (size_t)q);
+                if (t < best) best = t;
+            }
+        }
+        out[(size_t)(e * c.agents_per_env + a) * out_stride + out_offset + i] = best;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grid helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int grid_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ------------------------------------------------------------------------------------------------
+// Localisation, one wave per vehicle.
+// ------------------------------------------------------------------------------------------------
+__device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int n, int lane_id) {
+    const MdShape sh = s.shape[n];
+    if (!md_drives(sh.flags)) return;
+    MdNav nav = s.nav[n];
+    const int m = w.env_map[e];
+    const MdLane* lanes = w.lanes + w.lane_off[m];
+    const int32_t* rroads = s.route_roads + (size_t)n * MD_ROUTE_LEN;
+    const int32_t* rnodes = s.route_nodes + (size_t)n * MD_ROUTE_LEN;
+    const int cur_road = rroads[nav.ck0];
+    const bool has_next = nav.ck1 != nav.ck0;
+    const int next_road = has_next ? rroads[nav.ck1] : -1;
+
+    const MdGrid g = w.grid[m];
+    const int gx = (int)md_floor((sh.cx - g.x0) * g.inv_cell);
+    const int gy = (int)md_floor((sh.cy - g.y0) * g.inv_cell);
+    int it0 = 0, it1 = 0;
+    if (gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) {
+        const int cell = g.cell_base + gy * g.nx + gx;
+        it0 = w.cell_start[cell];
+        it1 = w.cell_start[cell + 1];
+    }
+    int on_lane = 0;
+    int best_any = -1, best_cur = -1, best_next = -1;
+    float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
+    for (int it = it0; it < it1; ++it) {
+        const int l = w.cell_items[it];
+        if (l < 0) continue;  // quad item
+        const MdLane* L = &lanes[l];
+        if (sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1) continue;
+        // hull containment: edges spread over the 64 lanes, ballot vote
+        const float* xy = w.hull_xy + 2 * (size_t)L->hull_off;
+        const int hn = L->hull_n;
+        bool outside = false;
+        for (int i = lane_id; i < hn; i += 64) {
+            const int j = (i + 1 == hn) ? 0 : i + 1;
+            const float ex = xy[2 * j] - xy[2 * i], ey = xy[2 * j + 1] - xy[2 * i + 1];
+            const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
+            if (cr < 0.0f) outside = true;
+        }
+        if (__ballot(outside) != 0ull || hn < 3) continue;
+        on_lane = 1;
+        float ls, llat;
+        md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
+        const float lh = md_lane_heading_at(L, ls);
+        float hs_, hc_;
+        md_sincos(lh, &hs_, &hc_);
+        const float cosangle = hc_ * sh.c + hs_ * sh.s;
+        if (!(cosangle > 0.0f)) continue;
+        const float dist = md_lane_distance(L, ls, llat);
+        if (dist < d_any) { d_any = dist; best_any = l; }
+        if (L->road == cur_road && dist < d_cur) { d_cur = dist; best_cur = l; }
+        if (has_next && L->road == next_road && dist < d_next) { d_next = dist; best_next = l; }
+    }
+    if (lane_id != 0) return;  // everything below is wave-uniform; lane 0 commits
+    int lane = -1;
+    if (best_cur >= 0) lane = best_cur;
+    else if (!has_next) lane = best_any;
+    else if (best_next >= 0) lane = best_next;
+    else lane = best_any;
+    uint32_t fl = s.flags[n] & ~(uint32_t)MD_FL_ON_LANE;
+    if (on_lane) fl |= MD_FL_ON_LANE;
+    s.flags[n] = fl;
+    if (lane < 0) lane = nav.lane;
+    s.nav[n].lane = lane;
+    if (lane < 0) return;
+    if (nav.ck0 == nav.ck1) return;
+    float ls, llat;
+    md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    if (!(ls < 5.0f)) return;
+    const int start_node = w.roads[w.road_off[m] + lanes[lane].road].start_node;
+    const int k = nav.route_len;
+    int idx = -1;
+    for (int j = nav.ck1; j < k - 1; ++j) {
+        if (rnodes[j] == start_node) { idx = j; break; }
+    }
+    if (idx < 0) return;
+    s.nav[n].ck0 = idx;
+    s.nav[n].ck1 = (idx + 1 == k - 1) ? idx : idx + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Contacts, one wave per vehicle.
+// ------------------------------------------------------------------------------------------------
+__device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id) {
+    const int base = e * c.cap;
+    const int n = base + slot;
+    const MdShape me = s.shape[n];
+    if (!md_drives(me.flags)) return;
+    uint32_t fl = 0;
+    for (int j0 = 0; j0 < c.cap; j0 += 64) {
+        const int j = j0 + lane_id;
+        if (j >= c.cap || j == slot) continue;
+        const MdShape o = s.shape[base + j];
+        if (!md_present(o.flags)) continue;
+        const int k = md_kind_of(o.flags);
+        int hit;
+        if (md_is_circle_kind(k)) hit = md_obb_circle(me.cx, me.cy, me.c, me.s, me.hl, me.hw, o.cx, o.cy, o.hl);
+        else hit = md_obb_obb(me.cx, me.cy, me.c, me.s, me.hl, me.hw, o.cx, o.cy, o.c, o.s, o.hl, o.hw);
+        if (!hit) continue;
+        if (k == MD_KIND_VEHICLE) fl |= MD_FL_CRASH_VEHICLE;
+        else if (k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_BARRIER) fl |= MD_FL_CRASH_OBJECT;
+        else if (k == MD_KIND_PEDESTRIAN || k == MD_KIND_CYCLIST) fl |= MD_FL_CRASH_HUMAN;
+    }
+    // static quads through the grid: cells under the chassis AABB (+ margin)
+    const int m = w.env_map[e];
+    const MdGrid g = w.grid[m];
+    const float ext_x = md_fabs(me.c) * me.hl + md_fabs(me.s) * me.hw + 0.05f;
+    const float ext_y = md_fabs(me.s) * me.hl + md_fabs(me.c) * me.hw + 0.05f;
+    int gx0 = (int)md_floor((me.cx - ext_x - g.x0) * g.inv_cell);
+    int gx1 = (int)md_floor((me.cx + ext_x - g.x0) * g.inv_cell);
+    int gy0 = (int)md_floor((me.cy - ext_y - g.y0) * g.inv_cell);
+    int gy1 = (int)md_floor((me.cy + ext_y - g.y0) * g.inv_cell);
+    if (!(gx1 < 0 || gy1 < 0 || gx0 >= g.nx || gy0 >= g.ny)) {
+        gx0 = grid_clampi(gx0, 0, g.nx - 1);
+        gx1 = grid_clampi(gx1, 0, g.nx - 1);
+        gy0 = grid_clampi(gy0, 0, g.ny - 1);
+        gy1 = grid_clampi(gy1, 0, g.ny - 1);
+        const float* quads = w.quads + 8 * (size_t)w.quad_off[m];
+        const int32_t* qkind = w.quad_kind + w.quad_off[m];
+        for (int gy = gy0; gy <= gy1; ++gy)
+            for (int gx = gx0; gx <= gx1; ++gx) {
+                const int cell = g.cell_base + gy * g.nx + gx;
+                const int it0 = w.cell_start[cell], it1 = w.cell_start[cell + 1];
+                for (int it = it0 + lane_id; it < it1; it += 64) {
+                    const int item = w.cell_items[it];
+                    if (item >= 0) continue;  // lane item
+                    const int q = ~item;
+                    if (!md_obb_quad(me.cx, me.cy, me.c, me.s, me.hl, me.hw, quads + 8 * (size_t)q)) continue;
+                    switch (qkind[q]) {
+                        case MD_Q_LINE_WHITE_CONT: fl |= MD_FL_ON_WHITE_CONT; break;
+                        case MD_Q_LINE_YELLOW_CONT: fl |= MD_FL_ON_YELLOW_CONT; break;
+                        case MD_Q_LINE_BROKEN: fl |= MD_FL_ON_BROKEN; break;
+                        case MD_Q_SIDEWALK: fl |= MD_FL_CRASH_SIDEWALK; break;
+                        case MD_Q_CROSSWALK: fl |= MD_FL_ON_CROSSWALK; break;
+                        default: break;
+                    }
+                }
+            }
+    }
+    // wave OR-reduce of the flag word
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fl |= (uint32_t)__shfl_xor((int)fl, off, 64);
+    if (lane_id == 0) s.flags[n] = (s.flags[n] & MD_FL_ON_LANE) | fl;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traffic trigger (wave 0) -- PGTrafficManager.before_step, manager/traffic_manager.py:80-88
+// ------------------------------------------------------------------------------------------------
+__device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int lane_id) {
+    const int base = e * c.cap;
+    const int m = w.env_map[e];
+    const MdLane* lanes = w.lanes + w.lane_off[m];
+    int my_min = 0x7fffffff;
+    for (int j = lane_id; j < c.cap; j += 64) {
+        const int f = s.shape[base + j].flags;
+        if ((f & MD_F_PENDING) && (f & MD_F_ALIVE)) {
+            const int o = s.nav[base + j].trigger_order;
+            my_min = o < my_min ? o : my_min;
+        }
+    }
+    const int min_order = wave_min_i(my_min);  // wavefront min-reduce
+    if (min_order == 0x7fffffff) return;
+    // trigger road of that block: lowest slot carrying min_order
+    int my_slot = 0x7fffffff;
+    for (int j = lane_id; j < c.cap; j += 64) {
+        const int f = s.shape[base + j].flags;
+        if ((f & MD_F_PENDING) && (f & MD_F_ALIVE) && s.nav[base + j].trigger_order == min_order)
+            my_slot = j < my_slot ? j : my_slot;
+    }
+    const int first_slot = wave_min_i(my_slot);
+    const int trig_road = s.nav[base + first_slot].trigger_road;
+    bool fire = false;
+    for (int a = lane_id; a < c.agents_per_env; a += 64) {
+        if (!md_drives(s.shape[base + a].flags)) continue;
+        const int al = s.nav[base + a].lane;
+        if (al >= 0 && lanes[al].road == trig_road) fire = true;
+    }
+    if (__ballot(fire) == 0ull) return;
+    for (int j = lane_id; j < c.cap; j += 64) {
+        const int f = s.shape[base + j].flags;
+        if ((f & MD_F_PENDING) && (f & MD_F_ALIVE) && s.nav[base + j].trigger_order == min_order)
+            s.shape[base + j].flags = f & ~MD_F_PENDING;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The per-env kernel.  PH selects the phases (a compile-time mask: the single-phase entry points
+// instantiate it with one bit, md_step with all of them).
+// ------------------------------------------------------------------------------------------------
+template <int PH>
+__global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState s, MdConfig c, float* lidar_out,
+                                                     int lidar_stride, int lidar_offset) {
+    const int e = blockIdx.x;
+    if (e >= c.n_envs) return;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int base = e * c.cap;
+    __shared__ int sh_just_reset;
+
+    if (tid == 0) sh_just_reset = 0;
+    __syncthreads();
+
+    if (PH & PH_RESET) {
+        if (s.need_reset[e]) {  // uniform per block
+            for (int j = tid; j < c.cap; j += kBlock) {
+                s.shape[base + j] = s.shape0[base + j];
+                s.dyn[base + j] = s.dyn0[base + j];
+                s.nav[base + j] = s.nav0[base + j];
+                s.pid[base + j] = s.pid0[base + j];
+                s.flags[base + j] = 0;
+                s.action[2 * (base + j)] = 0.0f;
+                s.action[2 * (base + j) + 1] = 0.0f;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                s.need_reset[e] = 0;
+                sh_just_reset = 1;
+            }
+        }
+        __syncthreads();
+    }
+    const int just_reset = sh_just_reset;
+
+    if ((PH & PH_IDM) && !just_reset) {
+        if (wave == 0) trigger_env(w, s, c, e, lane);
+        __syncthreads();
+        for (int j = c.agents_per_env + tid; j < c.cap; j += kBlock) {
+            const int f = s.shape[base + j].flags;
+            if (md_drives(f) && !(f & MD_F_AGENT)) md_idm_vehicle(&w, &s, &c, e, j);
+        }
+        __syncthreads();
+    }
+    if ((PH & PH_INTEGRATE) && !just_reset) {
+        for (int j = tid; j < c.cap; j += kBlock) md_integrate_mover(&s, &c, base + j);
+        __syncthreads();
+    }
+    if (PH & PH_LOCALIZE) {
+        for (int j = wave; j < c.cap; j += kWaves) localize_vehicle(w, s, e, base + j, lane);
+        __syncthreads();
+    }
+    if (PH & PH_CONTACTS) {
+        for (int j = wave; j < c.cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
+        __syncthreads();
+    }
+    if (PH & PH_TRAFFIC) {
+        for (int j = tid; j < c.cap; j += kBlock) {
+            const int f = s.shape[base + j].flags;
+            if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[base + j] & MD_FL_ON_LANE))
+                s.shape[base + j].flags = f & ~MD_F_ALIVE;
+        }
+        __syncthreads();
+    }
+    if (PH & PH_OBSERVE) {
+        for (int a = tid; a < c.agents_per_env; a += kBlock) md_observe_agent(&w, &s, &c, e, a, just_reset);
+        // lidar only reads shapes; observe writes obs[0:19], flags, nav -- no barrier needed before lidar
+    }
+    if (PH & PH_LIDAR) {
+        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, lidar_out, lidar_stride, lidar_offset);
+    }
+}
+
+int check_common(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    if (!w || !s || !c) {
+        snprintf(g_err, sizeof g_err, "null MdWorld/MdState/MdConfig pointer");
+        return MD_EINVAL;
+    }
+    if (c->struct_size != (int32_t)sizeof(MdConfig)) {
+        snprintf(g_err, sizeof g_err, "MdConfig.struct_size=%d, library expects %d", c->struct_size, (int)sizeof(MdConfig));
+        return MD_EABI;
+    }
+    if (c->n_envs <= 0 || c->cap <= 0 || c->cap > MD_MAX_CAP || c->agents_per_env <= 0 || c->agents_per_env > c->cap) {
+        snprintf(g_err, sizeof g_err, "bad sizes: n_envs=%d cap=%d agents_per_env=%d (cap<=%d)", c->n_envs, c->cap,
+                 c->agents_per_env, MD_MAX_CAP);
+        return MD_EINVAL;
+    }
+    if (c->n_beams < 0 || c->n_beams > MD_MAX_BEAMS) {
+        snprintf(g_err, sizeof g_err, "n_beams=%d out of range [0,%d]", c->n_beams, MD_MAX_BEAMS);
+        return MD_EINVAL;
+    }
+    if (!s->shape) {
+        snprintf(g_err, sizeof g_err, "MdState.shape is null");
+        return MD_EINVAL;
+    }
+    if (w->n_envs != c->n_envs) {
+        snprintf(g_err, sizeof g_err, "MdWorld.n_envs=%d != MdConfig.n_envs=%d", w->n_envs, c->n_envs);
+        return MD_EINVAL;
+    }
+    return MD_OK;
+}
+
+int need(const void* p, const char* name) {
+    if (p) return MD_OK;
+    snprintf(g_err, sizeof g_err, "required pointer %s is null", name);
+    return MD_EINVAL;
+}
+
+template <int PH>
+int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
+           void* stream) {
+    hipLaunchKernelGGL(env_kernel<PH>, dim3(c->n_envs), dim3(kBlock), 0, (hipStream_t)stream, *w, *s, *c, lidar_out,
+                       stride, offset);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
+
+#define NEED(p)                                  \
+    do {                                         \
+        int _r = need((const void*)(p), #p);     \
+        if (_r != MD_OK) return _r;              \
+    } while (0)
+
+int check_world(const MdWorld* w) {
+    NEED(w->env_map); NEED(w->lane_off); NEED(w->lanes); NEED(w->hull_xy); NEED(w->road_off); NEED(w->roads);
+    NEED(w->quad_off); NEED(w->quads); NEED(w->quad_kind); NEED(w->grid); NEED(w->cell_start); NEED(w->cell_items);
+    return MD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int md_abi(int32_t* sizes, int n) {
+    const int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),
+                           sizeof(MdRoad), sizeof(MdGrid), sizeof(MdWorld), sizeof(MdState), sizeof(MdConfig)};
+    for (int i = 0; sizes && i < n && i < 11; ++i) sizes[i] = v[i];
+    return MD_ABI_VERSION;
+}
+
+__attribute__((visibility("default"))) const char* md_last_error(void) { return g_err; }
+
+__attribute__((visibility("default"))) int md_lidar(const MdWorld* w, const MdState* s, const MdConfig* c, float* out,
+                                                   int out_stride, int out_offset, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    NEED(out); NEED(w->beam_cs);
+    if (c->n_beams <= 0 || out_stride < c->n_beams + out_offset || out_offset < 0) {
+        snprintf(g_err, sizeof g_err, "md_lidar: n_beams=%d stride=%d offset=%d", c->n_beams, out_stride, out_offset);
+        return MD_EINVAL;
+    }
+    return launch<PH_LIDAR>(w, s, c, out, out_stride, out_offset, stream);
+}
+
+__attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                           const float* beam_cs, int n_beams, float range,
+                                                           uint32_t kind_mask, float* out, int out_stride,
+                                                           int out_offset, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    NEED(out); NEED(beam_cs); NEED(w->env_map); NEED(w->quad_off); NEED(w->quads); NEED(w->quad_kind);
+    if (n_beams <= 0 || n_beams > MD_MAX_BEAMS || out_stride < n_beams + out_offset || out_offset < 0 || !(range > 0.0f)) {
+        snprintf(g_err, sizeof g_err, "md_line_detector: n_beams=%d stride=%d offset=%d range=%f", n_beams, out_stride,
+                 out_offset, (double)range);
+        return MD_EINVAL;
+    }
+    hipLaunchKernelGGL(line_detector_kernel, dim3(c->n_envs), dim3(kBlock), 0, (hipStream_t)stream, *w, *s, *c, beam_cs,
+                       n_beams, range, kind_mask, out, out_stride, out_offset);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
+
+__attribute__((visibility("default"))) int md_integrate(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                       void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    NEED(s->dyn); NEED(s->param); NEED(s->action);
+    return launch<PH_INTEGRATE>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_localize(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                      void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->nav); NEED(s->flags); NEED(s->route_nodes); NEED(s->route_roads);
+    return launch<PH_LOCALIZE>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_contacts(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                      void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->flags);
+    return launch<PH_CONTACTS>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_observe(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                     void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->dyn); NEED(s->param); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_roads); NEED(s->final_lane);
+    NEED(s->flags); NEED(s->obs); NEED(s->reward); NEED(s->cost); NEED(s->step_info); NEED(s->need_reset);
+    if (c->obs_dim < 19) {
+        snprintf(g_err, sizeof g_err, "obs_dim=%d < 19", c->obs_dim);
+        return MD_EINVAL;
+    }
+    return launch<PH_OBSERVE>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_idm(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->dyn); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_roads); NEED(s->idm_rand);
+    NEED(w->node_adj_off); NEED(w->node_adj); NEED(w->node_off);
+    return launch<PH_IDM>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                                void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    NEED(s->flags);
+    return launch<PH_TRAFFIC>(w, s, c, nullptr, 0, 0, stream);
+}
+
+__attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->dyn); NEED(s->param); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_nodes); NEED(s->route_roads);
+    NEED(s->final_lane); NEED(s->idm_rand); NEED(s->flags); NEED(s->obs); NEED(s->reward); NEED(s->cost);
+    NEED(s->step_info); NEED(s->need_reset); NEED(w->node_adj_off); NEED(w->node_adj); NEED(w->node_off);
+    if (c->n_beams > 0) NEED(w->beam_cs);
+    NEED(s->shape0); NEED(s->dyn0); NEED(s->nav0); NEED(s->pid0);
+    if (c->obs_dim != 19 + c->n_beams) {
+        snprintf(g_err, sizeof g_err, "obs_dim=%d != 19 + n_beams=%d", c->obs_dim, c->n_beams);
+        return MD_EINVAL;
+    }
+    return launch<PH_ALL>(w, s, c, s->obs, c->obs_dim, 19, stream);
+}
+
+}  // extern "C"

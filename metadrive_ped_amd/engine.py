@@ -1,0 +1,206 @@
+"""BatchedEngine: the host side of the batched step().  Owns every table and state array as
+PyTorch-ROCm tensors (device memory + streams are torch's job; arithmetic is the HIP library's) and
+drives the C-ABI.  Plays the role of BaseEngine + the manager chain for E lock-stepped worlds
+(metadrive/engine/base_engine.py:306-478): reset() builds the scenes on the host with numpy
+RandomState streams, step() is ONE md_step launch.
+
+Sharding: an engine owns envs [env_seed_offset, env_seed_offset + num_envs) of the global batch;
+env g uses scenario seed start_seed + g % num_scenarios, so results do not depend on how many
+GPUs the batch is split over.
+"""
+import ctypes as C
+
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.mapgen.pg import PGMap
+from metadrive_ped_amd.mapgen.tables import MapTables, WorldTables, beam_table
+from metadrive_ped_amd.scene import EnvScene
+
+STATE_ARRAY_SPECS = None  # filled below
+
+
+class HostScene:
+    """Host (numpy) copy of everything: world tables + reset snapshot.  Also what the tests hand to
+    the CPU oracle."""
+    def __init__(self, cfg):
+        self.cfg = cfg
+        E = cfg["num_envs"]
+        cap = cfg["mover_capacity"]
+        A = cfg["num_agents"]
+        self.E, self.cap, self.A = E, cap, A
+        self.n_beams = int(cfg["vehicle_config"]["lidar"]["num_lasers"]) if cfg["vehicle_config"]["lidar"]["distance"] > 0 else 0
+        self.obs_dim = 19 + self.n_beams
+        mc = cfg["map_config"]
+        seeds = [cfg["start_seed"] + ((cfg["env_seed_offset"] + e) % cfg["num_scenarios"]) for e in range(E)]
+        self.seeds = seeds
+        uniq = sorted(set(seeds))
+        map_of_seed = {}
+        tables, scenes = [], {}
+        scene_cfg = dict(cap=cap, agents_per_env=A, physics_world_step_size=cfg["physics_world_step_size"],
+                         random_spawn_lane_index=cfg["random_spawn_lane_index"],
+                         spawn_lane_index=cfg["agent_configs"]["default_agent"]["spawn_lane_index"],
+                         agent_vehicle_model=cfg["vehicle_config"]["vehicle_model"],
+                         spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
+                         spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
+                         traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"])
+        for s in uniq:
+            pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+                       generate_type=mc["type"], generate_config=mc["config"], block_dist=cfg["block_dist_config"])
+            mt = MapTables(pg)
+            map_of_seed[s] = len(tables)
+            tables.append(mt)
+            scenes[s] = EnvScene(s, mt, scene_cfg)
+        self.map_tables = tables
+        self.scenes = scenes
+        env_map = [map_of_seed[s] for s in seeds]
+        self.world = WorldTables(tables, env_map, beam_table(self.n_beams))
+        N = E * cap
+
+        def stack(field):
+            return np.concatenate([getattr(scenes[s], field) for s in seeds], axis=0)
+
+        st = {}
+        st["shape0"] = stack("shape")
+        st["dyn0"] = stack("dyn")
+        st["nav0"] = stack("nav")
+        st["pid0"] = stack("pid")
+        st["param"] = stack("param")
+        st["route_nodes"] = stack("route_nodes")
+        st["route_roads"] = stack("route_roads")
+        st["final_lane"] = stack("final_lane")
+        st["idm_rand"] = stack("idm_rand")
+        st["shape"] = st["shape0"].copy()
+        st["dyn"] = st["dyn0"].copy()
+        st["nav"] = st["nav0"].copy()
+        st["pid"] = st["pid0"].copy()
+        st["action"] = np.zeros((N, 2), np.float32)
+        st["flags"] = np.zeros(N, np.uint32)
+        st["obs"] = np.zeros((E * A, self.obs_dim), np.float32)
+        st["reward"] = np.zeros(E * A, np.float32)
+        st["cost"] = np.zeros(E * A, np.float32)
+        st["step_info"] = np.zeros((E * A, 8), np.float32)
+        st["need_reset"] = np.ones(E, np.int32)
+        self.state = st
+        self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
+
+    def clone_state(self):
+        return {k: v.copy() for k, v in self.state.items()}
+
+
+def make_md_config(cfg, E, A, cap, n_beams):
+    k = abi.MdConfig()
+    k.struct_size = C.sizeof(abi.MdConfig)
+    k.n_envs, k.agents_per_env, k.cap = E, A, cap
+    k.n_beams, k.obs_dim = n_beams, 19 + n_beams
+    k.substeps = int(cfg["decision_repeat"])
+    k.horizon = int(cfg["horizon"]) if cfg["horizon"] else 0
+    k.dt = float(cfg["physics_world_step_size"])
+    k.lidar_range = float(cfg["vehicle_config"]["lidar"]["distance"])
+    for name in ("success_reward", "out_of_road_penalty", "crash_vehicle_penalty", "crash_object_penalty",
+                 "driving_reward", "speed_reward", "crash_vehicle_cost", "crash_object_cost", "out_of_road_cost"):
+        setattr(k, name, float(cfg[name]))
+    for name in ("use_lateral_reward", "out_of_route_done", "on_continuous_line_done", "crash_vehicle_done",
+                 "crash_object_done", "crash_human_done", "truncate_as_terminate", "enable_idm_lane_change",
+                 "auto_reset"):
+        setattr(k, name, int(bool(cfg[name])))
+    k.traffic_mode = {"trigger": 0, "respawn": 1, "hybrid": 2}[cfg["traffic_mode"]]
+    k.max_lane_width = 4.5      # BaseMap.MAX_LANE_WIDTH (component/map/base_map.py:38)
+    k.total_width = (3 + 1) * 4.5  # (MAX_LANE_NUM + 1) * MAX_LANE_WIDTH (obs/state_obs.py:92)
+    k.curve_radius_max = 60.0   # BlockParameterSpace.CURVE radius max
+    k.curve_angle_max = 135.0
+    return k
+
+
+def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
+    w = abi.MdWorld()
+    w.n_maps, w.n_envs = n_maps, n_envs
+    abi.fill_struct(w, abi.WORLD_FIELDS, world_arrays, ptr_of)
+    s = abi.MdState()
+    abi.fill_struct(s, abi.STATE_FIELDS, state_arrays, ptr_of)
+    return w, s, md_config
+
+
+class BatchedEngine:
+    def __init__(self, cfg):
+        import torch
+        from metadrive_ped_amd import _lib
+        self.torch = torch
+        self.lib = _lib.load()
+        self._check = _lib.check
+        self.cfg = cfg
+        self.device = torch.device(cfg["device"])
+        if self.device.type != "cuda":
+            raise _lib.MdStepError("BatchedEngine needs a ROCm device (config['device']={!r}); there is no CPU "
+                                   "fallback".format(cfg["device"]))
+        self.host = None
+        self.build()
+
+    # -- upload helpers ---------------------------------------------------------------------------
+    def _to_dev(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+        return t.to(self.device)
+
+    def build(self):
+        """(Re)generate maps + scenes on the host and upload.  BaseEnv.reset's map/agent/traffic managers."""
+        torch = self.torch
+        self.host = HostScene(self.cfg)
+        h = self.host
+        self.E, self.A, self.cap = h.E, h.A, h.cap
+        self.n_beams, self.obs_dim = h.n_beams, h.obs_dim
+        self.world_dev = {k: self._to_dev(v) for k, v in h.world.arrays.items()}
+        self.state_dev = {k: self._to_dev(v) for k, v in h.state.items()}
+        ptr = lambda t: t.data_ptr()
+        self.w, self.s, self.k = make_structs(self.world_dev, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
+        sd = self.state_dev
+        # typed views for the env API
+        self.obs = sd["obs"].view(torch.float32).view(self.E, self.A, self.obs_dim)
+        self.reward = sd["reward"].view(torch.float32).view(self.E, self.A)
+        self.cost = sd["cost"].view(torch.float32).view(self.E, self.A)
+        self.flags = sd["flags"].view(torch.int32).view(self.E, self.cap)
+        self.action = sd["action"].view(torch.float32).view(self.E, self.cap, 2)
+        self.step_info = sd["step_info"].view(torch.float32).view(self.E, self.A, 8)
+        self.need_reset = sd["need_reset"].view(torch.int32)
+        self.shape_f = sd["shape"].view(torch.float32).view(self.E, self.cap, 8)
+        self.dyn_f = sd["dyn"].view(torch.float32).view(self.E, self.cap, 8)
+        self.nav_i = sd["nav"].view(torch.int32).view(self.E, self.cap, 16)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        """All envs back to their reset snapshot; returns after the reset observation is computed.
+        (BaseEnv.reset -> engine.reset -> _get_reset_return, envs/base_env.py:502-584)"""
+        self.need_reset.fill_(1)
+        self.step_raw()
+
+    def step_raw(self):
+        self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
+
+    def step(self, actions):
+        """actions: tensor [E, A, 2] (or [E, 2] when A == 1), float32, on the engine's device."""
+        a = actions
+        if a.dim() == 2:
+            a = a.unsqueeze(1)
+        self.action[:, :self.A, :] = a.to(self.device, self.torch.float32)
+        self.step_raw()
+
+    def call(self, name):
+        """Single-phase entry points (parity tests): md_integrate, md_localize, ..."""
+        fn = getattr(self.lib, name)
+        self._check(fn(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), name)
+
+    def lidar(self, out, stride, offset):
+        self._check(self.lib.md_lidar(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(out.data_ptr()),
+                                      stride, offset, self._stream()), "md_lidar")
+
+    def download_state(self):
+        """Device state -> dict of numpy arrays with the host dtypes (tests / checkpoints)."""
+        out = {}
+        for k, v in self.host.state.items():
+            out[k] = self.state_dev[k].cpu().numpy().view(v.dtype).reshape(v.shape).copy()
+        return out
+
+    def upload_state(self, arrays):
+        for k, v in arrays.items():
+            self.state_dev[k].copy_(self.torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).reshape(-1)))

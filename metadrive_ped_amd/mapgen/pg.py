@@ -1,0 +1,441 @@
+"""Procedural map generation (reset-time, host, numpy RandomState) for the batched engine.
+
+Produces, for one seed, the same road graph the reference's BIG search produces -- block type
+sequence, per-block parameters, lane geometry, line decoration, sockets -- by consuming the same
+RandomState streams in the same order:
+
+  BIG stream   get_np_random(seed):  choice(block types, p) -> choice(socket ids) -> randint(0, 10000)
+               per sampled block                     (component/algorithm/BIG.py:97-118)
+  block stream get_np_random(block_seed): randint(0, 1e6) once at construction and once more per
+               construction trial; that integer seeds every parameter's own stream
+               (base_class/base_runnable.py:22-29,82-96; block/base_block.py:95-130)
+  backtracking up to MAX_TRIAL = 5 re-samples per block, then pop one block (BIG.py:83-165)
+
+Block types built so far: FirstPGBlock "I", Straight "S", Curve "C"
+(pgblock/first_block.py:13-108, straight.py:9-55, curve.py:10-90).  The other types of
+BLOCK_TYPE_DISTRIBUTION_V2 (ramps, intersections, roundabout) are not built yet: sampling one raises
+NotImplementedError naming it, so a config never silently changes the map distribution.
+
+Road-crossing check: check_lane_on_road (utils/pg/utils.py:36-71) with the bounding-box pre-filter
+of get_lanes_bounding_box (:74-147).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from metadrive_ped_amd.mapgen.lanes import (COLOR_GREY, COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_SIDE,
+                                            CircularLane, StraightLane)
+from metadrive_ped_amd.pg_space import BlockParameterSpace, Parameter, sample_parameters
+from metadrive_ped_amd.rng import get_np_random
+
+NEG = "-"
+DECORATION = ("decoration", "decoration_")
+SIDEWALK_WIDTH = 2.0
+SIDEWALK_LINE_DIST = 0.6
+
+# algorithm/blocks_prob_dist.py:22-41 (order matters: np_random.choice indexes into it)
+BLOCK_TYPE_DISTRIBUTION_V2 = OrderedDict([
+    ("Curve", 0.3), ("Straight", 0.1), ("InRampOnStraight", 0.1), ("OutRampOnStraight", 0.1),
+    ("StdInterSection", 0.15), ("StdTInterSection", 0.15), ("Roundabout", 0.1), ("InFork", 0.0), ("OutFork", 0.0),
+    ("Merge", 0.0), ("Split", 0.0), ("ParkingLot", 0.0), ("TollGate", 0.0), ("Bidirection", 0.0),
+])
+BLOCK_ID = {"Curve": "C", "Straight": "S", "InRampOnStraight": "r", "OutRampOnStraight": "R", "StdInterSection": "X",
+            "StdTInterSection": "T", "Roundabout": "O", "InFork": "f", "OutFork": "F", "Merge": "y", "Split": "Y",
+            "ParkingLot": "P", "TollGate": "$", "Bidirection": "B"}
+MIN_LANE_NUM, MAX_LANE_NUM = 1, 5  # PGBlockDistConfig
+
+
+class BlockDist:
+    """User-replaceable block distribution (config key `block_dist_config`)."""
+    def __init__(self, dist=None):
+        self.dist = OrderedDict(dist) if dist is not None else OrderedDict(BLOCK_TYPE_DISTRIBUTION_V2)
+
+    def all_blocks(self):
+        return list(self.dist.keys())
+
+    def block_probability(self):
+        return list(self.dist.values())
+
+    def name_of_id(self, block_id):
+        for k in self.dist:
+            if BLOCK_ID[k] == block_id:
+                return k
+        raise ValueError("No {} block type".format(block_id))
+
+
+def negate_road(start, end):
+    """Road.__neg__ (component/road_network/road.py:22-27)"""
+    i = end.find(NEG)
+    if i == -1:
+        return NEG + end, NEG + start
+    return end[i + 1:], start[i + 1:]
+
+
+def is_negative_road(end_node):
+    return end_node.find(NEG) != -1
+
+
+class RoadNet:
+    """graph[from][to] -> [lanes], insertion-ordered like the reference's dict-of-dicts."""
+    def __init__(self):
+        self.graph = OrderedDict()
+
+    def add_lane(self, a, b, lane):
+        self.graph.setdefault(a, OrderedDict()).setdefault(b, []).append(lane)
+
+    def lanes(self, a, b):
+        return self.graph[a][b]
+
+    def merge(self, other):
+        for a, tos in other.graph.items():
+            self.graph[a] = tos  # whole `from` entry replaced, as dict.update does (node_road_network.py:100)
+
+    def remove(self, other):
+        for a in list(other.graph.keys()):
+            self.graph.pop(a, None)
+
+    def roads(self):
+        for a, tos in self.graph.items():
+            for b, lanes in tos.items():
+                yield a, b, lanes
+
+
+# ---------------------------------------------------------------------------------------------
+# crossing test
+# ---------------------------------------------------------------------------------------------
+def _contour(lanes, extra=3.0):
+    pts = []
+    if isinstance(lanes[0], CircularLane):
+        for lane, side in ((lanes[0], -1), (lanes[-1], 1)):
+            off = side * (lane.width / 2.0 + extra)
+            pts += [lane.position(0.1, off), lane.position(lane.length - 0.1, off)]
+            half_pi = np.pi / 2.0
+            start_phase = (lane.start_phase // half_pi) * half_pi
+            start_phase += half_pi if lane.clockwise else 0
+            for k in range(4):
+                phi = start_phase + k * half_pi * lane.direction
+                if lane.direction * phi > lane.direction * lane.end_phase:
+                    break
+                pts.append(lane.center + (lane.radius - off * lane.direction) * np.array([math.cos(phi), math.sin(phi)]))
+    else:
+        for lane, side in ((lanes[0], -1), (lanes[-1], 1)):
+            off = side * (lane.width / 2.0 + extra)
+            pts += [lane.position(0.1, off), lane.position(lane.length - 0.1, off)]
+    a = np.asarray(pts)
+    return a[:, 0].max(), a[:, 0].min(), a[:, 1].max(), a[:, 1].min()
+
+
+def lane_crosses_network(net, lane, positive, ignore_intersection_checking=False):
+    """True when `lane` (sampled at its edge `positive * width/2`) lies on an existing road."""
+    if ignore_intersection_checking:
+        return True
+    xmax2, xmin2, ymax2, ymin2 = _contour([lane])
+    for a, b, lanes in net.roads():
+        if (a, b) == DECORATION or len(lanes) == 0:
+            continue
+        xmax1, xmin1, ymax1, ymin1 = _contour(lanes)
+        if xmin1 > xmax2 or xmin2 > xmax1 or ymin1 > ymax2 or ymin2 > ymax1:
+            continue
+        for other in lanes:
+            for i in range(1, int(lane.length), 1):
+                p = lane.position(i, positive * lane.width / 2.0)
+                s, lat = other.local_coordinates(p)
+                if abs(lat) <= other.width / 2.0 and 0 <= s <= other.length:
+                    return True
+    return False
+
+
+# ---------------------------------------------------------------------------------------------
+# road builders (create_pg_block_utils.py:50-281)
+# ---------------------------------------------------------------------------------------------
+def create_road_from(lane, lane_num, road, block_net, global_net, ignore_check=False):
+    """`lane` is the RIGHT-most lane of the new road; build the lane_num-1 lanes to its left."""
+    a, b = road
+    width = lane.width
+    made = []
+    cur = lane
+    for i in range(lane_num - 1, 0, -1):
+        if isinstance(cur, StraightLane):
+            side = cur.shifted(-width)
+        else:
+            side = cur.with_radius(cur.radius + width if cur.clockwise else cur.radius - width)
+        side.line_types = [LINE_CONTINUOUS, LINE_BROKEN] if i == 1 else [LINE_BROKEN, LINE_BROKEN]
+        made.append(side)
+        cur = side
+    made.reverse()
+    made.append(lane)
+    lane.line_types = [LINE_BROKEN if len(made) > 1 else LINE_CONTINUOUS, LINE_SIDE]
+    factor = (SIDEWALK_WIDTH + SIDEWALK_LINE_DIST + width / 2.0) * 2.0 / width
+    no_cross = not lane_crosses_network(global_net, lane, factor, ignore_check)
+    for l in made:
+        block_net.add_lane(a, b, l)
+    if lane_num == 1:
+        made[-1].line_types = [LINE_CONTINUOUS, LINE_SIDE]
+    made[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
+    return no_cross
+
+
+def create_adverse_road(road, block_net, global_net, ignore_check=False):
+    a, b = road
+    lanes = block_net.lanes(a, b)
+    ref = lanes[-1]
+    num = len(lanes) * 2
+    w = ref.width
+    if isinstance(ref, StraightLane):
+        sym = StraightLane(ref.position(ref.length, -(num - 1) * w), ref.position(0, -(num - 1) * w), w,
+                           ref.line_types)
+    else:
+        clockwise = not ref.clockwise
+        radius = ref.radius + (num - 1) * w if not clockwise else ref.radius - (num - 1) * w
+        sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
+    ok = create_road_from(sym, num // 2, negate_road(a, b), block_net, global_net, ignore_check)
+    lanes[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
+    return ok
+
+
+def bend_then_straight(prev, follow_len, radius, angle, clockwise, width, line_types):
+    """create_bend_straight (create_pg_block_utils.py:19-47)"""
+    sign = 1 if clockwise else -1
+    center = prev.position(prev.length, sign * radius)
+    lx, ly = prev.direction_lateral
+    start_phase = np.arctan2(ly, lx) + (np.pi if clockwise else 0)
+    bend = CircularLane(center, radius, start_phase, angle, clockwise, width, line_types)
+    bend_end = bend.position(2 * radius * angle / 2, 0)
+    v = bend_end - center
+    n = math.sqrt(v[0] ** 2 + v[1] ** 2)
+    # get_vertical_vector: ((-vy, vx)/n, (vy, -vx)/n); clockwise picks the second
+    nxt = np.asarray((v[1] / n, -v[0] / n)) if clockwise else np.asarray((-v[1] / n, v[0] / n))
+    straight = StraightLane(bend_end, nxt * follow_len + bend_end, width, line_types)
+    return bend, straight
+
+
+# ---------------------------------------------------------------------------------------------
+# blocks
+# ---------------------------------------------------------------------------------------------
+class Socket:
+    def __init__(self, positive, negative):
+        self.positive, self.negative = positive, negative
+        self.index = None
+
+
+class Block:
+    ID = "?"
+    SPACE = {}
+
+    def __init__(self, index, pre_socket, global_net, seed):
+        self.index = index
+        self.name = str(index) + self.ID
+        self.pre_socket = pre_socket
+        self.global_net = global_net
+        self.net = RoadNet()
+        self.sockets = OrderedDict()
+        self.respawn_roads = []
+        self.trials = 0
+        self.rng = get_np_random(seed)
+        self.config = sample_parameters(self.rng, self.SPACE)  # the draw made in BaseRunnable.__init__
+        self._part, self._road = 0, 0
+        if index != 0:
+            self.positive_lanes = global_net.lanes(*pre_socket.positive)
+            self.lane_num = len(self.positive_lanes)
+            self.basic_lane = self.positive_lanes[-1]
+
+    def node(self):
+        self._road += 1
+        return "{}{}{}_{}_".format(self.index, self.ID, self._part, self._road - 1)
+
+    def add_socket(self, s):
+        if s.index is None:
+            s.index = "{}-socket{}".format(self.name, len(self.sockets))
+        self.sockets[s.index] = s
+
+    def construct(self):
+        """construct_block: resample parameters, rebuild the topology, merge into the global net."""
+        self.config = sample_parameters(self.rng, self.SPACE)
+        self.clear()
+        self.trials += 1
+        ok = self.plug()
+        self.global_net.merge(self.net)
+        return ok
+
+    def clear(self):
+        if len(self.global_net.graph) > 0:
+            self.global_net.remove(self.net)
+        self.net.graph.clear()
+        self._part, self._road = 0, 0
+        self.respawn_roads = []
+        self.sockets.clear()
+
+    def positive_roads_lanes(self):
+        return [lanes for a, b, lanes in self.net.roads() if not is_negative_road(b) and (a, b) != DECORATION]
+
+    def intermediate_spawn_lanes(self):
+        """PGBlock.get_intermediate_spawn_lanes (pgblock/pg_block.py:238-244)"""
+        out = self.positive_roads_lanes()
+        for r in self.respawn_roads:
+            lanes = self.net.lanes(*r)
+            if lanes not in out:
+                out.append(lanes)
+        return out
+
+
+class FirstBlock(Block):
+    ID = "I"
+    NODE_1, NODE_2, NODE_3 = ">", ">>", ">>>"
+    ENTRANCE_LENGTH = 10
+
+    def __init__(self, global_net, lane_width, lane_num, length):
+        super().__init__(0, None, global_net, 0)
+        basic = StraightLane([0, 0], [self.ENTRANCE_LENGTH, 0], lane_width, (LINE_BROKEN, LINE_SIDE))
+        r1 = (self.NODE_1, self.NODE_2)
+        create_road_from(basic, lane_num, r1, self.net, global_net)
+        create_adverse_road(r1, self.net, global_net)
+        nxt = basic.extended(length - self.ENTRANCE_LENGTH, [LINE_BROKEN, LINE_SIDE])
+        r2 = (self.NODE_2, self.NODE_3)
+        create_road_from(nxt, lane_num, r2, self.net, global_net)
+        create_adverse_road(r2, self.net, global_net)
+        global_net.merge(self.net)
+        s = Socket(r2, negate_road(*r2))
+        s.index = "{}-socket{}".format(self.name, 0)
+        self.add_socket(s)
+        self.respawn_roads = [r2]
+        self.trials = 0
+
+
+class Straight(Block):
+    ID = "S"
+    SPACE = BlockParameterSpace.STRAIGHT
+
+    def plug(self):
+        length = self.config[Parameter.length]
+        new_lane = self.basic_lane.extended(length, [LINE_BROKEN, LINE_SIDE])
+        start = self.pre_socket.positive[1]
+        road = (start, self.node())
+        ok = create_road_from(new_lane, self.lane_num, road, self.net, self.global_net)
+        ok = create_adverse_road(road, self.net, self.global_net) and ok
+        self.add_socket(Socket(road, negate_road(*road)))
+        return ok
+
+
+class Curve(Block):
+    ID = "C"
+    SPACE = BlockParameterSpace.CURVE
+
+    def plug(self):
+        p = self.config
+        basic = self.basic_lane
+        start = self.pre_socket.positive[1]
+        road = (start, self.node())
+        curve, straight = bend_then_straight(basic, p[Parameter.length], p[Parameter.radius],
+                                             np.deg2rad(p[Parameter.angle]), p[Parameter.dir], basic.width,
+                                             (LINE_BROKEN, LINE_SIDE))
+        ok = create_road_from(curve, self.lane_num, road, self.net, self.global_net)
+        ok = create_adverse_road(road, self.net, self.global_net) and ok
+        road2 = (road[1], self.node())
+        ok = create_road_from(straight, self.lane_num, road2, self.net, self.global_net) and ok
+        ok = create_adverse_road(road2, self.net, self.global_net) and ok
+        self.add_socket(Socket(road2, negate_road(*road2)))
+        return ok
+
+
+BLOCK_CLASSES = {"Straight": Straight, "Curve": Curve}
+
+
+class PGMap:
+    """The BIG search (component/algorithm/BIG.py:27-165) driven to completion."""
+    MAX_TRIAL = 5
+
+    def __init__(self, seed, lane_num=3, lane_width=3.5, exit_length=50, generate_type="block_num", generate_config=3,
+                 block_dist=None):
+        self.seed = seed
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.dist = block_dist if block_dist is not None else BlockDist()
+        self.net = RoadNet()
+        self.rng = get_np_random(seed)
+        self.blocks = [FirstBlock(self.net, lane_width, lane_num, exit_length)]
+        self.sequence = None
+        if generate_type == "block_num":
+            assert isinstance(generate_config, int)
+            self.block_num = generate_config + 1
+        elif generate_type == "block_sequence":
+            assert isinstance(generate_config, str)
+            self.block_num = len(generate_config) + 1
+            self.sequence = FirstBlock.ID + generate_config
+        else:
+            raise ValueError("Map can not be created by {}".format(generate_type))
+        self._search()
+        # lane.index assignment (PGBlock.create_in_world -> _construct_lane)
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    def _sample_block(self):
+        if self.sequence is None:
+            name = self.rng.choice(self.dist.all_blocks(), p=self.dist.block_probability())
+        else:
+            name = self.dist.name_of_id(self.sequence[len(self.blocks)])
+        last = self.blocks[-1]
+        socket_id = self.rng.choice(list(last.sockets.keys()))
+        seed = int(self.rng.randint(0, 10000))
+        name = str(name)
+        if name not in BLOCK_CLASSES:
+            raise NotImplementedError(
+                "PG block type '{}' (id '{}') is not built yet in metadrive_ped_amd.mapgen; restrict "
+                "`block_dist_config` or pass a block sequence made of {}".format(
+                    name, BLOCK_ID.get(name), sorted(BLOCK_ID[k] for k in BLOCK_CLASSES)))
+        return BLOCK_CLASSES[name](len(self.blocks), last.sockets[socket_id], self.net, seed)
+
+    def _construct(self, block):
+        ok = block.construct()
+        n = max(len(self.net.lanes(*s.positive)) for s in block.sockets.values())
+        if n < MIN_LANE_NUM or n > MAX_LANE_NUM:
+            ok = False
+        return ok
+
+    def _search(self):
+        FORWARD, BACK, SIBLING, DESTRUCT = 1, 0, 3, 4
+        step = FORWARD
+        while True:
+            if len(self.blocks) >= self.block_num and step == FORWARD:
+                return
+            if step == FORWARD:
+                block = self._sample_block()
+                self.blocks.append(block)
+                step = FORWARD if self._construct(block) else DESTRUCT
+            elif step == DESTRUCT:
+                block = self.blocks[-1]
+                block.clear()
+                step = SIBLING if block.trials < self.MAX_TRIAL else BACK
+            elif step == SIBLING:
+                block = self.blocks[-1]
+                if len(self.blocks) == 1:
+                    step = FORWARD
+                elif block.trials < self.MAX_TRIAL:
+                    step = FORWARD if self._construct(block) else DESTRUCT
+                else:
+                    step = BACK
+            elif step == BACK:
+                self.blocks.pop()
+                if len(self.blocks) > 1:  # FirstPGBlock.destruct_block is a no-op (first_block.py:106-108)
+                    self.blocks[-1].clear()
+                step = SIBLING
+
+    # ------------------------------------------------------------------------------------------
+    def bfs_route(self, start_node, goal):
+        """NodeRoadNetwork.shortest_path / bfs_paths (road_network/node_road_network.py:242-271).
+        Neighbour order follows graph insertion order (the reference iterates a set difference;
+        PG maps built from I/S/C blocks are chains, so the shortest path is unique)."""
+        g = self.net.graph
+        queue = [(start_node, [start_node])]
+        while queue:
+            node, path = queue.pop(0)
+            if node not in g:
+                return []
+            for nxt in g[node].keys():
+                if nxt in path:
+                    continue
+                if nxt == goal:
+                    return path + [nxt]
+                if nxt in g:
+                    queue.append((nxt, path + [nxt]))
+        return []

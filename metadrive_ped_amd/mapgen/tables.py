@@ -1,0 +1,313 @@
+"""Flatten generated maps into the structure-of-arrays tables the kernels read (include/mdstep.h).
+
+Per map: MdLane records (+ convex hull vertices), MdRoad records, node adjacency (CSR), static
+quads (lane-line ghost boxes and side-walk strips) and a uniform grid over lanes' hulls and quads.
+`MapTables.concat` stacks many maps into one CSR set indexed by map id.
+
+Geometry definitions restated from the reference:
+  lane hull          block/base_block.py:431-468 (convex hull of lane.polygon)
+  line ghost boxes   block/base_block.py:470-519 (half width LANE_LINE_WIDTH/4 = 0.0375 m),
+                     pgblock/pg_block.py:259-292 (continuous: 4 m pieces; broken: 1.5 m stripe per 3 m),
+                     pgblock/pg_block.py:334-362 (which side of which lane gets a line)
+  side walk          pgblock/pg_block.py:294-332 (strip from w/2+0.2 to w/2+2.2, 3 m stations)
+  map region         constants.py:496-508 (TerrainProperty.point_in_map)
+"""
+import math
+
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.mapgen.lanes import (COLOR_GREY, LINE_BROKEN, LINE_CONTINUOUS, LINE_GUARDRAIL, LINE_NONE,
+                                            LINE_SIDE, CircularLane, convex_hull, wrap_to_pi)
+from metadrive_ped_amd.mapgen.pg import DECORATION, is_negative_road
+
+LANE_SEGMENT_LENGTH = 4.0
+STRIPE_LENGTH = 1.5
+LANE_LINE_WIDTH = 0.15
+SIDEWALK_LENGTH = 3.0
+SIDEWALK_WIDTH = 2.0
+MAP_REGION_SIZE = 1024.0  # BASE_DEFAULT_CONFIG map_region_size (envs/base_env.py)
+GRID_CELL = 8.0
+GRID_MARGIN = 0.25  # cells get every item whose AABB (+ margin) touches them
+
+
+def _ccw(q):
+    q = np.asarray(q, dtype=np.float64)
+    area = 0.0
+    for i in range(4):
+        j = (i + 1) % 4
+        area += q[i, 0] * q[j, 1] - q[j, 0] * q[i, 1]
+    return q if area >= 0 else q[::-1].copy()
+
+
+def _line_box(p0, p1):
+    """Ghost box of one lane-line piece as a CCW quad, or None (zero length / outside the map)."""
+    p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
+    d = p1 - p0
+    length = math.sqrt(d[0] ** 2 + d[1] ** 2)
+    mid = (p0 + p1) / 2
+    half = MAP_REGION_SIZE / 2
+    if not (-half <= mid[0] <= half and -half <= mid[1] <= half):
+        return None
+    if length <= 0:
+        return None
+    u = d / length
+    n = np.array([-u[1], u[0]]) * (LANE_LINE_WIDTH / 4)
+    return _ccw([p0 - n, p1 - n, p1 + n, p0 + n])
+
+
+def lane_line_quads(lane, construct_left_right):
+    """Quads + kinds for the lines of one lane; also the side-walk quads when a line is SIDE."""
+    quads, kinds = [], []
+    for side, ltype, color, need in zip((-1, 1), lane.line_types, lane.line_colors, construct_left_right):
+        if not need or ltype == LINE_NONE:
+            continue
+        lateral = side * lane.width / 2
+        if ltype in (LINE_CONTINUOUS, LINE_SIDE, LINE_GUARDRAIL):
+            kind = abi.Q_LINE_WHITE_CONT if color == COLOR_GREY else abi.Q_LINE_YELLOW_CONT
+            n = int(lane.length / LANE_SEGMENT_LENGTH)
+            pieces = []
+            if n == 0:
+                pieces.append((lane.position(0, lateral), lane.position(lane.length, lateral)))
+            for k in range(n):
+                a = lane.position(LANE_SEGMENT_LENGTH * k, lateral)
+                b = lane.position(lane.length, lateral) if k == n - 1 else lane.position((k + 1) * LANE_SEGMENT_LENGTH, lateral)
+                pieces.append((a, b))
+            for a, b in pieces:
+                q = _line_box(a, b)
+                if q is not None:
+                    quads.append(q)
+                    kinds.append(kind)
+            if ltype == LINE_SIDE:
+                for q in sidewalk_quads(lane):
+                    quads.append(q)
+                    kinds.append(abi.Q_SIDEWALK)
+        elif ltype == LINE_BROKEN:
+            n = int(lane.length / (2 * STRIPE_LENGTH))
+            for k in range(n):
+                a = lane.position(k * STRIPE_LENGTH * 2, lateral)
+                b = lane.position(k * STRIPE_LENGTH * 2 + STRIPE_LENGTH, lateral)
+                if k == n - 1:
+                    b = lane.position(lane.length - STRIPE_LENGTH, lateral)
+                q = _line_box(a, b)
+                if q is not None:
+                    quads.append(q)
+                    kinds.append(abi.Q_LINE_BROKEN)
+        else:
+            raise ValueError("line type {}".format(ltype))
+    return quads, kinds
+
+
+def sidewalk_quads(lane):
+    start_lat = lane.width / 2 + 0.2
+    side_lat = start_lat + SIDEWALK_WIDTH
+    if lane.radius != 0 and side_lat > lane.radius:
+        return []
+    longs = np.arange(0, lane.length + SIDEWALK_LENGTH, SIDEWALK_LENGTH)
+    longs = [min(lane.length + 0.1, s) for s in longs]
+    out = []
+    for s0, s1 in zip(longs[:-1], longs[1:]):
+        if s1 <= s0:
+            continue
+        q = _ccw([lane.position(s0, start_lat), lane.position(s1, start_lat), lane.position(s1, side_lat),
+                  lane.position(s0, side_lat)])
+        out.append(q)
+    return out
+
+
+class MapTables:
+    """numpy tables of ONE map (all offsets map-local)."""
+    def __init__(self, pg_map):
+        self.pg_map = pg_map
+        net = pg_map.net
+        nodes = {}
+        roads, lanes_flat = [], []
+        self.lane_id = {}      # (a, b, i) -> lane id
+        self.road_id = {}      # (a, b) -> road id
+        self.lane_objs = []
+
+        def node_id(name):
+            if name not in nodes:
+                nodes[name] = len(nodes)
+            return nodes[name]
+
+        block_of_road = {}
+        for bi, blk in enumerate(pg_map.blocks):
+            for a, b, _ in blk.net.roads():
+                block_of_road[(a, b)] = bi
+        for a, b, lanes in net.roads():
+            if (a, b) == DECORATION:
+                continue
+            rid = len(roads)
+            self.road_id[(a, b)] = rid
+            roads.append((len(lanes_flat), len(lanes), node_id(a), node_id(b), int(is_negative_road(b)),
+                          block_of_road.get((a, b), -1)))
+            for i, l in enumerate(lanes):
+                self.lane_id[(a, b, i)] = len(lanes_flat)
+                lanes_flat.append((l, rid, i, len(lanes)))
+                self.lane_objs.append(l)
+        self.node_names = list(nodes.keys())
+        self.node_index = nodes
+        n_nodes = len(nodes)
+
+        # --- lanes + hulls ---
+        self.lanes = np.zeros(len(lanes_flat), dtype=abi.LANE_DT)
+        hull_pts = []
+        hull_off = 0
+        for k, (l, rid, i, n) in enumerate(lanes_flat):
+            r = self.lanes[k]
+            r["road"], r["idx"], r["n_in_road"] = rid, i, n
+            r["length"], r["width"] = l.length, l.width
+            r["sx"], r["sy"] = l.start
+            r["ex"], r["ey"] = l.end
+            el = l.end_lateral()
+            r["elx"], r["ely"] = el
+            if isinstance(l, CircularLane):
+                r["type"] = 1
+                r["ax"], r["ay"] = l.center
+                r["bx"], r["by"] = l.radius, l.start_phase
+                r["end_phase"] = l.end_phase
+                r["end_phase_w"] = wrap_to_pi(l.end_phase)
+                r["dirsign"] = l.direction
+                r["angle"] = l.angle
+            else:
+                r["type"] = 0
+                r["ax"], r["ay"] = l.start
+                r["bx"], r["by"] = l.direction
+                r["heading"] = l.heading
+            hull = convex_hull(l.polygon()).astype(np.float32)
+            r["hull_off"], r["hull_n"] = hull_off, len(hull)
+            r["x0"], r["y0"] = hull[:, 0].min(), hull[:, 1].min()
+            r["x1"], r["y1"] = hull[:, 0].max(), hull[:, 1].max()
+            hull_pts.append(hull)
+            hull_off += len(hull)
+        self.hull_xy = np.concatenate(hull_pts, axis=0).astype(np.float32) if hull_pts else np.zeros((0, 2), np.float32)
+
+        # --- roads / node adjacency ---
+        self.roads = np.zeros(len(roads), dtype=abi.ROAD_DT)
+        for k, (fl, n, sa, sb, neg, blk) in enumerate(roads):
+            self.roads[k] = (fl, n, sa, sb, neg, blk, (0, 0))
+        adj = [[] for _ in range(n_nodes)]
+        for k, (fl, n, sa, sb, neg, blk) in enumerate(roads):
+            adj[sa].append((sb, k))
+        self.node_adj_off = np.zeros(n_nodes + 1, dtype=np.int32)
+        flat = []
+        for i in range(n_nodes):
+            self.node_adj_off[i + 1] = self.node_adj_off[i] + len(adj[i])
+            flat += adj[i]
+        self.node_adj = np.asarray(flat, dtype=np.int32).reshape(-1, 2) if flat else np.zeros((0, 2), np.int32)
+
+        # --- static quads (pgblock/pg_block.py:248-257: left+right on lane 0 of positive roads, else right only) ---
+        quads, kinds = [], []
+        for a, b, lanes in net.roads():
+            if (a, b) == DECORATION:
+                continue
+            pos = not is_negative_road(b)
+            for i, l in enumerate(lanes):
+                q, kd = lane_line_quads(l, (True, True) if (i == 0 and pos) else (False, True))
+                quads += q
+                kinds += kd
+        self.quads = np.asarray(quads, dtype=np.float32).reshape(-1, 8) if quads else np.zeros((0, 8), np.float32)
+        self.quad_kind = np.asarray(kinds, dtype=np.int32)
+        self._build_grid()
+
+    def _build_grid(self):
+        boxes = []  # (x0, y0, x1, y1, item)
+        for k in range(len(self.lanes)):
+            r = self.lanes[k]
+            boxes.append((r["x0"], r["y0"], r["x1"], r["y1"], k))
+        for k in range(len(self.quads)):
+            q = self.quads[k].reshape(4, 2)
+            boxes.append((q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max(), ~k))
+        b = np.asarray([bb[:4] for bb in boxes], dtype=np.float64)
+        x0 = math.floor(b[:, 0].min() - 1.0)
+        y0 = math.floor(b[:, 1].min() - 1.0)
+        x1, y1 = b[:, 2].max() + 1.0, b[:, 3].max() + 1.0
+        nx = int(math.ceil((x1 - x0) / GRID_CELL))
+        ny = int(math.ceil((y1 - y0) / GRID_CELL))
+        cells = [[] for _ in range(nx * ny)]
+        for (bx0, by0, bx1, by1, item) in boxes:
+            gx0 = max(0, int(math.floor((bx0 - GRID_MARGIN - x0) / GRID_CELL)))
+            gx1 = min(nx - 1, int(math.floor((bx1 + GRID_MARGIN - x0) / GRID_CELL)))
+            gy0 = max(0, int(math.floor((by0 - GRID_MARGIN - y0) / GRID_CELL)))
+            gy1 = min(ny - 1, int(math.floor((by1 + GRID_MARGIN - y0) / GRID_CELL)))
+            for gy in range(gy0, gy1 + 1):
+                for gx in range(gx0, gx1 + 1):
+                    cells[gy * nx + gx].append(item)
+        self.grid = np.zeros(1, dtype=abi.GRID_DT)
+        self.grid[0]["x0"], self.grid[0]["y0"] = x0, y0
+        self.grid[0]["inv_cell"] = 1.0 / GRID_CELL
+        self.grid[0]["nx"], self.grid[0]["ny"] = nx, ny
+        self.cell_start = np.zeros(nx * ny + 1, dtype=np.int32)
+        items = []
+        for i, c in enumerate(cells):
+            # lane items ascending first (the localisation tie-break is "lowest lane id"), then quads
+            c_sorted = sorted([x for x in c if x >= 0]) + sorted([x for x in c if x < 0], reverse=True)
+            items += c_sorted
+            self.cell_start[i + 1] = len(items)
+        self.cell_items = np.asarray(items, dtype=np.int32)
+
+
+class WorldTables:
+    """Many maps stacked into the CSR layout of MdWorld."""
+    def __init__(self, maps, env_map, beam_cs):
+        self.maps = maps
+        n = len(maps)
+        self.arrays = {}
+        lane_off, road_off, quad_off, node_off = [0], [0], [0], [0]
+        hull_base, cell_base, item_base, adj_base = 0, 0, 0, 0
+        lanes, hulls, roads, quads, qk, grids, cstart, citems, adj_off, adj = [], [], [], [], [], [], [], [], [], []
+        for m in maps:
+            l = m.lanes.copy()
+            l["hull_off"] += hull_base
+            lanes.append(l)
+            hulls.append(m.hull_xy)
+            hull_base += len(m.hull_xy)
+            roads.append(m.roads)
+            quads.append(m.quads)
+            qk.append(m.quad_kind)
+            g = m.grid.copy()
+            g["cell_base"] = cell_base
+            grids.append(g)
+            cstart.append(m.cell_start + item_base)
+            cell_base += len(m.cell_start)
+            citems.append(m.cell_items)
+            item_base += len(m.cell_items)
+            adj_off.append(m.node_adj_off[:-1] + adj_base)
+            adj.append(m.node_adj)
+            adj_base += len(m.node_adj)
+            lane_off.append(lane_off[-1] + len(l))
+            road_off.append(road_off[-1] + len(m.roads))
+            quad_off.append(quad_off[-1] + len(m.quads))
+            node_off.append(node_off[-1] + len(m.node_adj_off) - 1)
+        a = self.arrays
+        a["env_map"] = np.asarray(env_map, dtype=np.int32)
+        a["lane_off"] = np.asarray(lane_off, dtype=np.int32)
+        a["lanes"] = np.concatenate(lanes)
+        a["hull_xy"] = np.concatenate(hulls).astype(np.float32).reshape(-1, 2)
+        a["road_off"] = np.asarray(road_off, dtype=np.int32)
+        a["roads"] = np.concatenate(roads)
+        a["quad_off"] = np.asarray(quad_off, dtype=np.int32)
+        a["quads"] = np.concatenate(quads).astype(np.float32).reshape(-1, 8)
+        a["quad_kind"] = np.concatenate(qk).astype(np.int32)
+        a["grid"] = np.concatenate(grids)
+        a["cell_start"] = np.concatenate(cstart).astype(np.int32)
+        a["cell_items"] = np.concatenate(citems).astype(np.int32)
+        a["node_adj_off"] = np.concatenate(adj_off + [np.asarray([adj_base], dtype=np.int32)]).astype(np.int32)
+        a["node_adj"] = np.concatenate(adj).astype(np.int32).reshape(-1, 2)
+        a["node_off"] = np.asarray(node_off, dtype=np.int32)
+        a["beam_cs"] = np.asarray(beam_cs, dtype=np.float32).reshape(-1, 2)
+        self.n_maps = n
+        self.n_envs = len(env_map)
+        # guard: padding arrays that may legitimately be empty
+        for k in ("quads", "quad_kind", "cell_items", "node_adj", "hull_xy"):
+            if a[k].size == 0:
+                a[k] = np.zeros((1, ) + a[k].shape[1:], dtype=a[k].dtype)
+
+
+def beam_table(n_beams, phase=0.0):
+    """cos/sin of DistanceDetector._get_lidar_range (component/sensors/distance_detector.py:177-180)."""
+    if n_beams <= 0:
+        return np.zeros((1, 2), np.float32)
+    ang = np.arange(0, n_beams) * (2 * np.pi / n_beams) + phase
+    return np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)

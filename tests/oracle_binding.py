@@ -1,0 +1,113 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libmdoracle.so).  TEST INFRASTRUCTURE: imported by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only -- never by the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.engine import make_structs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libmdoracle.so")
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(ORACLE_SO):
+        build()
+    lib = C.CDLL(ORACLE_SO)
+    W, S, K = C.POINTER(abi.MdWorld), C.POINTER(abi.MdState), C.POINTER(abi.MdConfig)
+    for name in ("ref_integrate", "ref_localize", "ref_contacts", "ref_observe", "ref_idm", "ref_traffic_after_step",
+                 "ref_step"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [W, S, K]
+    lib.ref_step_mt.restype = C.c_int
+    lib.ref_step_mt.argtypes = [W, S, K, C.c_int]
+    lib.ref_lidar.restype = C.c_int
+    lib.ref_lidar.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_int]
+    lib.ref_line_detector.restype = C.c_int
+    lib.ref_line_detector.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
+    lib.ref_abi.restype = C.c_int
+    lib.ref_abi.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    f = C.c_float
+    lib.ref_lane_local.argtypes = [C.c_void_p, f, f, C.c_void_p]
+    lib.ref_lane_heading_at.restype = f
+    lib.ref_lane_heading_at.argtypes = [C.c_void_p, f]
+    lib.ref_heading_diff.restype = f
+    lib.ref_heading_diff.argtypes = [C.c_void_p, f, f, f, f]
+    lib.ref_navi.argtypes = [C.c_void_p, f, f, f, f, f, f, f, C.c_void_p]
+    lib.ref_idm_acc.restype = f
+    lib.ref_idm_acc.argtypes = [f, f, C.c_int, f, f]
+    lib.ref_pid.restype = f
+    lib.ref_pid.argtypes = [C.c_void_p, f, f, f, f]
+    lib.ref_wrap_to_pi.restype = f
+    lib.ref_wrap_to_pi.argtypes = [f]
+    lib.ref_sincos.argtypes = [f, C.c_void_p]
+    lib.ref_atan2.restype = f
+    lib.ref_atan2.argtypes = [f, f]
+    lib.ref_acos.restype = f
+    lib.ref_acos.argtypes = [f]
+    lib.ref_sanitize.restype = f
+    lib.ref_sanitize.argtypes = [f]
+    lib.ref_ray_shape.restype = f
+    lib.ref_ray_shape.argtypes = [f, f, f, f, C.c_void_p]
+    lib.ref_obb_obb.restype = C.c_int
+    lib.ref_obb_obb.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_obb_quad.restype = C.c_int
+    lib.ref_obb_quad.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ref_bicycle.argtypes = [C.c_void_p, f, f, C.c_void_p, f, C.c_int]
+    abi.check_abi(lib.ref_abi, ORACLE_SO)
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+class OracleWorld:
+    """The oracle running on a HostScene's tables with its own copy of the state."""
+    def __init__(self, host, state=None):
+        self.lib = load()
+        self.host = host
+        self.state = state if state is not None else host.clone_state()
+        self.w, self.s, self.k = make_structs(host.world.arrays, self.state, host.md_config, host.world.n_maps, host.E,
+                                              _ptr)
+
+    def call(self, name, *extra):
+        rc = getattr(self.lib, name)(C.byref(self.w), C.byref(self.s), C.byref(self.k), *extra)
+        assert rc == 0, (name, rc)
+
+    def step(self, actions=None, threads=1):
+        if actions is not None:
+            a = self.state["action"].reshape(self.host.E, self.host.cap, 2)
+            a[:, :self.host.A, :] = np.asarray(actions, np.float32).reshape(self.host.E, self.host.A, 2)
+        if threads > 1:
+            self.call("ref_step_mt", threads)
+        else:
+            self.call("ref_step")
+
+    def reset(self):
+        self.state["need_reset"][:] = 1
+        self.call("ref_step")
+
+    def lidar(self):
+        out = np.zeros((self.host.E * self.host.A, self.host.n_beams), np.float32)
+        self.call("ref_lidar", C.c_void_p(out.ctypes.data), self.host.n_beams, 0)
+        return out
+
+    @property
+    def obs(self):
+        return self.state["obs"]
