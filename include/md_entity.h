@@ -194,8 +194,7 @@ MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* 
     s->cost[ai] = cost;
 
     /* ---- info (base_vehicle.py:243-271) ---- */
-    float dist_km = md_norm(d->last_x - x, d->last_y - y) / 1000.0f;
-    float step_energy = 3.25f * md_exp(0.01f * speed_kmh) * dist_km / 100.0f * 1000.0f;
+    float step_energy = md_step_energy(speed_kmh, md_norm(d->last_x - x, d->last_y - y));
     if (just_reset) step_energy = 0.0f;
     s->pid[n].energy += step_energy;
     info[0] = step_reward;

@@ -384,4 +384,32 @@ MD_HD void md_navi_for_checkpoint(const MdLane* ref, float later_middle, float x
     out5[4] = md_clip((angle * 57.29577951308232f / angle_max_deg + 1.0f) / 2.0f, 0.0f, 1.0f);
 }
 
+/* step energy in mL (base_vehicle.py:255-271): 3.25 * e^(0.01 v_kmh) * distance_km / 100 * 1000 */
+MD_HD float md_step_energy(float speed_kmh, float dist_m) {
+    float dist_km = dist_m / 1000.0f;
+    float e = md_exp(0.01f * speed_kmh);
+    float t = 3.25f * e;
+    t = t * dist_km;
+    t = t / 100.0f;
+    return t * 1000.0f;
+}
+
+MD_HD float md_probe_eval(int op, float a, float b) {
+    float s, c;
+    switch (op) {
+        case 0: md_sincos(a, &s, &c); return s;
+        case 1: md_sincos(a, &s, &c); return c;
+        case 2: return md_atan2(a, b);
+        case 3: return md_acos(a);
+        case 4: return md_exp(a);
+        case 5: return a / b;
+        case 6: return md_sqrt(a);
+        case 7: return md_wrap_to_pi(a);
+        case 8: return md_asin(a);
+        case 9: return md_norm(a, b);
+        case 10: return md_step_energy(a, b);
+        default: return 0.0f;
+    }
+}
+
 #endif /* MD_GEOM_H */

@@ -37,13 +37,10 @@ MD_HD float md_max(float a, float b) { return a > b ? a : b; }
 /* metadrive/utils/math.py:54-55  clip(a, low, high) = min(max(a, low), high) */
 MD_HD float md_clip(float a, float lo, float hi) { return md_min(md_max(a, lo), hi); }
 
-MD_HD float md_sqrt(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fsqrt_rn(x);
-#else
-    return __builtin_sqrtf(x);
-#endif
-}
+/* Correctly rounded on both sides: gcc -> sqrtss; hipcc -> IEEE sqrt expansion
+ * (-fhip-fp32-correctly-rounded-divide-sqrt is the default).  NOT __fsqrt_rn: on ROCm 7.2 that is
+ * __ocml_native_sqrt_f32, a ~1 ulp approximation (found by tests/test_gpu_math.py). */
+MD_HD float md_sqrt(float x) { return __builtin_sqrtf(x); }
 
 /* metadrive/utils/math.py:50-51  norm(x, y) */
 MD_HD float md_norm(float x, float y) { return md_sqrt(x * x + y * y); }

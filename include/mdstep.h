@@ -266,6 +266,13 @@ typedef struct MdConfig {
 int md_abi(int32_t* sizes, int n);
 const char* md_last_error(void);
 
+/* Arithmetic self-test hook: out[i] = f_op(a[i], b[i]) evaluated ON THE DEVICE with the shared
+ * float32 formulas of md_math.h / md_geom.h (op: 0 sin, 1 cos, 2 atan2(a,b), 3 acos, 4 exp, 5 a/b,
+ * 6 sqrt, 7 wrap_to_pi, 8 asin, 9 norm(a,b), 10 energy model of base_vehicle.py:255-271 with a = speed
+ * km/h, b = distance m).  The parity tests compare it bit for bit with the host build of the same
+ * formulas: this is what makes "bit-exact booleans" a checkable claim. */
+int md_probe_math(int op, const float* a, const float* b, float* out, int n, void* stream);
+
 /* Lidar: Lidar.perceive / perceive()  component/sensors/lidar.py:49-73,
  * component/sensors/distance_detector.py:27-85, utils/math.py:76-81.
  * For agent a of env e: out[(e*A+a)*out_stride + out_offset + i] = closest hit fraction in [0,1]

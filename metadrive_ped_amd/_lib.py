@@ -42,6 +42,8 @@ def load():
     lib.md_line_detector.restype = C.c_int
     lib.md_line_detector.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_int, C.c_int,
                                      C.c_void_p]
+    lib.md_probe_math.restype = C.c_int
+    lib.md_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     abi.check_abi(lib.md_abi, LIB_PATH)
     _LIB = lib
     return lib

@@ -461,6 +461,11 @@ __global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState s, MdCon
     }
 }
 
+__global__ void probe_kernel(int op, const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = md_probe_eval(op, a[i], b[i]);
+}
+
 int check_common(const MdWorld* w, const MdState* s, const MdConfig* c) {
     if (!w || !s || !c) {
         snprintf(g_err, sizeof g_err, "null MdWorld/MdState/MdConfig pointer");
@@ -533,6 +538,21 @@ __attribute__((visibility("default"))) int md_abi(int32_t* sizes, int n) {
 }
 
 __attribute__((visibility("default"))) const char* md_last_error(void) { return g_err; }
+
+__attribute__((visibility("default"))) int md_probe_math(int op, const float* a, const float* b, float* out, int n,
+                                                        void* stream) {
+    if (!a || !b || !out || n <= 0) {
+        snprintf(g_err, sizeof g_err, "md_probe_math: null pointer or n<=0");
+        return MD_EINVAL;
+    }
+    hipLaunchKernelGGL(probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, op, a, b, out, n);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
 
 __attribute__((visibility("default"))) int md_lidar(const MdWorld* w, const MdState* s, const MdConfig* c, float* out,
                                                    int out_stride, int out_offset, void* stream) {

@@ -407,6 +407,9 @@ EXPORT int ref_obb_quad(const MdShape* a, const float* q) { return md_obb_quad(a
 EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, float dt, int n) {
     for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], steer, thr, P, dt);
 }
+EXPORT void ref_probe_math(int op, const float* a, const float* b, float* out, int n) {
+    for (int i = 0; i < n; ++i) out[i] = md_probe_eval(op, a[i], b[i]);
+}
 EXPORT int ref_abi(int32_t* sizes, int n) {
     int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),
                      sizeof(MdRoad), sizeof(MdGrid), sizeof(MdWorld), sizeof(MdState), sizeof(MdConfig)};
