@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- agent-steps/s of the batched MetaDrive step() on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one env.step() of the whole batch: ONE md_step launch that advances every env by 0.1 s
+of simulated time (IDM traffic -> kinematic integration -> lane localisation -> contacts -> obs /
+reward / done -> 240-beam lidar), with auto-reset of finished envs inside the same launch.
+Workload at N=1 is BASELINE.json configs[1]: 4096 batched MetaDriveEnv, 3-block PG map (block types
+built so far: Curve / Straight), 240-beam lidar, traffic_density 0.1, one env per scenario seed.
+For N>1 every rank owns 4096 envs of the global batch (weak scaling, no data-path collective: envs
+are independent worlds); rank 0 prints ONE JSON line.  Inputs (state, maps, actions) are resident in
+HBM when the timed region starts.
+
+Extra objects in the JSON line:
+  roofline     the fused step kernel: algorithmic bytes per launch / average launch duration
+               (HIP events on the launch stream) against the HBM peak
+  lidar        the stand-alone md_lidar kernel measured the same way (bytes = 16 + 24*M + 4*B per agent)
+  cpu_baseline the CPU oracle (oracle/md_oracle.c, "port") on the host cores, bounded sample
+  with_gather  (N>1) the same K steps followed by an RCCL all_gather of (obs, reward, flags)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    p.add_argument("--cap", type=int, default=32, help="mover slots per env")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-envs", type=int, default=1024)
+    p.add_argument("--cpu-steps", type=int, default=60)
+    return p.parse_args()
+
+
+def cs_dist():
+    from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2
+    d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
+    d["Curve"], d["Straight"] = 0.6, 0.4
+    return d
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    E = args.envs
+    cfg = make_config(dict(
+        num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0, map=3,
+        block_dist_config=cs_dist(), traffic_density=0.1, mover_capacity=args.cap, auto_reset=True, horizon=1000,
+        device="cuda:%d" % local_rank))
+    # host-side scene generation happens BEFORE the GPU / process group are touched (fork pool inside)
+    t0 = time.time()
+    from metadrive_ped_amd.engine import HostScene
+    host = HostScene(cfg)
+    torch.cuda.set_device(local_rank)
+    eng = BatchedEngine(cfg, host=host)
+    build_s = time.time() - t0
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = eng.device
+    A, cap, B = eng.A, eng.cap, eng.n_beams
+
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(rank)
+    n_act = 64
+    actions = (torch.rand(n_act, E, A, 2, generator=gen) * 2 - 1)
+    actions[..., 1] = actions[..., 1].abs() * 0.9 + 0.1  # mostly forward, so that envs meet traffic and curves
+    actions[..., 0] *= 0.25
+    actions = actions.to(dev)
+
+    eng.reset()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(k, base=0):
+        for i in range(k):
+            eng.step(actions[(base + i) % n_act])
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    total_agent_steps = args.steps * E * A * world
+    value = total_agent_steps / elapsed
+
+    # ---- per-launch duration of the fused step kernel with HIP events on the launch stream ----
+    n_ev = 50
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for i, (a, b) in enumerate(evs):
+        eng.action[:, :A, :] = actions[i % n_act]
+        a.record()
+        eng.step_raw()
+        b.record()
+    torch.cuda.synchronize()
+    step_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    step_ms_avg = sum(step_ms) / len(step_ms)
+    # present movers per env right now (alive, kind != none)
+    flags = eng.shape_f.view(torch.int32)[..., 6]
+    present = ((flags & 0x10) != 0) & ((flags & 0xF) != 0)
+    M = float(present.sum().item()) / E           # movers per env (agents + traffic)
+    T = M - A
+    # whole step per agent ~ 2.6 KB + 136 B * T/A  (state R/W, action, navi/route, obs, flags)
+    bytes_step = (2600.0 + 136.0 * T / A) * E * A
+    achieved = bytes_step / (step_ms_avg * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="env_kernel<255> (fused md_step)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                    bytes_per_launch=int(bytes_step), avg_launch_us=round(step_ms_avg * 1e3, 2),
+                    movers_per_env=round(M, 2))
+
+    # ---- stand-alone lidar kernel ----
+    out = torch.empty(E * A, B, device=dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for a, b in evs:
+        a.record()
+        eng.lidar(out, B, 0)
+        b.record()
+    torch.cuda.synchronize()
+    lid_ms = sum(a.elapsed_time(b) for a, b in evs) / n_ev
+    bytes_lidar = (16.0 + 24.0 * (M - 1) + 4.0 * B) * E * A
+    lidar = dict(kernel="env_kernel<128> (md_lidar)", avg_launch_us=round(lid_ms * 1e3, 2),
+                 achieved=round(bytes_lidar / (lid_ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=round(bytes_lidar / (lid_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=int(bytes_lidar),
+                 flops_per_launch=int(30.0 * B * (M - 1) * E * A))
+
+    # ---- optional gather (N>1): obs + reward + flags to every rank over RCCL ----
+    with_gather = None
+    if world > 1:
+        obs_g = torch.empty(world * E * A * eng.obs_dim, device=dev)
+        rew_g = torch.empty(world * E * A, device=dev)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eng.step(actions[i % n_act])
+            dist.all_gather_into_tensor(obs_g, eng.obs.reshape(-1))
+            dist.all_gather_into_tensor(rew_g, eng.reward.reshape(-1))
+        torch.cuda.synchronize()
+        barrier()
+        eg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(eg, op=dist.ReduceOp.MAX)
+        with_gather = dict(value=round(total_agent_steps / float(eg.item()), 1), unit="agent-steps/s",
+                           collective="all_gather_into_tensor(obs,reward)")
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_binding as ob
+        from metadrive_ped_amd.engine import HostScene
+        n_cpu = min(args.cpu_envs, E)
+        ccfg = dict(cfg)
+        ccfg["num_envs"] = n_cpu
+        host = HostScene(ccfg)
+        orc = ob.OracleWorld(host)
+        cores = os.cpu_count() or 1
+        orc.reset()
+        acts = actions[:, :n_cpu].cpu().numpy()
+        t0 = time.perf_counter()
+        for i in range(args.cpu_steps):
+            orc.step(acts[i % n_act], threads=cores)
+        dt = time.perf_counter() - t0
+        cpu_baseline = dict(value=round(n_cpu * A * args.cpu_steps / dt, 1), unit="agent-steps/s", cores=cores, kind="port",
+                            sample="%d envs x %d steps of the same workload, oracle/md_oracle.c ref_step_mt on %d threads"
+                                   % (n_cpu, args.cpu_steps, cores))
+
+    if rank == 0:
+        line = OrderedDict(
+            metric="agent-steps/sec at 4096 envs x 240-beam lidar", value=round(value, 1), unit="agent-steps/s",
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+            higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload="BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (Curve/Straight "
+                                 "blocks), 240-beam lidar, traffic_density=0.1, trigger traffic, auto-reset" % E,
+                        envs_per_gpu=E, agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
+            roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, with_gather=with_gather,
+            host_build_s=round(build_s, 1))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

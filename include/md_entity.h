@@ -8,12 +8,46 @@
  * trigger (wave min-reduce) -- are written twice: brute force in oracle/md_oracle.c, wave-parallel
  * in metadrive_ped_amd/csrc/mdstep.hip.
  *
+ * Indexing convention: every routine here receives an ENV-LOCAL view of MdState (md_env_view): the
+ * pointers are already advanced to the env's first mover / first agent, so slot j is s->shape[j],
+ * agent a's observation row is s->obs[a * obs_dim], and the env's reset flag is s->need_reset[0].
+ * The oracle makes the view by pointer offset into the global arrays; the fused HIP kernel points
+ * it at the env's LDS-staged copies.
+ *
  * Reference citations are relative to /root/reference/metadrive.
  */
 #ifndef MD_ENTITY_H
 #define MD_ENTITY_H
 
 #include "md_geom.h"
+
+/* env-local view of the global state arrays (see header comment) */
+MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
+    MdState v = *g;
+    const size_t b = (size_t)e * (size_t)c->cap;
+    const size_t a = (size_t)e * (size_t)c->agents_per_env;
+    v.shape = g->shape + b;
+    v.dyn = g->dyn ? g->dyn + b : 0;
+    v.param = g->param ? g->param + b : 0;
+    v.nav = g->nav ? g->nav + b : 0;
+    v.pid = g->pid ? g->pid + b : 0;
+    v.action = g->action ? g->action + 2 * b : 0;
+    v.route_nodes = g->route_nodes ? g->route_nodes + b * MD_ROUTE_LEN : 0;
+    v.route_roads = g->route_roads ? g->route_roads + b * MD_ROUTE_LEN : 0;
+    v.final_lane = g->final_lane ? g->final_lane + b : 0;
+    v.idm_rand = g->idm_rand ? g->idm_rand + b * MD_IDM_RAND : 0;
+    v.flags = g->flags ? g->flags + b : 0;
+    v.obs = g->obs ? g->obs + a * (size_t)c->obs_dim : 0;
+    v.reward = g->reward ? g->reward + a : 0;
+    v.cost = g->cost ? g->cost + a : 0;
+    v.step_info = g->step_info ? g->step_info + a * 8 : 0;
+    v.need_reset = g->need_reset ? g->need_reset + e : 0;
+    v.shape0 = g->shape0 ? g->shape0 + b : 0;
+    v.dyn0 = g->dyn0 ? g->dyn0 + b : 0;
+    v.nav0 = g->nav0 ? g->nav0 + b : 0;
+    v.pid0 = g->pid0 ? g->pid0 + b : 0;
+    return v;
+}
 
 MD_HD int md_kind_of(int flags) { return flags & MD_KIND_MASK; }
 MD_HD int md_is_circle_kind(int k) { return k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_PEDESTRIAN; }
@@ -58,8 +92,8 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
 
 
 MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, int just_reset) {
-    int n = e * c->cap + a;
-    int ai = e * c->agents_per_env + a;
+    int n = a;
+    int ai = a; /* env-local view: agent a of this env */
     float* obs = s->obs + (size_t)ai * c->obs_dim;
     float* info = s->step_info + (size_t)ai * 8;
     MdShape* sh = &s->shape[n];
@@ -205,15 +239,32 @@ MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* 
     info[5] = llat;
     info[6] = ls;
     info[7] = (float)nav->steps;
-    if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[e] = 1;
+    if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[0] = 1;
 }
 
 
+/* ------------------------------------------------------------------------------------------
+ * IDM traffic policy: IDMPolicy.act (policy/idm_policy.py:235-402) with FrontBackObjects
+ * (policy/idm_policy.py:82-132).  Split in three stages so that the object scan in the middle can
+ * run either serially (oracle, md_find_front_back below) or lane-parallel with wavefront
+ * min-reductions (HIP kernel):
+ *   md_idm_plan    move_to_next_road (:269-291) + which lanes to scan
+ *   front/back     per-object evaluators md_idm_is_candidate / md_fb_same_lane_gap / md_fb_neighbour
+ *   md_idm_decide  lane_change_policy (:330-402), steering_control (:293-301), acceleration (:303-320)
+ * The bare `except:` fallback (idm_policy.py:254-260) is modelled by the `fail` paths.
+ * -----------------------------------------------------------------------------------------*/
 typedef struct {
     int front[3], back[3];
     float front_d[3], back_d[3];
     int exist[3];
 } FrontBack;
+
+typedef struct {
+    int success;  /* move_to_next_road() result                                   */
+    int use_ref;  /* scan left/right neighbours too (lane_change_policy path)     */
+    int fail;     /* no routing target lane: fallback branch                      */
+    int ids[3];   /* left, current, right lane ids to scan (-1 = absent)          */
+} MdIdmPlan;
 
 #define IDM_MAX_LONG_DIST 30.0f
 #define IDM_SAFE_LANE_CHANGE 15.0f
@@ -223,76 +274,6 @@ typedef struct {
 #define IDM_CREEP_SPEED 5.0f
 #define IDM_MAX_SPEED 100.0f
 
-MD_HD void md_find_front_back(const MdState* s, const MdConfig* c, const MdLane* lanes, int base, int self_slot,
-                            const unsigned char* cand, int lane_id, int use_ref, const MdRoad* ref_road, float px,
-                            float py, FrontBack* fb) {
-    int ids[3] = {-1, lane_id, -1};
-    if (use_ref) {
-        int idx = lanes[lane_id].idx;
-        if (idx > 0) ids[0] = ref_road->first_lane + idx - 1;
-        if (idx + 1 < ref_road->n_lanes) ids[2] = ref_road->first_lane + idx + 1;
-    }
-    for (int i = 0; i < 3; ++i) {
-        fb->front[i] = fb->back[i] = -1;
-        fb->exist[i] = ids[i] >= 0;
-        fb->front_d[i] = fb->back_d[i] = IDM_MAX_LONG_DIST;
-        if (ids[i] < 0) continue;
-        const MdLane* L = &lanes[ids[i]];
-        float cur_long, tmp;
-        md_lane_local(L, px, py, &cur_long, &tmp);
-        float left_long = L->length - cur_long;
-        /* The reference walks a Python set (arbitrary order) and lets an object on the successor /
-         * predecessor lane compete only while no same-lane object has been found yet
-         * (idm_policy.py:110-130).  Canonical, order-independent form used here: same-lane objects
-         * first; connected-lane objects only when the same lane offered none. Ties -> lowest slot. */
-        int found_front = 0, found_back = 0;
-        for (int j = 0; j < c->cap; ++j) {
-            if (j == self_slot || !cand[j]) continue;
-            const MdShape* o = &s->shape[base + j];
-            int ol = (md_kind_of(o->flags) == MD_KIND_VEHICLE && !(o->flags & MD_F_STATIC)) ? s->nav[base + j].lane : o->aux;
-            if (ol != ids[i]) continue;
-            float os, ot;
-            md_lane_local(L, o->cx, o->cy, &os, &ot);
-            float lg = os - cur_long;
-            if (fb->front_d[i] > lg && lg > 0.0f) {
-                fb->front_d[i] = lg;
-                fb->front[i] = j;
-                found_front = 1;
-            }
-            if (lg < 0.0f && md_fabs(lg) < fb->back_d[i]) {
-                fb->back_d[i] = md_fabs(lg);
-                fb->back[i] = j;
-                found_back = 1;
-            }
-        }
-        if (found_front && found_back) continue;
-        for (int j = 0; j < c->cap; ++j) {
-            if (j == self_slot || !cand[j]) continue;
-            const MdShape* o = &s->shape[base + j];
-            int ol = (md_kind_of(o->flags) == MD_KIND_VEHICLE && !(o->flags & MD_F_STATIC)) ? s->nav[base + j].lane : o->aux;
-            if (ol < 0 || ol == ids[i]) continue;
-            const MdLane* OL = &lanes[ol];
-            if (!found_front && md_lane_is_previous_of(L, OL)) {
-                float os, ot;
-                md_lane_local(OL, o->cx, o->cy, &os, &ot);
-                float lg = os + left_long;
-                if (fb->front_d[i] > lg && lg > 0.0f) {
-                    fb->front_d[i] = lg;
-                    fb->front[i] = j;
-                }
-            } else if (!found_back && md_lane_is_previous_of(OL, L)) {
-                float os, ot;
-                md_lane_local(OL, o->cx, o->cy, &os, &ot);
-                float lg = OL->length - os + cur_long;
-                if (fb->back_d[i] > lg) {
-                    fb->back_d[i] = lg;
-                    fb->back[i] = j;
-                }
-            }
-        }
-    }
-}
-
 MD_HD int md_road_connects(const MdWorld* w, int m, int from_node, int to_node) {
     /* BaseRoadNetwork.has_connection (road_network/base_road_network.py:106-113): graph[from][to] exists */
     int nb = w->node_off[m];
@@ -301,24 +282,56 @@ MD_HD int md_road_connects(const MdWorld* w, int m, int from_node, int to_node) 
     return 0;
 }
 
-MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot) {
-    int base = e * c->cap;
-    int n = base + slot;
-    MdShape* sh = &s->shape[n];
-    MdNav* nav = &s->nav[n];
-    MdPid* pid = &s->pid[n];
-    MdDyn* d = &s->dyn[n];
+/* lidar.get_surrounding_objects(v): bodies touching the r = 50 m ghost cylinder (sensors/lidar.py:170-186) */
+MD_HD int md_idm_is_candidate(const MdShape* o, float px, float py) {
+    if (!md_present(o->flags)) return 0;
+    if (md_is_circle_kind(md_kind_of(o->flags))) {
+        float dx = o->cx - px, dy = o->cy - py, rr = 50.0f + o->hl;
+        return (dx * dx + dy * dy) <= rr * rr;
+    }
+    return md_obb_circle(o->cx, o->cy, o->c, o->s, o->hl, o->hw, px, py, 50.0f);
+}
+
+/* obj.lane: vehicles carry their localised lane, props the lane they were placed on */
+MD_HD int md_obj_lane_of(const MdState* s, int j) {
+    const MdShape* o = &s->shape[j];
+    return (md_kind_of(o->flags) == MD_KIND_VEHICLE && !(o->flags & MD_F_STATIC)) ? s->nav[j].lane : o->aux;
+}
+
+/* same-lane object: signed gap along the lane (idm_policy.py:111-121) */
+MD_HD float md_fb_same_lane_gap(const MdLane* L, float cur_long, const MdShape* o) {
+    float os, ot;
+    md_lane_local(L, o->cx, o->cy, &os, &ot);
+    return os - cur_long;
+}
+
+/* object on a connected lane (idm_policy.py:123-132): returns 1 = front candidate, 2 = back candidate,
+ * 0 = neither; *lg = its distance. */
+MD_HD int md_fb_neighbour(const MdLane* L, const MdLane* OL, float cur_long, float left_long, const MdShape* o,
+                          int need_front, int need_back, float* lg) {
+    if (need_front && md_lane_is_previous_of(L, OL)) {
+        float os, ot;
+        md_lane_local(OL, o->cx, o->cy, &os, &ot);
+        *lg = os + left_long;
+        return 1;
+    }
+    if (need_back && md_lane_is_previous_of(OL, L)) {
+        float os, ot;
+        md_lane_local(OL, o->cx, o->cy, &os, &ot);
+        *lg = OL->length - os + cur_long;
+        return 2;
+    }
+    return 0;
+}
+
+/* Stage A */
+MD_HD void md_idm_plan(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, MdIdmPlan* p) {
+    MdNav* nav = &s->nav[slot];
     int m = w->env_map[e];
     const MdLane* lanes = w->lanes + w->lane_off[m];
     const MdRoad* roads = w->roads + w->road_off[m];
-    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
+    const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
     const MdRoad* cur_road = &roads[rroads[nav->ck0]];
-    int has_next = nav->ck1 != nav->ck0;
-    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : 0;
-    float px = sh->cx, py = sh->cy;
-    float speed_kmh = md_fabs(d->speed) * 3.6f;
-
-    /* ---- move_to_next_road (idm_policy.py:269-291) ---- */
     int success;
     int veh_lane = nav->lane;
     int in_cur = (veh_lane >= 0) && (lanes[veh_lane].road == rroads[nav->ck0]);
@@ -339,38 +352,107 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
         }
     } else if (in_cur && nav->target_lane != veh_lane) {
         nav->target_lane = veh_lane;
-        nav->timer = s->idm_rand[(size_t)n * MD_IDM_RAND + (nav->rand_cursor % MD_IDM_RAND)];
+        nav->timer = s->idm_rand[(size_t)slot * MD_IDM_RAND + (nav->rand_cursor % MD_IDM_RAND)];
         nav->rand_cursor += 1;
         success = 1;
     } else {
         success = 1;
     }
+    p->success = success;
+    p->fail = (nav->target_lane < 0);
+    p->use_ref = success && c->enable_idm_lane_change;
+    p->ids[0] = p->ids[2] = -1;
+    p->ids[1] = nav->target_lane;
+    if (!p->fail && p->use_ref) {
+        int idx = lanes[nav->target_lane].idx;
+        if (idx > 0) p->ids[0] = cur_road->first_lane + idx - 1;
+        if (idx + 1 < cur_road->n_lanes) p->ids[2] = cur_road->first_lane + idx + 1;
+    }
+}
 
-    /* ---- lidar.get_surrounding_objects(v): bodies touching the r=50 ghost cylinder (lidar.py:170-186) ---- */
-    unsigned char cand[MD_MAX_CAP];
-    for (int j = 0; j < c->cap; ++j) {
-        cand[j] = 0;
-        if (j == slot) continue;
-        const MdShape* o = &s->shape[base + j];
-        if (!md_present(o->flags)) continue;
-        int k = md_kind_of(o->flags);
-        if (md_is_circle_kind(k)) {
-            float dx = o->cx - px, dy = o->cy - py, rr = 50.0f + o->hl;
-            cand[j] = (dx * dx + dy * dy) <= rr * rr;
-        } else {
-            cand[j] = (unsigned char)md_obb_circle(o->cx, o->cy, o->c, o->s, o->hl, o->hw, px, py, 50.0f);
+/* Stage B, serial form.  The reference walks a Python set (arbitrary order) and lets an object on the
+ * successor / predecessor lane compete only while no same-lane object has been found yet
+ * (idm_policy.py:110-130).  Canonical, order-independent form: same-lane objects first;
+ * connected-lane objects only when the same lane offered none.  Ties -> lowest slot. */
+MD_HD void md_find_front_back(const MdState* s, const MdConfig* c, const MdLane* lanes, int self_slot,
+                              const MdIdmPlan* p, float px, float py, FrontBack* fb) {
+    for (int i = 0; i < 3; ++i) {
+        fb->front[i] = fb->back[i] = -1;
+        fb->exist[i] = p->ids[i] >= 0;
+        fb->front_d[i] = fb->back_d[i] = IDM_MAX_LONG_DIST;
+        if (p->ids[i] < 0) continue;
+        const MdLane* L = &lanes[p->ids[i]];
+        float cur_long, tmp;
+        md_lane_local(L, px, py, &cur_long, &tmp);
+        float left_long = L->length - cur_long;
+        int found_front = 0, found_back = 0;
+        for (int j = 0; j < c->cap; ++j) {
+            if (j == self_slot) continue;
+            const MdShape* o = &s->shape[j];
+            if (!md_idm_is_candidate(o, px, py)) continue;
+            if (md_obj_lane_of(s, j) != p->ids[i]) continue;
+            float lg = md_fb_same_lane_gap(L, cur_long, o);
+            if (fb->front_d[i] > lg && lg > 0.0f) {
+                fb->front_d[i] = lg;
+                fb->front[i] = j;
+                found_front = 1;
+            }
+            if (lg < 0.0f && md_fabs(lg) < fb->back_d[i]) {
+                fb->back_d[i] = md_fabs(lg);
+                fb->back[i] = j;
+                found_back = 1;
+            }
+        }
+        if (found_front && found_back) continue;
+        for (int j = 0; j < c->cap; ++j) {
+            if (j == self_slot) continue;
+            const MdShape* o = &s->shape[j];
+            if (!md_idm_is_candidate(o, px, py)) continue;
+            int ol = md_obj_lane_of(s, j);
+            if (ol < 0 || ol == p->ids[i]) continue;
+            float lg;
+            int cls = md_fb_neighbour(L, &lanes[ol], cur_long, left_long, o, !found_front, !found_back, &lg);
+            if (cls == 1) {
+                if (fb->front_d[i] > lg && lg > 0.0f) {
+                    fb->front_d[i] = lg;
+                    fb->front[i] = j;
+                }
+            } else if (cls == 2) {
+                if (fb->back_d[i] > lg) {
+                    fb->back_d[i] = lg;
+                    fb->back[i] = j;
+                }
+            }
         }
     }
+}
+
+/* Stage C */
+MD_HD void md_idm_decide(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, const MdIdmPlan* p,
+                         const FrontBack* fbp) {
+    (void)c;
+    MdShape* sh = &s->shape[slot];
+    MdNav* nav = &s->nav[slot];
+    MdPid* pid = &s->pid[slot];
+    MdDyn* d = &s->dyn[slot];
+    int m = w->env_map[e];
+    const MdLane* lanes = w->lanes + w->lane_off[m];
+    const MdRoad* roads = w->roads + w->road_off[m];
+    const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
+    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    int has_next = nav->ck1 != nav->ck0;
+    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : 0;
+    float px = sh->cx, py = sh->cy;
+    float speed_kmh = md_fabs(d->speed) * 3.6f;
+    FrontBack fb = *fbp;
 
     int front_obj = -1;
     float front_dist = 5.0f;
     int steer_lane = nav->target_lane;
-    int fail = (nav->target_lane < 0);
+    int fail = p->fail;
     if (!fail) {
-        FrontBack fb;
-        if (success && c->enable_idm_lane_change) {
+        if (p->use_ref) {
             /* ---- lane_change_policy (idm_policy.py:330-402) ---- */
-            md_find_front_back(s, c, lanes, base, slot, cand, nav->target_lane, 1, cur_road, px, py, &fb);
             int ncur = cur_road->n_lanes;
             int avail_lo = 0, avail_hi = ncur - 1;
             int lane_num_diff = has_next ? (ncur - next_road->n_lanes) : 0;
@@ -412,17 +494,17 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
             if (!decided && !fail) {
                 int overtake = 0;
                 if (md_fabs(speed_kmh - IDM_NORMAL_SPEED) > 3.0f && fb.front[1] >= 0) {
-                    float fsp = md_fabs(s->dyn[base + fb.front[1]].speed) * 3.6f;
+                    float fsp = md_fabs(s->dyn[fb.front[1]].speed) * 3.6f;
                     if (md_fabs(fsp - IDM_NORMAL_SPEED) > 3.0f && nav->timer > IDM_LANE_CHANGE_FREQ) overtake = 1;
                 }
                 if (overtake) {
                     /* speeds of neighbours; -1 encodes None */
                     float right_sp = -1.0f, left_sp = -1.0f;
-                    if (fb.front[2] >= 0) right_sp = md_fabs(s->dyn[base + fb.front[2]].speed) * 3.6f;
+                    if (fb.front[2] >= 0) right_sp = md_fabs(s->dyn[fb.front[2]].speed) * 3.6f;
                     else if (fb.exist[2] && fb.front_d[2] > IDM_SAFE_LANE_CHANGE && fb.back_d[2] > IDM_SAFE_LANE_CHANGE)
                         right_sp = IDM_MAX_SPEED;
-                    float front_sp = md_fabs(s->dyn[base + fb.front[1]].speed) * 3.6f;
-                    if (fb.front[0] >= 0) left_sp = md_fabs(s->dyn[base + fb.front[0]].speed) * 3.6f;
+                    float front_sp = md_fabs(s->dyn[fb.front[1]].speed) * 3.6f;
+                    if (fb.front[0] >= 0) left_sp = md_fabs(s->dyn[fb.front[0]].speed) * 3.6f;
                     else if (fb.exist[0] && fb.front_d[0] > IDM_SAFE_LANE_CHANGE && fb.back_d[0] > IDM_SAFE_LANE_CHANGE)
                         left_sp = IDM_MAX_SPEED;
                     if (left_sp >= 0.0f && left_sp - front_sp > IDM_LANE_CHANGE_SPEED_INC) {
@@ -449,7 +531,6 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
                 }
             }
         } else {
-            md_find_front_back(s, c, lanes, base, slot, cand, nav->target_lane, 0, cur_road, px, py, &fb);
             front_obj = fb.front[1];
             front_dist = fb.front_d[1];
             steer_lane = nav->target_lane;
@@ -461,8 +542,8 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
         steer_lane = nav->target_lane;
     }
     if (steer_lane < 0) { /* never localised: coast straight */
-        s->action[2 * n] = 0.0f;
-        s->action[2 * n + 1] = 0.0f;
+        s->action[2 * slot] = 0.0f;
+        s->action[2 * slot + 1] = 0.0f;
         return;
     }
     /* ---- steering_control (idm_policy.py:293-301) ---- */
@@ -475,16 +556,32 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
     /* ---- acceleration (idm_policy.py:303-320) ---- */
     float dv = 0.0f;
     if (front_obj >= 0) {
-        const MdShape* fo = &s->shape[base + front_obj];
-        float fv = (md_kind_of(fo->flags) == MD_KIND_VEHICLE) ? s->dyn[base + front_obj].speed : 0.0f;
+        const MdShape* fo = &s->shape[front_obj];
+        float fv = (md_kind_of(fo->flags) == MD_KIND_VEHICLE) ? s->dyn[front_obj].speed : 0.0f;
         float evx = d->speed * sh->c * 3.6f, evy = d->speed * sh->s * 3.6f;
         float fvx = fv * fo->c * 3.6f, fvy = fv * fo->s * 3.6f;
         dv = (evx - fvx) * sh->c + (evy - fvy) * sh->s;
     }
     float acc = md_idm_acceleration(speed_kmh, pid->target_speed, front_obj >= 0, front_dist, dv);
-    s->action[2 * n] = steering;
-    s->action[2 * n + 1] = acc;
+    s->action[2 * slot] = steering;
+    s->action[2 * slot + 1] = acc;
 }
 
+/* All three stages for one vehicle, serial. */
+MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot) {
+    MdIdmPlan plan;
+    FrontBack fb;
+    md_idm_plan(w, s, c, e, slot, &plan);
+    for (int i = 0; i < 3; ++i) {
+        fb.front[i] = fb.back[i] = -1;
+        fb.exist[i] = 0;
+        fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
+    }
+    if (!plan.fail) {
+        const MdLane* lanes = w->lanes + w->lane_off[w->env_map[e]];
+        md_find_front_back(s, c, lanes, slot, &plan, s->shape[slot].cx, s->shape[slot].cy, &fb);
+    }
+    md_idm_decide(w, s, c, e, slot, &plan, &fb);
+}
 
 #endif /* MD_ENTITY_H */

@@ -94,6 +94,7 @@ BATCH_DEFAULT_CONFIG = dict(
     mover_capacity=64,      # slots per env: agents + traffic + props
     auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
     device="cuda:0",
+    build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
 )
 
 _OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False, discrete_action=False,

@@ -61,10 +61,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
 // ------------------------------------------------------------------------------------------------
 // Lidar for one (agent, sector) work item, executed by one wave.
 // ------------------------------------------------------------------------------------------------
-__device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int a, int sec, int lane,
+__device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int a, int sec, int lane,
                            float* __restrict__ out_row) {
-    const int base = e * c.cap;
-    const MdShape me = s.shape[base + a];  // wave-uniform
+    const MdShape me = s.shape[a];  // wave-uniform (s is the env-local, LDS-staged view)
     const int beam = sec * 64 + lane;
     const bool valid = beam < c.n_beams;
     if (!md_present(me.flags)) {
@@ -118,7 +117,7 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
         const int j = j0 + lane;
         MdShape o;
         o.flags = 0;
-        if (j < c.cap) o = s.shape[base + j];
+        if (j < c.cap) o = s.shape[j];
         bool keep = (j < c.cap) && (j != a) && md_present(o.flags);
         if (keep) {
             const float ddx = o.cx - me.cx, ddy = o.cy - me.cy;
@@ -154,14 +153,14 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
 }
 
 __device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, float* out,
-                            int out_stride, int out_offset) {
+                            int out_stride, int out_offset) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
     const int nsec = (c.n_beams + 63) >> 6;
     const int items = c.agents_per_env * nsec;
     for (int it = wave; it < items; it += kWaves) {
         const int a = it / nsec, sec = it - a * nsec;
         float* row = out + (size_t)(e * c.agents_per_env + a) * out_stride + out_offset;
-        lidar_item(w, s, c, e, a, sec, lane, row);
+        lidar_item(w, s, c, a, sec, lane, row);
     }
 }
 
@@ -201,6 +200,7 @@ __device__ __forceinline__ int grid_clampi(int v, int lo, int hi) { return v < l
 // Localisation, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
 __device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int n, int lane_id) {
+    // n = slot inside the env-local view
     const MdShape sh = s.shape[n];
     if (!md_drives(sh.flags)) return;
     MdNav nav = s.nav[n];
@@ -284,8 +284,8 @@ __device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int 
 // Contacts, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
 __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id) {
-    const int base = e * c.cap;
-    const int n = base + slot;
+    const int base = 0;  // env-local view
+    const int n = slot;
     const MdShape me = s.shape[n];
     if (!md_drives(me.flags)) return;
     uint32_t fl = 0;
@@ -346,10 +346,100 @@ __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdCon
 }
 
 // ------------------------------------------------------------------------------------------------
+// IDM for one traffic vehicle, executed by one wave: lanes = candidate objects; the lead / rear
+// vehicle gap scan is a wavefront arg-min reduction (key = gap, tie -> lowest slot), which is the
+// order-independent form of FrontBackObjects.get_find_front_back_objs (policy/idm_policy.py:82-132).
+// Stages A (route bookkeeping) and C (lane-change policy, PID steering, IDM acceleration) are
+// scalar and run on lane 0.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_argmin(float& key, int& slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float k2 = __shfl_xor(key, off, 64);
+        const int s2 = __shfl_xor(slot, off, 64);
+        const bool take = (k2 < key) || (k2 == key && s2 < slot);
+        key = take ? k2 : key;
+        slot = take ? s2 : slot;
+    }
+}
+
+__device__ void idm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id) {
+    constexpr float kInf = 3.0e38f;
+    MdIdmPlan plan;
+    plan.success = plan.use_ref = plan.fail = 0;
+    plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
+    if (lane_id == 0) md_idm_plan(&w, &s, &c, e, slot, &plan);
+    plan.success = bcast_i(plan.success, 0);
+    plan.use_ref = bcast_i(plan.use_ref, 0);
+    plan.fail = bcast_i(plan.fail, 0);
+    plan.ids[0] = bcast_i(plan.ids[0], 0);
+    plan.ids[1] = bcast_i(plan.ids[1], 0);
+    plan.ids[2] = bcast_i(plan.ids[2], 0);
+    FrontBack fb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fb.front[i] = fb.back[i] = -1;
+        fb.exist[i] = plan.ids[i] >= 0 && !plan.fail;
+        fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
+    }
+    if (!plan.fail) {
+        const MdLane* lanes = w.lanes + w.lane_off[w.env_map[e]];
+        const float px = s.shape[slot].cx, py = s.shape[slot].cy;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (plan.ids[i] < 0) continue;  // wave-uniform
+            const MdLane* L = &lanes[plan.ids[i]];
+            float cur_long, tmp;
+            md_lane_local(L, px, py, &cur_long, &tmp);
+            const float left_long = L->length - cur_long;
+            int found_front = 0, found_back = 0;
+            // pass 1: objects on the same lane
+            for (int j0 = 0; j0 < c.cap; j0 += 64) {
+                const int j = j0 + lane_id;
+                float kf = kInf, kb = kInf;
+                if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py) &&
+                    md_obj_lane_of(&s, j) == plan.ids[i]) {
+                    const float lg = md_fb_same_lane_gap(L, cur_long, &s.shape[j]);
+                    if (lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
+                    if (lg < 0.0f && md_fabs(lg) < IDM_MAX_LONG_DIST) kb = md_fabs(lg);
+                }
+                int jf = j, jb = j;
+                wave_argmin(kf, jf);
+                wave_argmin(kb, jb);
+                if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; found_front = 1; }
+                if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; found_back = 1; }
+            }
+            if (found_front && found_back) continue;
+            // pass 2: objects on the successor / predecessor lane
+            for (int j0 = 0; j0 < c.cap; j0 += 64) {
+                const int j = j0 + lane_id;
+                float kf = kInf, kb = kInf;
+                if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py)) {
+                    const int ol = md_obj_lane_of(&s, j);
+                    if (ol >= 0 && ol != plan.ids[i]) {
+                        float lg;
+                        const int cls = md_fb_neighbour(L, &lanes[ol], cur_long, left_long, &s.shape[j], !found_front,
+                                                        !found_back, &lg);
+                        if (cls == 1 && lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
+                        if (cls == 2 && lg < IDM_MAX_LONG_DIST) kb = lg;
+                    }
+                }
+                int jf = j, jb = j;
+                wave_argmin(kf, jf);
+                wave_argmin(kb, jb);
+                if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; }
+                if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; }
+            }
+        }
+    }
+    if (lane_id == 0) md_idm_decide(&w, &s, &c, e, slot, &plan, &fb);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Traffic trigger (wave 0) -- PGTrafficManager.before_step, manager/traffic_manager.py:80-88
 // ------------------------------------------------------------------------------------------------
 __device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int lane_id) {
-    const int base = e * c.cap;
+    const int base = 0;  // env-local view
     const int m = w.env_map[e];
     const MdLane* lanes = w.lanes + w.lane_off[m];
     int my_min = 0x7fffffff;
@@ -389,75 +479,109 @@ __device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& 
 // The per-env kernel.  PH selects the phases (a compile-time mask: the single-phase entry points
 // instantiate it with one bit, md_step with all of them).
 // ------------------------------------------------------------------------------------------------
+// Cooperative 16-byte copy (both sides 16-byte aligned, nbytes a multiple of 16).
+__device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, int tid) {
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    for (int i = tid; i < (nbytes >> 4); i += kBlock) d[i] = s[i];
+}
+
 template <int PH>
-__global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState s, MdConfig c, float* lidar_out,
+__global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                                                      int lidar_stride, int lidar_offset) {
     const int e = blockIdx.x;
     if (e >= c.n_envs) return;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int base = e * c.cap;
-    __shared__ int sh_just_reset;
+    const int cap = c.cap;
 
-    if (tid == 0) sh_just_reset = 0;
-    __syncthreads();
+    // ---- LDS image of this env's dynamic state (dynamic LDS: cap * 172 B + 16 B) ----
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MdShape* l_shape = reinterpret_cast<MdShape*>(smem);
+    MdDyn* l_dyn = reinterpret_cast<MdDyn*>(l_shape + cap);
+    MdNav* l_nav = reinterpret_cast<MdNav*>(l_dyn + cap);
+    MdPid* l_pid = reinterpret_cast<MdPid*>(l_nav + cap);
+    float* l_action = reinterpret_cast<float*>(l_pid + cap);
+    uint32_t* l_flags = reinterpret_cast<uint32_t*>(l_action + 2 * cap);
 
-    if (PH & PH_RESET) {
-        if (s.need_reset[e]) {  // uniform per block
-            for (int j = tid; j < c.cap; j += kBlock) {
-                s.shape[base + j] = s.shape0[base + j];
-                s.dyn[base + j] = s.dyn0[base + j];
-                s.nav[base + j] = s.nav0[base + j];
-                s.pid[base + j] = s.pid0[base + j];
-                s.flags[base + j] = 0;
-                s.action[2 * (base + j)] = 0.0f;
-                s.action[2 * (base + j) + 1] = 0.0f;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                s.need_reset[e] = 0;
-                sh_just_reset = 1;
-            }
+    const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
+    constexpr bool kLidarOnly = (PH == PH_LIDAR);
+    const bool do_reset = (PH & PH_RESET) && gv.need_reset[0] != 0;  // block-uniform
+    const int just_reset = do_reset ? 1 : 0;
+
+    copy16(l_shape, do_reset ? gv.shape0 : gv.shape, cap * (int)sizeof(MdShape), tid);
+    if (!kLidarOnly) {
+        copy16(l_dyn, do_reset ? gv.dyn0 : gv.dyn, cap * (int)sizeof(MdDyn), tid);
+        copy16(l_nav, do_reset ? gv.nav0 : gv.nav, cap * (int)sizeof(MdNav), tid);
+        copy16(l_pid, do_reset ? gv.pid0 : gv.pid, cap * (int)sizeof(MdPid), tid);
+        for (int j = tid; j < cap; j += kBlock) {
+            l_action[2 * j] = do_reset ? 0.0f : gv.action[2 * j];
+            l_action[2 * j + 1] = do_reset ? 0.0f : gv.action[2 * j + 1];
+            l_flags[j] = do_reset ? 0u : gv.flags[j];
         }
-        __syncthreads();
     }
-    const int just_reset = sh_just_reset;
+    MdState s = gv;  // env-local view whose hot arrays live in LDS
+    s.shape = l_shape;
+    if (!kLidarOnly) {
+        s.dyn = l_dyn;
+        s.nav = l_nav;
+        s.pid = l_pid;
+        s.action = l_action;
+        s.flags = l_flags;
+    }
+    __syncthreads();
 
     if ((PH & PH_IDM) && !just_reset) {
         if (wave == 0) trigger_env(w, s, c, e, lane);
         __syncthreads();
-        for (int j = c.agents_per_env + tid; j < c.cap; j += kBlock) {
-            const int f = s.shape[base + j].flags;
-            if (md_drives(f) && !(f & MD_F_AGENT)) md_idm_vehicle(&w, &s, &c, e, j);
+        for (int j = c.agents_per_env + wave; j < cap; j += kWaves) {
+            const int f = s.shape[j].flags;  // wave-uniform
+            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, s, c, e, j, lane);
         }
         __syncthreads();
     }
     if ((PH & PH_INTEGRATE) && !just_reset) {
-        for (int j = tid; j < c.cap; j += kBlock) md_integrate_mover(&s, &c, base + j);
+        for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
         __syncthreads();
     }
     if (PH & PH_LOCALIZE) {
-        for (int j = wave; j < c.cap; j += kWaves) localize_vehicle(w, s, e, base + j, lane);
+        for (int j = wave; j < cap; j += kWaves) localize_vehicle(w, s, e, j, lane);
         __syncthreads();
     }
     if (PH & PH_CONTACTS) {
-        for (int j = wave; j < c.cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
+        for (int j = wave; j < cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
         __syncthreads();
     }
     if (PH & PH_TRAFFIC) {
-        for (int j = tid; j < c.cap; j += kBlock) {
-            const int f = s.shape[base + j].flags;
-            if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[base + j] & MD_FL_ON_LANE))
-                s.shape[base + j].flags = f & ~MD_F_ALIVE;
+        for (int j = tid; j < cap; j += kBlock) {
+            const int f = s.shape[j].flags;
+            if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) s.shape[j].flags = f & ~MD_F_ALIVE;
         }
         __syncthreads();
     }
     if (PH & PH_OBSERVE) {
         for (int a = tid; a < c.agents_per_env; a += kBlock) md_observe_agent(&w, &s, &c, e, a, just_reset);
-        // lidar only reads shapes; observe writes obs[0:19], flags, nav -- no barrier needed before lidar
+        // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
     if (PH & PH_LIDAR) {
         if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, lidar_out, lidar_stride, lidar_offset);
+    }
+
+    // ---- write the modified arrays back (coalesced 16-byte stores) ----
+    if (!kLidarOnly) {
+        __syncthreads();
+        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid);
+        if (PH & (PH_RESET | PH_INTEGRATE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid);
+        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid);
+        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid);
+        for (int j = tid; j < cap; j += kBlock) {
+            if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE)) {
+                gv.action[2 * j] = l_action[2 * j];
+                gv.action[2 * j + 1] = l_action[2 * j + 1];
+            }
+            if (PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE)) gv.flags[j] = l_flags[j];
+        }
+        if (do_reset && tid == 0) gv.need_reset[0] = 0;
     }
 }
 
@@ -504,7 +628,8 @@ int need(const void* p, const char* name) {
 template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
-    hipLaunchKernelGGL(env_kernel<PH>, dim3(c->n_envs), dim3(kBlock), 0, (hipStream_t)stream, *w, *s, *c, lidar_out,
+    const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 12) + 16;
+    hipLaunchKernelGGL(env_kernel<PH>, dim3(c->n_envs), dim3(kBlock), lds, (hipStream_t)stream, *w, *s, *c, lidar_out,
                        stride, offset);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
@@ -519,6 +644,12 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
         int _r = need((const void*)(p), #p);     \
         if (_r != MD_OK) return _r;              \
     } while (0)
+
+int check_state(const MdState* s) {
+    NEED(s->shape); NEED(s->dyn); NEED(s->param); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->flags);
+    NEED(s->route_nodes); NEED(s->route_roads); NEED(s->need_reset);
+    return MD_OK;
+}
 
 int check_world(const MdWorld* w) {
     NEED(w->env_map); NEED(w->lane_off); NEED(w->lanes); NEED(w->hull_xy); NEED(w->road_off); NEED(w->roads);
@@ -592,6 +723,8 @@ __attribute__((visibility("default"))) int md_integrate(const MdWorld* w, const 
                                                        void* stream) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
+    r = check_state(s);
+    if (r != MD_OK) return r;
     NEED(s->dyn); NEED(s->param); NEED(s->action);
     return launch<PH_INTEGRATE>(w, s, c, nullptr, 0, 0, stream);
 }
@@ -599,6 +732,8 @@ __attribute__((visibility("default"))) int md_integrate(const MdWorld* w, const 
 __attribute__((visibility("default"))) int md_localize(const MdWorld* w, const MdState* s, const MdConfig* c,
                                                       void* stream) {
     int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_state(s);
     if (r != MD_OK) return r;
     r = check_world(w);
     if (r != MD_OK) return r;
@@ -610,6 +745,8 @@ __attribute__((visibility("default"))) int md_contacts(const MdWorld* w, const M
                                                       void* stream) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
+    r = check_state(s);
+    if (r != MD_OK) return r;
     r = check_world(w);
     if (r != MD_OK) return r;
     NEED(s->flags);
@@ -619,6 +756,8 @@ __attribute__((visibility("default"))) int md_contacts(const MdWorld* w, const M
 __attribute__((visibility("default"))) int md_observe(const MdWorld* w, const MdState* s, const MdConfig* c,
                                                      void* stream) {
     int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_state(s);
     if (r != MD_OK) return r;
     r = check_world(w);
     if (r != MD_OK) return r;
@@ -634,6 +773,8 @@ __attribute__((visibility("default"))) int md_observe(const MdWorld* w, const Md
 __attribute__((visibility("default"))) int md_idm(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
+    r = check_state(s);
+    if (r != MD_OK) return r;
     r = check_world(w);
     if (r != MD_OK) return r;
     NEED(s->dyn); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_roads); NEED(s->idm_rand);
@@ -645,12 +786,16 @@ __attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* 
                                                                 void* stream) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
+    r = check_state(s);
+    if (r != MD_OK) return r;
     NEED(s->flags);
     return launch<PH_TRAFFIC>(w, s, c, nullptr, 0, 0, stream);
 }
 
 __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
     int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_state(s);
     if (r != MD_OK) return r;
     r = check_world(w);
     if (r != MD_OK) return r;

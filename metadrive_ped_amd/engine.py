@@ -9,6 +9,7 @@ env g uses scenario seed start_seed + g % num_scenarios, so results do not depen
 GPUs the batch is split over.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -18,6 +19,15 @@ from metadrive_ped_amd.mapgen.tables import MapTables, WorldTables, beam_table
 from metadrive_ped_amd.scene import EnvScene
 
 STATE_ARRAY_SPECS = None  # filled below
+
+
+def _build_one(job):
+    """One scenario seed -> (MapTables, EnvScene).  Module-level so that a fork pool can run it."""
+    s, mc, dist, scene_cfg = job
+    pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+               generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
+    mt = MapTables(pg)
+    return mt, EnvScene(s, mt, scene_cfg)
 
 
 class HostScene:
@@ -44,13 +54,20 @@ class HostScene:
                          spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"])
-        for s in uniq:
-            pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
-                       generate_type=mc["type"], generate_config=mc["config"], block_dist=cfg["block_dist_config"])
-            mt = MapTables(pg)
+        jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
+        workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
+        if len(jobs) >= 64 and workers > 1:
+            # reset-time host work only; fork BEFORE this process has touched the GPU (HostScene is built
+            # ahead of the first device allocation in BatchedEngine.build)
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(workers) as pool:
+                built = pool.map(_build_one, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
+        else:
+            built = [_build_one(j) for j in jobs]
+        for s, (mt, sc) in zip(uniq, built):
             map_of_seed[s] = len(tables)
             tables.append(mt)
-            scenes[s] = EnvScene(s, mt, scene_cfg)
+            scenes[s] = sc
         self.map_tables = tables
         self.scenes = scenes
         env_map = [map_of_seed[s] for s in seeds]
@@ -122,7 +139,7 @@ def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
 
 
 class BatchedEngine:
-    def __init__(self, cfg):
+    def __init__(self, cfg, host=None):
         import torch
         from metadrive_ped_amd import _lib
         self.torch = torch
@@ -133,7 +150,7 @@ class BatchedEngine:
         if self.device.type != "cuda":
             raise _lib.MdStepError("BatchedEngine needs a ROCm device (config['device']={!r}); there is no CPU "
                                    "fallback".format(cfg["device"]))
-        self.host = None
+        self.host = host
         self.build()
 
     # -- upload helpers ---------------------------------------------------------------------------
@@ -144,7 +161,8 @@ class BatchedEngine:
     def build(self):
         """(Re)generate maps + scenes on the host and upload.  BaseEnv.reset's map/agent/traffic managers."""
         torch = self.torch
-        self.host = HostScene(self.cfg)
+        if self.host is None:
+            self.host = HostScene(self.cfg)
         h = self.host
         self.E, self.A, self.cap = h.E, h.A, h.cap
         self.n_beams, self.obs_dim = h.n_beams, h.obs_dim

@@ -14,7 +14,7 @@
  * IDM formulas) come from include/md_geom.h + md_math.h, shared with the HIP build so that the
  * comparison is bit-exact; see the headers for why.
  *
- * Parity pinning: tests/golden/*.json hold outputs of the reference's own Python (lanes, navi,
+ * Parity pinning: tests/golden/ (JSON fixtures) hold outputs of the reference's own Python (lanes, navi,
  * obs normalisation, reward/done, IDM/PID, lidar mask, RNG streams, PG topology per seed) generated
  * in the build container by oracle/gen/gen_golden.py; tests/test_oracle_golden.py checks this file
  * against them.  Parts whose numbers come out of Bullet in the reference (vehicle trajectories,
@@ -245,7 +245,10 @@ EXPORT int ref_traffic_after_step(const MdWorld* w, const MdState* s, const MdCo
  * -----------------------------------------------------------------------------------------*/
 EXPORT int ref_observe(const MdWorld* w, const MdState* s, const MdConfig* c) {
     for (int e = 0; e < c->n_envs; ++e)
-        for (int a = 0; a < c->agents_per_env; ++a) md_observe_agent(w, s, c, e, a, 0);
+        for (int a = 0; a < c->agents_per_env; ++a) {
+            MdState v = md_env_view(s, c, e);
+            md_observe_agent(w, &v, c, e, a, 0);
+        }
     return MD_OK;
 }
 
@@ -296,7 +299,8 @@ static void idm_env(const MdWorld* w, const MdState* s, const MdConfig* c, int e
     for (int j = c->agents_per_env; j < c->cap; ++j) {
         const MdShape* o = &s->shape[base + j];
         if (!drives(o->flags) || (o->flags & MD_F_AGENT)) continue;
-        md_idm_vehicle(w, s, c, e, j);
+        MdState v = md_env_view(s, c, e);
+        md_idm_vehicle(w, &v, c, e, j);
     }
 }
 
@@ -336,7 +340,8 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         if (!(s->flags[base + j] & MD_FL_ON_LANE)) sh->flags &= ~MD_F_ALIVE;
     }
     for (int a = 0; a < c->agents_per_env; ++a) {
-        md_observe_agent(w, s, c, e, a, just_reset);
+        MdState v = md_env_view(s, c, e);
+        md_observe_agent(w, &v, c, e, a, just_reset);
         if (c->n_beams > 0)
             lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + 19);
     }
