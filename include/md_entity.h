@@ -82,7 +82,9 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     d->steering = steer;
     d->throttle = thr;
     float x = sh->cx, y = sh->cy, psi = d->heading, v = d->speed;
-    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, steer, thr, &s->param[n], c->dt);
+    MdBicycle bike;
+    md_bicycle_prepare(steer, thr, &s->param[n], &bike);
+    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, thr, &bike, &s->param[n], c->dt);
     sh->cx = x;
     sh->cy = y;
     d->heading = psi;
@@ -91,7 +93,8 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
 }
 
 
-MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, int just_reset) {
+MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c, int a,
+                             int just_reset) {
     int n = a;
     int ai = a; /* env-local view: agent a of this env */
     float* obs = s->obs + (size_t)ai * c->obs_dim;
@@ -106,9 +109,6 @@ MD_HD void md_observe_agent(const MdWorld* w, const MdState* s, const MdConfig* 
         for (int i = 0; i < 8; ++i) info[i] = 0.0f;
         return;
     }
-    int m = w->env_map[e];
-    const MdLane* lanes = w->lanes + w->lane_off[m];
-    const MdRoad* roads = w->roads + w->road_off[m];
     const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
     const MdRoad* cur_road = &roads[rroads[nav->ck0]];
     int has_next = nav->ck1 != nav->ck0;
@@ -325,11 +325,10 @@ MD_HD int md_fb_neighbour(const MdLane* L, const MdLane* OL, float cur_long, flo
 }
 
 /* Stage A */
-MD_HD void md_idm_plan(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, MdIdmPlan* p) {
+MD_HD void md_idm_plan(const MdWorld* w, const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c,
+                        int e, int slot, MdIdmPlan* p) {
     MdNav* nav = &s->nav[slot];
     int m = w->env_map[e];
-    const MdLane* lanes = w->lanes + w->lane_off[m];
-    const MdRoad* roads = w->roads + w->road_off[m];
     const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
     const MdRoad* cur_road = &roads[rroads[nav->ck0]];
     int success;
@@ -428,16 +427,12 @@ MD_HD void md_find_front_back(const MdState* s, const MdConfig* c, const MdLane*
 }
 
 /* Stage C */
-MD_HD void md_idm_decide(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, const MdIdmPlan* p,
+MD_HD void md_idm_decide(const MdLane* lanes, const MdRoad* roads, const MdState* s, int slot, const MdIdmPlan* p,
                          const FrontBack* fbp) {
-    (void)c;
     MdShape* sh = &s->shape[slot];
     MdNav* nav = &s->nav[slot];
     MdPid* pid = &s->pid[slot];
     MdDyn* d = &s->dyn[slot];
-    int m = w->env_map[e];
-    const MdLane* lanes = w->lanes + w->lane_off[m];
-    const MdRoad* roads = w->roads + w->road_off[m];
     const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
     const MdRoad* cur_road = &roads[rroads[nav->ck0]];
     int has_next = nav->ck1 != nav->ck0;
@@ -571,17 +566,16 @@ MD_HD void md_idm_decide(const MdWorld* w, const MdState* s, const MdConfig* c, 
 MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot) {
     MdIdmPlan plan;
     FrontBack fb;
-    md_idm_plan(w, s, c, e, slot, &plan);
+    const MdLane* lanes = w->lanes + w->lane_off[w->env_map[e]];
+    const MdRoad* roads = w->roads + w->road_off[w->env_map[e]];
+    md_idm_plan(w, lanes, roads, s, c, e, slot, &plan);
     for (int i = 0; i < 3; ++i) {
         fb.front[i] = fb.back[i] = -1;
         fb.exist[i] = 0;
         fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
     }
-    if (!plan.fail) {
-        const MdLane* lanes = w->lanes + w->lane_off[w->env_map[e]];
-        md_find_front_back(s, c, lanes, slot, &plan, s->shape[slot].cx, s->shape[slot].cy, &fb);
-    }
-    md_idm_decide(w, s, c, e, slot, &plan, &fb);
+    if (!plan.fail) md_find_front_back(s, c, lanes, slot, &plan, s->shape[slot].cx, s->shape[slot].cy, &fb);
+    md_idm_decide(lanes, roads, s, slot, &plan, &fb);
 }
 
 #endif /* MD_ENTITY_H */

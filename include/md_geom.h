@@ -246,17 +246,37 @@ MD_HD int md_lane_is_previous_of(const MdLane* A, const MdLane* B) {
  * psidot = v sin(beta)/lr.  Longitudinal: engine accel while throttle>=0 and speed below max,
  * constant idle-brake drag, brake decel capped by tyre friction; no reverse (enable_reverse=False).
  * -----------------------------------------------------------------------------------------*/
-MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float steer, float throttle,
+typedef struct MdBicycle {
+    float acc, dec;   /* engine acceleration / opposing deceleration for this step's action */
+    float beta;       /* slip angle atan(lr/(lf+lr) tan(delta))                              */
+    float sb_over_lr; /* sin(beta) / lr                                                      */
+} MdBicycle;
+
+/* Everything that depends on the action only (constant over the decision_repeat sub-steps), except
+ * the engine cut-off which looks at the current speed (base_vehicle.py:474). */
+MD_HD void md_bicycle_prepare(float steer, float throttle, const MdParam* P, MdBicycle* b) {
+    b->acc = (throttle > 0.0f) ? P->accel_gain * throttle : 0.0f;
+    if (throttle >= 0.0f) b->dec = P->roll_decel; /* setBrake(2.0): idle drag when the engine is idle / cut */
+    else b->dec = md_min(-throttle * P->brake_gain, P->fric_decel);
+    float delta = steer * P->max_steer;
+    float sd, cd;
+    md_sincos(delta, &sd, &cd);
+    float tan_d = sd / cd;
+    b->beta = md_atan(P->lr / (P->lf + P->lr) * tan_d);
+    float sb, cb;
+    md_sincos(b->beta, &sb, &cb);
+    b->sb_over_lr = sb / P->lr;
+}
+
+MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float throttle, const MdBicycle* b,
                               const MdParam* P, float dt) {
     float vv = *v;
     float speed_kmh = md_fabs(vv) * 3.6f;
     float acc = 0.0f, dec = 0.0f;
     if (throttle > 0.0f && !(speed_kmh > P->max_speed_kmh)) {
-        acc = P->accel_gain * throttle; /* engine force on 4 wheels; Bullet applies no brake impulse then */
-    } else if (throttle >= 0.0f) {
-        dec = P->roll_decel;            /* setBrake(2.0): idle drag, also above max speed */
+        acc = b->acc; /* engine force on 4 wheels; Bullet applies no brake impulse then */
     } else {
-        dec = md_min(-throttle * P->brake_gain, P->fric_decel);
+        dec = b->dec;
     }
     /* drag/brake opposes motion and never reverses it within a sub-step */
     float vnew = vv + acc * dt;
@@ -268,19 +288,12 @@ MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float st
         vnew = vnew + dv;
         if (vnew > 0.0f) vnew = 0.0f;
     }
-    float delta = steer * P->max_steer;
-    float sd, cd;
-    md_sincos(delta, &sd, &cd);
-    float tan_d = sd / cd;
-    float beta = md_atan(P->lr / (P->lf + P->lr) * tan_d);
-    float sb, cb;
-    md_sincos(beta, &sb, &cb);
     float sp, cp;
-    md_sincos(*psi + beta, &sp, &cp);
+    md_sincos(*psi + b->beta, &sp, &cp);
     float vm = 0.5f * (vv + vnew);
     *x = *x + vm * cp * dt;
     *y = *y + vm * sp * dt;
-    *psi = md_wrap_to_pi(*psi + vm * sb / P->lr * dt);
+    *psi = md_wrap_to_pi(*psi + vm * b->sb_over_lr * dt);
     *v = vnew;
 }
 

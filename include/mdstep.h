@@ -201,6 +201,8 @@ typedef struct MdWorld {
     const int32_t* node_adj;       /* [..] pairs flattened: (to_node, road_id)                  */
     const int32_t* node_off;       /* [n_maps+1] offset of each map's nodes in node_adj_off     */
     const float* beam_cs;      /* [n_beams][2] cos/sin of (2*pi*i/n_beams + phase)              */
+    int32_t max_lanes;         /* largest lane count of any map (sizes the kernels' LDS lane table) */
+    int32_t max_roads;         /* largest road count of any map                                 */
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */

@@ -76,6 +76,7 @@ class MdWorld(C.Structure):
         ("env_map", P), ("lane_off", P), ("lanes", P), ("hull_xy", P), ("road_off", P), ("roads", P),
         ("quad_off", P), ("quads", P), ("quad_kind", P), ("grid", P), ("cell_start", P), ("cell_items", P),
         ("node_adj_off", P), ("node_adj", P), ("node_off", P), ("beam_cs", P),
+        ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
     ]
 
 

@@ -24,13 +24,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "md_entity.h"
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / 64;
+constexpr int kBlock = 256;  // block size of the auxiliary kernels; env_kernel is templated on its own
 
 enum Phase : int {
     PH_RESET = 1,
@@ -46,16 +46,35 @@ enum Phase : int {
 
 thread_local char g_err[256] = "ok";
 
+// In-kernel phase stamps: DIAGNOSTIC BUILD ONLY (-DMD_STAMP, tools/stamp_profile.py).  The stamp
+// values go to a buffer of their own that no kernel code reads; the production build contains none.
+#ifdef MD_STAMP
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define MD_STAMP_AT(i)                                                                         \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define MD_STAMP_AT(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
+// Wavefront min-reduce over the lanes whose `valid` is set; returns `none` when no lane is valid.
+// Built from a 64-bit ballot + v_readlane walks over the set bits: on gfx950 __shfl_xor lowers to
+// ds_bpermute (an LDS-crossbar round trip of ~100+ cycles per step), and the candidate sets here are
+// sparse (a handful of lanes), so walking the ballot is several times faster than a 6-step butterfly.
+__device__ __forceinline__ int wave_min_i(int v, bool valid, int none) {
+    unsigned long long m = __ballot(valid);
+    int best = none;
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int o = __shfl(v, l, 64);
+        best = o < best ? o : best;
     }
-    return v;
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -152,8 +171,8 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
     if (valid) out_row[beam] = best;
 }
 
-__device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, float* out,
-                            int out_stride, int out_offset) {  // `out` is the GLOBAL output base
+__device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
+                            float* out, int out_stride, int out_offset) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
     const int nsec = (c.n_beams + 63) >> 6;
     const int items = c.agents_per_env * nsec;
@@ -199,13 +218,13 @@ __device__ __forceinline__ int grid_clampi(int v, int lo, int hi) { return v < l
 // ------------------------------------------------------------------------------------------------
 // Localisation, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
-__device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int n, int lane_id) {
-    // n = slot inside the env-local view
+__device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
+                                 int n, int lane_id) {
+    // n = slot inside the env-local view; lanes / roads = this env's map tables (LDS copies)
     const MdShape sh = s.shape[n];
     if (!md_drives(sh.flags)) return;
     MdNav nav = s.nav[n];
     const int m = w.env_map[e];
-    const MdLane* lanes = w.lanes + w.lane_off[m];
     const int32_t* rroads = s.route_roads + (size_t)n * MD_ROUTE_LEN;
     const int32_t* rnodes = s.route_nodes + (size_t)n * MD_ROUTE_LEN;
     const int cur_road = rroads[nav.ck0];
@@ -224,34 +243,53 @@ __device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int 
     int on_lane = 0;
     int best_any = -1, best_cur = -1, best_next = -1;
     float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
-    for (int it = it0; it < it1; ++it) {
-        const int l = w.cell_items[it];
-        if (l < 0) continue;  // quad item
-        const MdLane* L = &lanes[l];
-        if (sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1) continue;
-        // hull containment: edges spread over the 64 lanes, ballot vote
-        const float* xy = w.hull_xy + 2 * (size_t)L->hull_off;
-        const int hn = L->hull_n;
-        bool outside = false;
-        for (int i = lane_id; i < hn; i += 64) {
-            const int j = (i + 1 == hn) ? 0 : i + 1;
-            const float ex = xy[2 * j] - xy[2 * i], ey = xy[2 * j + 1] - xy[2 * i + 1];
-            const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
-            if (cr < 0.0f) outside = true;
+    // Candidate lanes of the cell: each LANE fetches one cell item and its lane record's hull AABB
+    // (three dependent loads done 64-wide instead of once per candidate), survivors are visited in
+    // ascending lane id through the ballot mask (ties in distance resolve to the lowest lane id, like
+    // the oracle's ascending scan).
+    for (int itb = it0; itb < it1; itb += 64) {
+        const int it = itb + lane_id;
+        int l = -1, h_off = 0, h_n = 0;
+        bool pass = false;
+        if (it < it1) {
+            l = w.cell_items[it];
+            if (l >= 0) {
+                const MdLane* L = &lanes[l];
+                pass = !(sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1);
+                h_off = L->hull_off;
+                h_n = L->hull_n;
+            }
         }
-        if (__ballot(outside) != 0ull || hn < 3) continue;
-        on_lane = 1;
-        float ls, llat;
-        md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
-        const float lh = md_lane_heading_at(L, ls);
-        float hs_, hc_;
-        md_sincos(lh, &hs_, &hc_);
-        const float cosangle = hc_ * sh.c + hs_ * sh.s;
-        if (!(cosangle > 0.0f)) continue;
-        const float dist = md_lane_distance(L, ls, llat);
-        if (dist < d_any) { d_any = dist; best_any = l; }
-        if (L->road == cur_road && dist < d_cur) { d_cur = dist; best_cur = l; }
-        if (has_next && L->road == next_road && dist < d_next) { d_next = dist; best_next = l; }
+        unsigned long long mask = __ballot(pass);
+        while (mask) {
+            const int k = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int lk = bcast_i(l, k);
+            const int hn = bcast_i(h_n, k);
+            const float* xy = w.hull_xy + 2 * (size_t)bcast_i(h_off, k);
+            // hull containment: edges spread over the 64 lanes, ballot vote
+            bool outside = false;
+            for (int i = lane_id; i < hn; i += 64) {
+                const int j = (i + 1 == hn) ? 0 : i + 1;
+                const float ex = xy[2 * j] - xy[2 * i], ey = xy[2 * j + 1] - xy[2 * i + 1];
+                const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
+                if (cr < 0.0f) outside = true;
+            }
+            if (__ballot(outside) != 0ull || hn < 3) continue;
+            on_lane = 1;
+            const MdLane* L = &lanes[lk];
+            float ls, llat;
+            md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
+            const float lh = md_lane_heading_at(L, ls);
+            float hs_, hc_;
+            md_sincos(lh, &hs_, &hc_);
+            const float cosangle = hc_ * sh.c + hs_ * sh.s;
+            if (!(cosangle > 0.0f)) continue;
+            const float dist = md_lane_distance(L, ls, llat);
+            if (dist < d_any) { d_any = dist; best_any = lk; }
+            if (L->road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
+            if (has_next && L->road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
+        }
     }
     if (lane_id != 0) return;  // everything below is wave-uniform; lane 0 commits
     int lane = -1;
@@ -269,7 +307,7 @@ __device__ void localize_vehicle(const MdWorld& w, const MdState& s, int e, int 
     float ls, llat;
     md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
     if (!(ls < 5.0f)) return;
-    const int start_node = w.roads[w.road_off[m] + lanes[lane].road].start_node;
+    const int start_node = roads[lanes[lane].road].start_node;
     const int k = nav.route_len;
     int idx = -1;
     for (int j = nav.ck1; j < k - 1; ++j) {
@@ -339,10 +377,14 @@ __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdCon
                 }
             }
     }
-    // wave OR-reduce of the flag word
+    // wave OR-reduce of the flag word: one ballot per flag bit that can be set here
+    uint32_t all = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fl |= (uint32_t)__shfl_xor((int)fl, off, 64);
-    if (lane_id == 0) s.flags[n] = (s.flags[n] & MD_FL_ON_LANE) | fl;
+    for (int b = 0; b < 9; ++b) {
+        const uint32_t bit = 1u << b;
+        if (__ballot((fl & bit) != 0) != 0ull) all |= bit;
+    }
+    if (lane_id == 0) s.flags[n] = (s.flags[n] & MD_FL_ON_LANE) | all;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,23 +394,33 @@ __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdCon
 // Stages A (route bookkeeping) and C (lane-change policy, PID steering, IDM acceleration) are
 // scalar and run on lane 0.
 // ------------------------------------------------------------------------------------------------
+// arg-min of (key, slot) over the wave; lanes holding kInf do not take part.  Ascending lane order
+// == ascending slot order, so the strict `<` keeps the lowest slot among equal keys.
 __device__ __forceinline__ void wave_argmin(float& key, int& slot) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float k2 = __shfl_xor(key, off, 64);
-        const int s2 = __shfl_xor(slot, off, 64);
-        const bool take = (k2 < key) || (k2 == key && s2 < slot);
-        key = take ? k2 : key;
-        slot = take ? s2 : slot;
+    unsigned long long m = __ballot(key < 3.0e38f);
+    float bk = 3.0e38f;
+    int bs = 0x7fffffff;
+    while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const float k = __shfl(key, l, 64);
+        const int sl = __shfl(slot, l, 64);
+        if (k < bk) {
+            bk = k;
+            bs = sl;
+        }
     }
+    key = bk;
+    slot = bs;
 }
 
-__device__ void idm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id) {
+__device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
+                                 const MdConfig& c, int e, int slot, int lane_id) {
     constexpr float kInf = 3.0e38f;
     MdIdmPlan plan;
     plan.success = plan.use_ref = plan.fail = 0;
     plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
-    if (lane_id == 0) md_idm_plan(&w, &s, &c, e, slot, &plan);
+    if (lane_id == 0) md_idm_plan(&w, lanes, roads, &s, &c, e, slot, &plan);
     plan.success = bcast_i(plan.success, 0);
     plan.use_ref = bcast_i(plan.use_ref, 0);
     plan.fail = bcast_i(plan.fail, 0);
@@ -383,7 +435,6 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdState& s, const MdCon
         fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
     }
     if (!plan.fail) {
-        const MdLane* lanes = w.lanes + w.lane_off[w.env_map[e]];
         const float px = s.shape[slot].cx, py = s.shape[slot].cy;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -432,16 +483,14 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdState& s, const MdCon
             }
         }
     }
-    if (lane_id == 0) md_idm_decide(&w, &s, &c, e, slot, &plan, &fb);
+    if (lane_id == 0) md_idm_decide(lanes, roads, &s, slot, &plan, &fb);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Traffic trigger (wave 0) -- PGTrafficManager.before_step, manager/traffic_manager.py:80-88
 // ------------------------------------------------------------------------------------------------
-__device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int lane_id) {
+__device__ void trigger_env(const MdLane* lanes, const MdState& s, const MdConfig& c, int lane_id) {
     const int base = 0;  // env-local view
-    const int m = w.env_map[e];
-    const MdLane* lanes = w.lanes + w.lane_off[m];
     int my_min = 0x7fffffff;
     for (int j = lane_id; j < c.cap; j += 64) {
         const int f = s.shape[base + j].flags;
@@ -450,7 +499,7 @@ __device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& 
             my_min = o < my_min ? o : my_min;
         }
     }
-    const int min_order = wave_min_i(my_min);  // wavefront min-reduce
+    const int min_order = wave_min_i(my_min, my_min != 0x7fffffff, 0x7fffffff);  // wavefront min-reduce
     if (min_order == 0x7fffffff) return;
     // trigger road of that block: lowest slot carrying min_order
     int my_slot = 0x7fffffff;
@@ -459,7 +508,7 @@ __device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& 
         if ((f & MD_F_PENDING) && (f & MD_F_ALIVE) && s.nav[base + j].trigger_order == min_order)
             my_slot = j < my_slot ? j : my_slot;
     }
-    const int first_slot = wave_min_i(my_slot);
+    const int first_slot = wave_min_i(my_slot, my_slot != 0x7fffffff, 0x7fffffff);
     const int trig_road = s.nav[base + first_slot].trigger_road;
     bool fire = false;
     for (int a = lane_id; a < c.agents_per_env; a += 64) {
@@ -480,15 +529,17 @@ __device__ void trigger_env(const MdWorld& w, const MdState& s, const MdConfig& 
 // instantiate it with one bit, md_step with all of them).
 // ------------------------------------------------------------------------------------------------
 // Cooperative 16-byte copy (both sides 16-byte aligned, nbytes a multiple of 16).
-__device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, int tid) {
+__device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, int tid, int nthreads) {
     uint4* d = reinterpret_cast<uint4*>(dst);
     const uint4* s = reinterpret_cast<const uint4*>(src);
-    for (int i = tid; i < (nbytes >> 4); i += kBlock) d[i] = s[i];
+    for (int i = tid; i < (nbytes >> 4); i += nthreads) d[i] = s[i];
 }
 
-template <int PH>
-__global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
-                                                     int lidar_stride, int lidar_offset) {
+template <int PH, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
+                                                    int lidar_stride, int lidar_offset) {
+    constexpr int kBlock = BLOCK;
+    constexpr int kWaves = BLOCK / 64;
     const int e = blockIdx.x;
     if (e >= c.n_envs) return;
     const int tid = threadIdx.x;
@@ -503,21 +554,56 @@ __global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdCon
     MdPid* l_pid = reinterpret_cast<MdPid*>(l_nav + cap);
     float* l_action = reinterpret_cast<float*>(l_pid + cap);
     uint32_t* l_flags = reinterpret_cast<uint32_t*>(l_action + 2 * cap);
+    // static tables of this env's map + the movers' routes: read many times by the serial per-vehicle
+    // logic, so they sit in LDS too (a dependent chain of HBM/L2 round trips otherwise)
+    int32_t* l_rroads = reinterpret_cast<int32_t*>(l_flags + ((cap + 3) & ~3));
+    MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
+    MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + w.max_lanes);
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
     constexpr bool kLidarOnly = (PH == PH_LIDAR);
-    const bool do_reset = (PH & PH_RESET) && gv.need_reset[0] != 0;  // block-uniform
-    const int just_reset = do_reset ? 1 : 0;
+    // The reset flag is loaded first but nothing below waits for it: the live state is staged
+    // unconditionally (one round trip) and only a resetting env re-stages from the snapshot.
+    const int reset_flag = (PH & PH_RESET) ? gv.need_reset[0] : 0;
 
-    copy16(l_shape, do_reset ? gv.shape0 : gv.shape, cap * (int)sizeof(MdShape), tid);
+    MD_STAMP_AT(0);
+    copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
+#ifndef MD_NO_STAGE_MAP
+    const MdLane* lanes = l_lanes;
+    const MdRoad* roads = l_roads;
+#else
+    const MdLane* lanes = w.lanes + w.lane_off[w.env_map[e]];
+    const MdRoad* roads = w.roads + w.road_off[w.env_map[e]];
+#endif
     if (!kLidarOnly) {
-        copy16(l_dyn, do_reset ? gv.dyn0 : gv.dyn, cap * (int)sizeof(MdDyn), tid);
-        copy16(l_nav, do_reset ? gv.nav0 : gv.nav, cap * (int)sizeof(MdNav), tid);
-        copy16(l_pid, do_reset ? gv.pid0 : gv.pid, cap * (int)sizeof(MdPid), tid);
+#ifndef MD_NO_STAGE_MAP
+        const int m = w.env_map[e];
+        const int lo = w.lane_off[m], ro = w.road_off[m];
+        copy16(l_lanes, w.lanes + lo, (w.lane_off[m + 1] - lo) * (int)sizeof(MdLane), tid, kBlock);
+        copy16(l_roads, w.roads + ro, (w.road_off[m + 1] - ro) * (int)sizeof(MdRoad), tid, kBlock);
+        copy16(l_rroads, gv.route_roads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
+#endif
+        copy16(l_dyn, gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+        copy16(l_nav, gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
+        copy16(l_pid, gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
         for (int j = tid; j < cap; j += kBlock) {
-            l_action[2 * j] = do_reset ? 0.0f : gv.action[2 * j];
-            l_action[2 * j + 1] = do_reset ? 0.0f : gv.action[2 * j + 1];
-            l_flags[j] = do_reset ? 0u : gv.flags[j];
+            l_action[2 * j] = gv.action[2 * j];
+            l_action[2 * j + 1] = gv.action[2 * j + 1];
+            l_flags[j] = gv.flags[j];
+        }
+    }
+    const bool do_reset = reset_flag != 0;  // block-uniform
+    const int just_reset = do_reset ? 1 : 0;
+    if (do_reset && !kLidarOnly) {
+        __syncthreads();
+        copy16(l_shape, gv.shape0, cap * (int)sizeof(MdShape), tid, kBlock);
+        copy16(l_dyn, gv.dyn0, cap * (int)sizeof(MdDyn), tid, kBlock);
+        copy16(l_nav, gv.nav0, cap * (int)sizeof(MdNav), tid, kBlock);
+        copy16(l_pid, gv.pid0, cap * (int)sizeof(MdPid), tid, kBlock);
+        for (int j = tid; j < cap; j += kBlock) {
+            l_action[2 * j] = 0.0f;
+            l_action[2 * j + 1] = 0.0f;
+            l_flags[j] = 0u;
         }
     }
     MdState s = gv;  // env-local view whose hot arrays live in LDS
@@ -528,30 +614,39 @@ __global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdCon
         s.pid = l_pid;
         s.action = l_action;
         s.flags = l_flags;
+#ifndef MD_NO_STAGE_MAP
+        s.route_roads = l_rroads;
+#endif
     }
     __syncthreads();
+    MD_STAMP_AT(1);
 
     if ((PH & PH_IDM) && !just_reset) {
-        if (wave == 0) trigger_env(w, s, c, e, lane);
+        if (wave == 0) trigger_env(lanes, s, c, lane);
         __syncthreads();
+        MD_STAMP_AT(2);
         for (int j = c.agents_per_env + wave; j < cap; j += kWaves) {
             const int f = s.shape[j].flags;  // wave-uniform
-            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, s, c, e, j, lane);
+            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, e, j, lane);
         }
         __syncthreads();
     }
+    MD_STAMP_AT(3);
     if ((PH & PH_INTEGRATE) && !just_reset) {
         for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
         __syncthreads();
     }
+    MD_STAMP_AT(4);
     if (PH & PH_LOCALIZE) {
-        for (int j = wave; j < cap; j += kWaves) localize_vehicle(w, s, e, j, lane);
+        for (int j = wave; j < cap; j += kWaves) localize_vehicle(w, lanes, roads, s, e, j, lane);
         __syncthreads();
     }
+    MD_STAMP_AT(5);
     if (PH & PH_CONTACTS) {
         for (int j = wave; j < cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
         __syncthreads();
     }
+    MD_STAMP_AT(6);
     if (PH & PH_TRAFFIC) {
         for (int j = tid; j < cap; j += kBlock) {
             const int f = s.shape[j].flags;
@@ -559,21 +654,25 @@ __global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdCon
         }
         __syncthreads();
     }
+    MD_STAMP_AT(7);
     if (PH & PH_OBSERVE) {
-        for (int a = tid; a < c.agents_per_env; a += kBlock) md_observe_agent(&w, &s, &c, e, a, just_reset);
+        for (int a = tid; a < c.agents_per_env; a += kBlock) md_observe_agent(lanes, roads, &s, &c, a, just_reset);
+        MD_STAMP_AT(8);
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
     if (PH & PH_LIDAR) {
-        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, lidar_out, lidar_stride, lidar_offset);
+        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset);
     }
 
+    MD_STAMP_AT(9);
     // ---- write the modified arrays back (coalesced 16-byte stores) ----
     if (!kLidarOnly) {
         __syncthreads();
-        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid);
-        if (PH & (PH_RESET | PH_INTEGRATE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid);
-        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid);
-        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid);
+        MD_STAMP_AT(10);
+        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+        if (PH & (PH_RESET | PH_INTEGRATE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
+        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
         for (int j = tid; j < cap; j += kBlock) {
             if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE)) {
                 gv.action[2 * j] = l_action[2 * j];
@@ -583,6 +682,7 @@ __global__ __launch_bounds__(kBlock) void env_kernel(MdWorld w, MdState g, MdCon
         }
         if (do_reset && tid == 0) gv.need_reset[0] = 0;
     }
+    MD_STAMP_AT(11);
 }
 
 __global__ void probe_kernel(int op, const float* a, const float* b, float* out, int n) {
@@ -628,9 +728,27 @@ int need(const void* p, const char* name) {
 template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
-    const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 12) + 16;
-    hipLaunchKernelGGL(env_kernel<PH>, dim3(c->n_envs), dim3(kBlock), lds, (hipStream_t)stream, *w, *s, *c, lidar_out,
-                       stride, offset);
+    const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
+                       (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
+                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 16;
+    if (lds > 64 * 1024 || w->max_lanes <= 0 || w->max_roads <= 0) {
+        snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
+                 lds, c->cap, w->max_lanes, w->max_roads);
+        return MD_EINVAL;
+    }
+    static const int block = [] {
+        const char* v = getenv("MD_BLOCK");  // tuning knob: threads per env workgroup (64 / 128 / 256)
+        const int b = v ? atoi(v) : 256;
+        return (b == 64 || b == 128 || b == 256) ? b : 256;
+    }();
+    const dim3 grid(c->n_envs);
+    const hipStream_t st = (hipStream_t)stream;
+    if (block == 64)
+        hipLaunchKernelGGL((env_kernel<PH, 64>), grid, dim3(64), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    else if (block == 128)
+        hipLaunchKernelGGL((env_kernel<PH, 128>), grid, dim3(128), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    else
+        hipLaunchKernelGGL((env_kernel<PH, 256>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
@@ -669,6 +787,14 @@ __attribute__((visibility("default"))) int md_abi(int32_t* sizes, int n) {
 }
 
 __attribute__((visibility("default"))) const char* md_last_error(void) { return g_err; }
+
+#ifdef MD_STAMP
+// diagnostic build only: buffer of n_envs * 16 uint64 device words, or NULL to stop stamping
+__attribute__((visibility("default"))) int md_debug_set_stamp_buffer(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? MD_OK : MD_ELAUNCH;
+}
+#endif
 
 __attribute__((visibility("default"))) int md_probe_math(int op, const float* a, const float* b, float* out, int n,
                                                         void* stream) {

@@ -133,6 +133,10 @@ def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
     w = abi.MdWorld()
     w.n_maps, w.n_envs = n_maps, n_envs
     abi.fill_struct(w, abi.WORLD_FIELDS, world_arrays, ptr_of)
+    lane_off = np.asarray(world_arrays["lane_off_host"])
+    road_off = np.asarray(world_arrays["road_off_host"])
+    w.max_lanes = int(np.diff(lane_off).max())
+    w.max_roads = int(np.diff(road_off).max())
     s = abi.MdState()
     abi.fill_struct(s, abi.STATE_FIELDS, state_arrays, ptr_of)
     return w, s, md_config
@@ -169,7 +173,9 @@ class BatchedEngine:
         self.world_dev = {k: self._to_dev(v) for k, v in h.world.arrays.items()}
         self.state_dev = {k: self._to_dev(v) for k, v in h.state.items()}
         ptr = lambda t: t.data_ptr()
-        self.w, self.s, self.k = make_structs(self.world_dev, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
+        wd = dict(self.world_dev)
+        wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
+        self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         sd = self.state_dev
         # typed views for the env API
         self.obs = sd["obs"].view(torch.float32).view(self.E, self.A, self.obs_dim)

@@ -1,0 +1,114 @@
+"""BatchedMetaDriveEnv: the reset()/step() surface of the reference's MetaDriveEnv for E lock-stepped
+environments on one MI355X.
+
+Mirrors (same names, argument meaning, return structure and error behaviour, with a leading env
+dimension): BaseEnv.reset / step / close / observation_space / action_space
+(metadrive/envs/base_env.py:269,426-431,502-537,678-700), MetaDriveEnv.default_config
+(envs/metadrive_env.py:16-99).  Single-agent returns are unwrapped like the reference's
+(_wrap_as_single_agent, base_env.py:618-623): obs [E, 259], reward [E], terminated [E], truncated [E],
+info = dict of [E] tensors with the reference's info keys (base_vehicle.py:243-252,
+metadrive_env.py:132-152,203-211,269; base_env.py:614-616).
+
+Everything returned is a torch tensor on the engine's device (views of the engine's buffers: copy
+them if you keep them across steps).  With config auto_reset=True an env that terminated or was
+truncated at step t is restored from its reset snapshot during step t+1, which then returns the
+reset observation with reward 0 (gymnasium's NEXT_STEP autoreset convention).
+"""
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.config import make_config
+from metadrive_ped_amd.envs.spaces import Box
+
+
+class BatchedMetaDriveEnv:
+    metadata = {"render_modes": []}
+
+    @classmethod
+    def default_config(cls):
+        return make_config({})
+
+    def __init__(self, config=None):
+        self.config = make_config(config)
+        if self.config["num_agents"] != 1 or self.config["is_multi_agent"]:
+            raise NotImplementedError("BatchedMetaDriveEnv is the single-agent env; multi-agent envs are separate classes")
+        self.num_envs = self.config["num_envs"]
+        self.engine = None
+        lidar = self.config["vehicle_config"]["lidar"]
+        n = lidar["num_lasers"] if lidar["distance"] > 0 else 0
+        self._obs_dim = 19 + n
+        self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
+        self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self.start_seed = self.config["start_seed"]
+        self.episode_rewards = None
+
+    # -- lifecycle ----------------------------------------------------------------------------
+    def lazy_init(self):
+        if self.engine is None:
+            from metadrive_ped_amd.engine import BatchedEngine
+            self.engine = BatchedEngine(self.config)
+
+    def reset(self, seed=None):
+        """seed: None keeps the scenario assignment; an int re-bases it (env e gets scenario
+        seed + (env_seed_offset + e) % num_scenarios), regenerating maps/traffic on the host."""
+        if seed is not None:
+            if not (isinstance(seed, (int, np.integer)) and seed >= 0):
+                raise ValueError("seed must be a non-negative int, got {!r}".format(seed))
+            if self.engine is not None and int(seed) != self.config["start_seed"]:
+                self.config["start_seed"] = int(seed)
+                self.engine.host = None
+                self.engine.cfg = self.config
+                self.engine.build()
+            self.config["start_seed"] = int(seed)
+        self.lazy_init()
+        self.engine.reset()
+        return self._obs(), self._info()
+
+    def step(self, actions):
+        if self.engine is None:
+            raise RuntimeError("call reset() before step()")
+        torch = self.engine.torch
+        a = actions
+        if not torch.is_tensor(a):
+            a = torch.as_tensor(np.asarray(a, dtype=np.float32))
+        if a.dim() == 1:
+            a = a.unsqueeze(0).expand(self.num_envs, 2)
+        if tuple(a.shape) != (self.num_envs, 2):
+            raise ValueError("actions must have shape [{}, 2], got {}".format(self.num_envs, tuple(a.shape)))
+        self.engine.step(a)
+        fl = self.engine.flags[:, 0]
+        terminated = (fl & abi.FL_TERMINATED) != 0
+        truncated = (fl & abi.FL_TRUNCATED) != 0
+        return self._obs(), self.engine.reward[:, 0], terminated, truncated, self._info()
+
+    def close(self):
+        self.engine = None
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _obs(self):
+        return self.engine.obs[:, 0, :]
+
+    def _info(self):
+        e = self.engine
+        fl = e.flags[:, 0]
+        si = e.step_info[:, 0, :]
+        bit = lambda m: (fl & m) != 0
+        info = {
+            "velocity": si[:, 1], "steering": e.dyn_f[:, 0, 2], "acceleration": e.dyn_f[:, 0, 3],
+            "step_energy": si[:, 2], "episode_energy": si[:, 3], "step_reward": si[:, 0], "episode_reward": si[:, 4],
+            "episode_length": e.nav_i[:, 0, 8], "cost": e.cost[:, 0],
+            "crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
+            "crash_building": bit(abi.FL_CRASH_BUILDING), "crash_human": bit(abi.FL_CRASH_HUMAN),
+            "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
+            "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
+            "on_lane": bit(abi.FL_ON_LANE), "on_broken_line": bit(abi.FL_ON_BROKEN),
+            "raw_action": e.action[:, 0, :], "action": e.action[:, 0, :],
+        }
+        info["crash"] = info["crash_vehicle"] | info["crash_object"] | info["crash_building"] | \
+            info["crash_sidewalk"] | info["crash_human"]
+        info["env_seed"] = e.torch.as_tensor(np.asarray(e.host.seeds, dtype=np.int64), device=e.device)
+        return info
+
+    @property
+    def current_seeds(self):
+        return list(self.engine.host.seeds)

@@ -196,7 +196,126 @@ def section_utils():
     dump("utils.json", out)
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils)
+
+def section_agent_step():
+    """Observation(9) + navi + reward + cost + done for posed agents.
+
+    Inputs are POSES and FLAGS (not actions): everything downstream of pose is pure Python in the
+    reference.  The fake vehicle exposes exactly the attributes the reference functions read; lanes,
+    roads and the road network are the reference's own objects from a BIG-generated map.
+    Not pinned here: navi dims 0,1,5,6 go through BaseVehicle.convert_to_local_coordinates, which is a
+    Panda3D NodePath transform (placeholder in this container) -- the generator substitutes the
+    (forward, left) projection SURVEY 8a-5 derives, and the fixture marks those dims as such.
+    """
+    import types
+    from types import SimpleNamespace
+    from metadrive.component.road_network import Road
+    from metadrive.component.navigation_module.node_network_navigation import NodeNetworkNavigation
+    from metadrive.component.vehicle.base_vehicle import BaseVehicle
+    from metadrive.obs.state_obs import StateObservation
+    from metadrive.envs.metadrive_env import MetaDriveEnv, METADRIVE_DEFAULT_CONFIG
+    from metadrive.utils.math import Vector
+    from metadrive.component.map.base_map import BaseMap
+    dist_cls, d = cs_dist(0.6, 0.4)
+    rng = np.random.RandomState(2024)
+    cases = []
+
+    class PosedNavigation(NodeNetworkNavigation):
+        # `map` is a property reading the engine singleton (base_navigation.py:137-139); only the two
+        # BaseMap class constants are read from it on this path (obs/state_obs.py:91-92,146)
+        map = SimpleNamespace(MAX_LANE_NUM=BaseMap.MAX_LANE_NUM, MAX_LANE_WIDTH=BaseMap.MAX_LANE_WIDTH)
+
+    for seed in (0, 3, 5, 8, 11):
+        big, net = build_reference_map(seed, 3, 3.5, 50, "block_num", 3, dist_cls)
+        net.after_init() if hasattr(net, "after_init") and not net.is_initialized else None
+        for f, td in net.graph.items():
+            for t, lanes in td.items():
+                for i, l in enumerate(lanes):
+                    l.index = (f, t, i)
+        dest = big.blocks[-1].get_socket_list()[0].positive_road.end_node
+        ckpts = net.shortest_path((">", ">>", 0), dest)
+        final_lane = net.graph[ckpts[-2]][ckpts[-1]][-1]
+        samples = []
+        for _ in range(40):
+            k = int(rng.randint(0, len(ckpts) - 1))
+            cur_lanes = net.graph[ckpts[k]][ckpts[k + 1]]
+            last_road = (k + 1 == len(ckpts) - 1)
+            idx = [k, k] if last_road else [k, k + 1]
+            next_lanes = None if last_road else net.graph[ckpts[k + 1]][ckpts[k + 2]]
+            li = int(rng.randint(0, len(cur_lanes)))
+            on_other_road = rng.rand() < 0.15
+            if on_other_road:
+                nr = Road(ckpts[k], ckpts[k + 1])
+                neg = -nr
+                lane = net.graph[neg.start_node][neg.end_node][li]
+            else:
+                lane = cur_lanes[li]
+            s_ = float(rng.uniform(0.5, lane.length - 0.5))
+            lat = float(rng.uniform(-2.6, 2.6))
+            pos = lane.position(s_, lat)
+            heading = float(lane.heading_theta_at(s_) + rng.uniform(-0.5, 0.5))
+            speed = float(rng.uniform(0, 24))
+            last_heading = heading - float(rng.uniform(-0.08, 0.08))
+            last_pos = (float(pos[0] - math.cos(last_heading) * speed * 0.1), float(pos[1] - math.sin(last_heading) * speed * 0.1))
+            act = [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))]
+            flags = dict(crash_vehicle=bool(rng.rand() < 0.15), crash_object=bool(rng.rand() < 0.1),
+                         crash_building=bool(rng.rand() < 0.03), crash_human=bool(rng.rand() < 0.05),
+                         crash_sidewalk=bool(rng.rand() < 0.1), on_lane=bool(rng.rand() < 0.9),
+                         on_yellow_continuous_line=bool(rng.rand() < 0.1), on_white_continuous_line=bool(rng.rand() < 0.1))
+            steps, horizon = int(rng.randint(0, 60)), int(rng.choice([0, 50]))
+
+            nav = object.__new__(PosedNavigation)
+            nav.checkpoints = ckpts
+            nav._target_checkpoints_index = idx
+            nav.current_ref_lanes = cur_lanes
+            nav.next_ref_lanes = next_lanes
+            nav.current_road = Road(ckpts[k], ckpts[k + 1])
+            nav.final_lane = final_lane
+            nav._current_lane = lane
+            hx, hy = math.cos(heading), math.sin(heading)
+            veh = SimpleNamespace(
+                position=Vector((float(pos[0]), float(pos[1]))), last_position=last_pos, heading=Vector((hx, hy)),
+                heading_theta=heading, last_heading_dir=Vector((math.cos(last_heading), math.sin(last_heading))),
+                speed_km_h=speed * 3.6, max_speed_km_h=80.0, steering=act[0], MAX_STEERING=BaseVehicle.MAX_STEERING,
+                last_current_action=[(0.0, 0.0), (act[0], act[1])], lane=lane, navigation=nav, engine=None,
+                config={"side_detector": {"num_lasers": 0, "distance": 50}, "lane_line_detector": {"num_lasers": 0, "distance": 20}},
+                out_of_route=False, **flags)
+            veh.convert_to_local_coordinates = lambda vec, origin, hx=hx, hy=hy: np.array(
+                [(vec[0] - (origin[0] if hasattr(origin, "__len__") else origin)) * hx +
+                 (vec[1] - (origin[1] if hasattr(origin, "__len__") else origin)) * hy,
+                 (vec[1] - (origin[1] if hasattr(origin, "__len__") else origin)) * hx -
+                 (vec[0] - (origin[0] if hasattr(origin, "__len__") else origin)) * hy])
+            veh.heading_diff = types.MethodType(BaseVehicle.heading_diff, veh)
+            left, right = BaseVehicle._dist_to_route_left_right(veh)
+            veh.dist_to_left_side, veh.dist_to_right_side = left, right
+            veh.out_of_route = bool(right < 0 or left < 0)
+            obs_self = SimpleNamespace(config={"random_agent_model": False}, engine=None)
+            state9 = [float(x) for x in StateObservation.vehicle_state(obs_self, veh)]
+            n1, _, ck1 = NodeNetworkNavigation._get_info_for_checkpoint(nav, 0, cur_lanes[0], veh)
+            n2, _, ck2 = NodeNetworkNavigation._get_info_for_checkpoint(
+                nav, 1, next_lanes[0] if next_lanes is not None else cur_lanes[0], veh)
+            cfg = dict(METADRIVE_DEFAULT_CONFIG)
+            cfg.update(horizon=(horizon or None), truncate_as_terminate=False)
+            env = SimpleNamespace(agents={"a": veh}, config=cfg, episode_lengths={"a": steps + 1}, current_seed=seed,
+                                  logger=MagicMock())
+            env._is_out_of_road = types.MethodType(MetaDriveEnv._is_out_of_road, env)
+            env._is_arrive_destination = MetaDriveEnv._is_arrive_destination
+            reward, rinfo = MetaDriveEnv.reward_function(env, "a")
+            done, dinfo = MetaDriveEnv.done_function(env, "a")
+            cost, _ = MetaDriveEnv.cost_function(env, "a")
+            samples.append(dict(
+                road_k=k, lane=list(lane.index), idx=idx, pos=[float(pos[0]), float(pos[1])], heading=heading,
+                last_pos=list(last_pos), last_heading=last_heading, speed=speed, action=act, flags=flags, steps=steps,
+                horizon=horizon, state9=state9, navi=[float(x) for x in n1] + [float(x) for x in n2],
+                checkpoints=[[float(ck1[0]), float(ck1[1])], [float(ck2[0]), float(ck2[1])]],
+                left_right=[float(left), float(right)], out_of_route=veh.out_of_route, reward=float(reward),
+                step_reward=float(rinfo["step_reward"]), cost=float(cost), done=bool(done),
+                done_info={k_: bool(v) for k_, v in dinfo.items() if k_ != "env_seed"}))
+        cases.append(dict(seed=seed, route=ckpts, final_lane=list(final_lane.index), samples=samples))
+    dump("agent_step.json", dict(navi_dims_supplied_by_generator=[0, 1, 5, 6], cases=cases))
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -247,7 +247,7 @@ EXPORT int ref_observe(const MdWorld* w, const MdState* s, const MdConfig* c) {
     for (int e = 0; e < c->n_envs; ++e)
         for (int a = 0; a < c->agents_per_env; ++a) {
             MdState v = md_env_view(s, c, e);
-            md_observe_agent(w, &v, c, e, a, 0);
+            md_observe_agent(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a, 0);
         }
     return MD_OK;
 }
@@ -341,7 +341,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
     }
     for (int a = 0; a < c->agents_per_env; ++a) {
         MdState v = md_env_view(s, c, e);
-        md_observe_agent(w, &v, c, e, a, just_reset);
+        md_observe_agent(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a, just_reset);
         if (c->n_beams > 0)
             lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + 19);
     }
@@ -410,7 +410,9 @@ EXPORT int ref_obb_obb(const MdShape* a, const MdShape* b) {
 }
 EXPORT int ref_obb_quad(const MdShape* a, const float* q) { return md_obb_quad(a->cx, a->cy, a->c, a->s, a->hl, a->hw, q); }
 EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, float dt, int n) {
-    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], steer, thr, P, dt);
+    MdBicycle b;
+    md_bicycle_prepare(steer, thr, P, &b);
+    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], thr, &b, P, dt);
 }
 EXPORT void ref_probe_math(int op, const float* a, const float* b, float* out, int n) {
     for (int i = 0; i < n; ++i) out[i] = md_probe_eval(op, a[i], b[i]);

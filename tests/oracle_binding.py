@@ -84,8 +84,9 @@ class OracleWorld:
         self.lib = load()
         self.host = host
         self.state = state if state is not None else host.clone_state()
-        self.w, self.s, self.k = make_structs(host.world.arrays, self.state, host.md_config, host.world.n_maps, host.E,
-                                              _ptr)
+        wa = dict(host.world.arrays)
+        wa["lane_off_host"], wa["road_off_host"] = wa["lane_off"], wa["road_off"]
+        self.w, self.s, self.k = make_structs(wa, self.state, host.md_config, host.world.n_maps, host.E, _ptr)
 
     def call(self, name, *extra):
         rc = getattr(self.lib, name)(C.byref(self.w), C.byref(self.s), C.byref(self.k), *extra)

@@ -1,0 +1,113 @@
+"""Host-side logic: config contract, spaces, scene construction, static grid."""
+import numpy as np
+import pytest
+
+from helpers import make_cfg
+from metadrive_ped_amd import abi
+
+
+def test_config_contract(cs_dist):
+    from metadrive_ped_amd.config import make_config
+    cfg = make_config({})
+    assert cfg["map"] == 3 and cfg["traffic_density"] == 0.1 and cfg["decision_repeat"] == 5
+    assert cfg["vehicle_config"]["lidar"]["num_lasers"] == 240 and cfg["success_reward"] == 10.0
+    with pytest.raises(KeyError):       # utils/config.py:23-38 unknown key
+        make_config(dict(not_a_key=1))
+    with pytest.raises(KeyError):
+        make_config(dict(vehicle_config=dict(lidar=dict(nope=1))))
+    with pytest.raises(TypeError):      # type check against the default
+        make_config(dict(traffic_density="dense"))
+    with pytest.raises(NotImplementedError):
+        make_config(dict(use_render=True))
+    assert make_config(dict(map="SCS"))["map_config"]["type"] == "block_sequence"
+    assert make_config(dict(map=5))["map_config"]["config"] == 5
+
+
+def test_unbuilt_block_type_fails_loudly():
+    from metadrive_ped_amd.mapgen.pg import PGMap
+    with pytest.raises(NotImplementedError, match="not built yet"):
+        for seed in range(20):  # default V2 distribution samples ramps/intersections/roundabout
+            PGMap(seed)
+
+
+def test_spaces_and_env_surface():
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    env = BatchedMetaDriveEnv(dict(num_envs=3, map="S"))
+    assert env.observation_space.shape == (259, ) and env.observation_space.dtype == np.float32
+    assert env.action_space.shape == (2, ) and env.action_space.contains(env.action_space.sample())
+    env2 = BatchedMetaDriveEnv(dict(num_envs=1, map="S", vehicle_config=dict(lidar=dict(num_lasers=0))))
+    assert env2.observation_space.shape == (19, )   # config 1 of BASELINE: lidar off -> 19 dims
+    with pytest.raises(RuntimeError):
+        env.step(np.zeros((3, 2), np.float32))      # step before reset
+
+
+def test_scene_routes_and_traffic(cs_dist):
+    from metadrive_ped_amd.engine import HostScene
+    h = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6))
+    cap = h.cap
+    shape = h.state["shape0"].reshape(6, cap)
+    nav = h.state["nav0"].reshape(6, cap)
+    for e in range(6):
+        t = h.map_tables[h.world.arrays["env_map"][e]]
+        assert shape["flags"][e, 0] == (abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT)
+        # agent spawns 5 m into its lane with zero lateral offset (envs/base_env.py:139-140)
+        lane = t.lane_objs[nav["lane"][e, 0]]
+        s, lat = lane.local_coordinates((shape["cx"][e, 0], shape["cy"][e, 0]))
+        assert abs(s - 5.0) < 1e-4 and abs(lat) < 1e-4
+        rn = h.state["route_nodes"].reshape(6, cap, -1)[e, 0]
+        k = nav["route_len"][e, 0]
+        assert t.node_names[rn[0]] == ">" and k >= 3 and (rn[k:] == -1).all()
+        n_tr = ((shape["flags"][e] & abi.F_PENDING) != 0).sum()
+        assert n_tr == h.scenes[h.seeds[e]].n_traffic
+        for j in range(1, cap):
+            if shape["flags"][e, j] & abi.F_ALIVE:
+                # traffic sits on a 10 m slot of a positive lane of the block that triggers it
+                lane = t.lane_objs[nav["lane"][e, j]]
+                s, lat = lane.local_coordinates((shape["cx"][e, j], shape["cy"][e, j]))
+                assert abs(s / 10 - round(s / 10)) < 1e-4 and abs(lat) < 1e-4
+                assert nav["trigger_order"][e, j] >= 1 and 0 <= nav["timer"][e, j] < 50
+
+
+def test_static_grid_is_conservative(cs_dist):
+    """Every lane hull / quad AABB is listed in every cell it touches (what makes grid culling exact)."""
+    from metadrive_ped_amd.engine import HostScene
+    h = HostScene(make_cfg(cs_dist, num_envs=2, num_scenarios=2))
+    for t in h.map_tables:
+        g = t.grid[0]
+        nx, ny, x0, y0, inv = int(g["nx"]), int(g["ny"]), float(g["x0"]), float(g["y0"]), float(g["inv_cell"])
+
+        def cells_of(bx0, by0, bx1, by1):
+            gx0, gx1 = int(np.floor((bx0 - x0) * inv)), int(np.floor((bx1 - x0) * inv))
+            gy0, gy1 = int(np.floor((by0 - y0) * inv)), int(np.floor((by1 - y0) * inv))
+            return [(gx, gy) for gy in range(gy0, gy1 + 1) for gx in range(gx0, gx1 + 1)]
+
+        def listed(item, gx, gy):
+            c = gy * nx + gx
+            return item in t.cell_items[t.cell_start[c]:t.cell_start[c + 1]]
+
+        for k, r in enumerate(t.lanes):
+            for gx, gy in cells_of(r["x0"], r["y0"], r["x1"], r["y1"]):
+                assert 0 <= gx < nx and 0 <= gy < ny and listed(k, gx, gy)
+        for k in range(0, len(t.quads), 7):
+            q = t.quads[k].reshape(4, 2)
+            for gx, gy in cells_of(q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max()):
+                assert listed(~k, gx, gy)
+        # lane items of a cell are ascending (tie-break of the localisation scan)
+        for c in range(nx * ny):
+            it = t.cell_items[t.cell_start[c]:t.cell_start[c + 1]]
+            ln = it[it >= 0]
+            assert (np.diff(ln) > 0).all()
+
+
+def test_line_quads_follow_reference_geometry(cs_dist):
+    from metadrive_ped_amd.engine import HostScene
+    h = HostScene(make_cfg(cs_dist, num_envs=1, num_scenarios=1, start_seed=1))
+    t = h.map_tables[0]
+    kinds = set(t.quad_kind.tolist())
+    assert {abi.Q_LINE_WHITE_CONT, abi.Q_LINE_YELLOW_CONT, abi.Q_LINE_BROKEN, abi.Q_SIDEWALK} <= kinds
+    q = t.quads[t.quad_kind == abi.Q_LINE_BROKEN].reshape(-1, 4, 2)
+    w = np.linalg.norm(q[:, 1] - q[:, 2], axis=1)
+    ln = np.linalg.norm(q[:, 0] - q[:, 1], axis=1)
+    np.testing.assert_allclose(np.minimum(w, ln), 0.075, atol=1e-5)   # 2 * LANE_LINE_WIDTH/4
+    # STRIPE_LENGTH stripes; the LAST stripe of a line runs to length - 1.5 (pg_block.py:268-269) so it is longer
+    assert np.median(np.maximum(w, ln)) == pytest.approx(1.5, abs=1e-4) and np.all(np.maximum(w, ln) < 4.5 + 1e-4)

@@ -1,0 +1,221 @@
+"""Behavioural invariants of the step path restated from the reference's integration tests
+(metadrive/tests/test_functionality, test_env), run on the CPU oracle; plus analytic checks of the
+geometry primitives (reference tests/test_component/test_detector_mask.py:125-147)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from helpers import make_cfg, scripted_actions
+from metadrive_ped_amd import abi
+import oracle_binding as ob
+
+
+def _world(cs_dist, **kw):
+    from metadrive_ped_amd.engine import HostScene
+    host = HostScene(make_cfg(cs_dist, **kw))
+    o = ob.OracleWorld(host)
+    o.reset()
+    return host, o
+
+
+def test_obs_in_space_and_info_contract(cs_dist):
+    """obs in Box(0,1,(259,)), scalar reward per env (test_env/test_metadrive_env.py:12-71)."""
+    host, o = _world(cs_dist, num_envs=8, num_scenarios=8)
+    for t in range(30):
+        o.step(scripted_actions(8, 1, t))
+        obs = o.obs
+        assert obs.shape == (8, 259) and obs.dtype == np.float32
+        assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+        assert np.isfinite(o.state["reward"]).all()
+
+
+def test_spawn_heading_diff_is_half(cs_dist):
+    """heading_diff(lane) == 0.5 for a freshly spawned vehicle (test_component/test_ego_vehicle.py:21)."""
+    host, o = _world(cs_dist, num_envs=4, num_scenarios=4)
+    np.testing.assert_allclose(o.obs[:, 2], 0.5, atol=1e-3)
+
+
+def test_full_throttle_drives_forward_and_engine_cuts_at_max_speed(cs_dist):
+    host, o = _world(cs_dist, num_envs=2, num_scenarios=2, map="S", traffic_density=0.0, auto_reset=False)
+    x0 = o.state["shape"]["cx"].reshape(2, -1)[:, 0].copy()
+    for t in range(120):
+        o.step(np.tile(np.array([0.0, 1.0], np.float32), (2, 1, 1)))
+    x = o.state["shape"]["cx"].reshape(2, -1)[:, 0]
+    v = o.state["dyn"]["speed"].reshape(2, -1)[:, 0]
+    assert (x > x0 + 50).all()
+    assert (v * 3.6 <= 80.0 + 1.5).all() and (v * 3.6 > 75).all()      # engine force is 0 above max_speed_km_h
+
+
+def test_brake_stops_without_reversing(cs_dist):
+    host, o = _world(cs_dist, num_envs=1, num_scenarios=1, map="S", traffic_density=0.0, auto_reset=False)
+    for t in range(40):
+        o.step(np.array([[[0.0, 1.0]]], np.float32))
+    for t in range(60):
+        o.step(np.array([[[0.0, -1.0]]], np.float32))
+    assert o.state["dyn"]["speed"][0] == 0.0                                 # enable_reverse=False
+
+
+def test_steering_off_road_terminates_with_penalty(cs_dist):
+    """out_of_road ends the episode with -out_of_road_penalty (test_reward_cost_done.py:54-74)."""
+    host, o = _world(cs_dist, num_envs=1, num_scenarios=1, map="S", traffic_density=0.0, auto_reset=False)
+    done_at = None
+    for t in range(200):
+        o.step(np.array([[[1.0, 0.6]]], np.float32))
+        fl = int(o.state["flags"][0])
+        if fl & abi.FL_TERMINATED:
+            done_at = t
+            break
+    assert done_at is not None
+    assert fl & abi.FL_OUT_OF_ROAD
+    assert o.state["reward"][0] == -5.0 and o.state["cost"][0] == 1.0
+
+
+def test_arrive_destination_gives_success_reward(cs_dist):
+    host, o = _world(cs_dist, num_envs=1, num_scenarios=1, map="S", traffic_density=0.0, auto_reset=False,
+                     random_spawn_lane_index=False)
+    got = False
+    for t in range(400):
+        o.step(np.array([[[0.0, 0.5]]], np.float32))
+        fl = int(o.state["flags"][0])
+        if fl & abi.FL_ARRIVE_DEST:
+            assert o.state["reward"][0] == 10.0 and (fl & abi.FL_TERMINATED)
+            got = True
+            break
+        assert not (fl & abi.FL_TERMINATED), abi.__dict__
+    assert got
+
+
+@pytest.mark.parametrize("truncate_as_terminate", [False, True])
+def test_horizon_semantics(cs_dist, truncate_as_terminate):
+    """horizon -> truncated at step == horizon; terminated only with truncate_as_terminate
+    (test_functionality/test_horizon_termination.py:14-63)."""
+    host, o = _world(cs_dist, num_envs=1, num_scenarios=1, map="S", traffic_density=0.0, auto_reset=False, horizon=7,
+                     truncate_as_terminate=truncate_as_terminate)
+    for t in range(1, 8):
+        o.step(np.array([[[0.0, 0.1]]], np.float32))
+        fl = int(o.state["flags"][0])
+        assert bool(fl & abi.FL_TRUNCATED) == (t >= 7)
+        assert bool(fl & abi.FL_TERMINATED) == (t >= 7 and truncate_as_terminate)
+
+
+def test_auto_reset_restores_snapshot(cs_dist):
+    host, o = _world(cs_dist, num_envs=1, num_scenarios=1, map="S", traffic_density=0.0, auto_reset=True, horizon=5)
+    first_obs = o.obs.copy()
+    for t in range(5):
+        o.step(np.array([[[0.0, 1.0]]], np.float32))
+    assert o.state["need_reset"][0] == 1
+    o.step(np.array([[[0.0, 1.0]]], np.float32))     # the step after `done` returns the reset observation
+    np.testing.assert_array_equal(o.obs, first_obs)
+    assert o.state["reward"][0] == 0.0 and int(o.state["flags"][0]) & abi.FL_TERMINATED == 0
+    assert o.state["nav"]["steps"][0] == 0
+
+
+def test_trigger_traffic_wakes_up_and_moves(cs_dist):
+    """Trigger-mode traffic is parked until the agent enters the block's trigger road, then drives
+    (test_functionality/test_traffic_mode.py:4-32, test_policy/test_idm_policy.py:57-76)."""
+    host, o = _world(cs_dist, num_envs=6, num_scenarios=6, traffic_density=0.3, auto_reset=False, crash_vehicle_done=False,
+                     mover_capacity=96)
+    f0 = o.state["shape"]["flags"].copy()
+    x0 = o.state["shape"]["cx"].copy()
+    assert ((f0 & abi.F_PENDING) != 0).sum() > 10
+    woke = np.zeros_like(f0, dtype=bool)
+    for t in range(150):
+        o.step(np.tile(np.array([0.0, 0.7], np.float32), (6, 1, 1)))
+        woke |= ((f0 & abi.F_PENDING) != 0) & ((o.state["shape"]["flags"] & abi.F_PENDING) == 0)
+    assert woke.sum() > 5
+    moved = np.abs(o.state["shape"]["cx"] - x0) + 0  # x is enough: blocks extend along +x first
+    still_pending = (o.state["shape"]["flags"] & abi.F_PENDING) != 0
+    assert (moved[still_pending] == 0).all()                                   # parked traffic never moves
+    assert (np.hypot(o.state["shape"]["cx"] - x0, o.state["shape"]["cy"] - o.state["shape"]["cy"])[woke] > 0.5).mean() > 0.5
+
+
+def test_dense_traffic_eventually_crashes(cs_dist):
+    """crash with a vehicle happens within 500 steps at high density (test_collision.py:4-19)."""
+    host, o = _world(cs_dist, num_envs=4, num_scenarios=4, map="SSS", traffic_density=1.0, auto_reset=False,
+                     mover_capacity=128)
+    crashed = np.zeros(4, bool)
+    for t in range(500):
+        o.step(np.tile(np.array([0.0, 1.0], np.float32), (4, 1, 1)))
+        crashed |= (o.state["flags"].reshape(4, -1)[:, 0] & abi.FL_CRASH_VEHICLE) != 0
+        if crashed.all():
+            break
+    assert crashed.any()
+
+
+def test_determinism_same_seed_same_rollout(cs_dist):
+    """Same config + seed => identical trajectories (test_scenario_randomness.py:10-67: 1e-5; here bitwise)."""
+    outs = []
+    for _ in range(2):
+        host, o = _world(cs_dist, num_envs=4, num_scenarios=4, start_seed=7)
+        for t in range(80):
+            o.step(scripted_actions(4, 1, t))
+        outs.append({k: v.copy() for k, v in o.state.items()})
+    for k in outs[0]:
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+# ---- analytic geometry ---------------------------------------------------------------------------
+def _line_intersect(theta, pos, a, b, maximum=10000.0):
+    """Ray from `pos` at angle theta against segment a-b: distance or `maximum` (analytic form of the
+    reference's test helper, tests/test_component/test_detector_mask.py:125-147, restated)."""
+    x0, y0 = pos
+    dx, dy = math.cos(theta), math.sin(theta)
+    ex, ey = b[0] - a[0], b[1] - a[1]
+    den = dx * ey - dy * ex
+    if abs(den) < 1e-12:
+        return maximum
+    t = ((a[0] - x0) * ey - (a[1] - y0) * ex) / den
+    u = ((a[0] - x0) * dy - (a[1] - y0) * dx) / den
+    if t >= 0 and 0 <= u <= 1:
+        return t
+    return maximum
+
+
+def test_ray_box_matches_analytic_segments():
+    lib = ob.load()
+    rng = np.random.RandomState(5)
+    n_hit = 0
+    for _ in range(3000):
+        sh = np.zeros(1, dtype=abi.SHAPE_DT)
+        cx, cy = rng.uniform(-25, 25, 2)
+        th = rng.uniform(-math.pi, math.pi)
+        hl, hw = rng.uniform(1.5, 3), rng.uniform(0.7, 1.2)
+        sh["cx"], sh["cy"], sh["c"], sh["s"], sh["hl"], sh["hw"] = cx, cy, math.cos(th), math.sin(th), hl, hw
+        sh["flags"] = abi.KIND_VEHICLE | abi.F_ALIVE
+        beam = rng.uniform(-math.pi, math.pi)
+        got = lib.ref_ray_shape(C.c_float(0), C.c_float(0), C.c_float(50 * math.cos(beam)), C.c_float(50 * math.sin(beam)),
+                                sh.ctypes.data)
+        u = np.array([math.cos(th), math.sin(th)])
+        v = np.array([-u[1], u[0]])
+        c = np.array([cx, cy])
+        corners = [c + hl * u + hw * v, c - hl * u + hw * v, c - hl * u - hw * v, c + hl * u - hw * v]
+        inside = abs(np.dot(-c, u)) <= hl and abs(np.dot(-c, v)) <= hw
+        d = min(_line_intersect(beam, (0, 0), corners[i], corners[(i + 1) % 4]) for i in range(4))
+        want = d / 50.0 if (d <= 50.0 and not inside) else 2.0
+        if want <= 1.0:
+            n_hit += 1
+            assert abs(got - want) < 2e-5, (got, want)
+        else:
+            assert got >= 1.0 or abs(d - 50.0) < 1e-3, (got, want, d)
+    assert n_hit > 100, n_hit
+
+
+def test_obb_overlap_symmetry_and_containment():
+    lib = ob.load()
+    rng = np.random.RandomState(9)
+    for _ in range(2000):
+        a, b = np.zeros(1, dtype=abi.SHAPE_DT), np.zeros(1, dtype=abi.SHAPE_DT)
+        for s in (a, b):
+            th = rng.uniform(-math.pi, math.pi)
+            s["cx"], s["cy"] = rng.uniform(-6, 6, 2)
+            s["c"], s["s"], s["hl"], s["hw"] = math.cos(th), math.sin(th), rng.uniform(1.5, 3), rng.uniform(0.7, 1.2)
+        ab = lib.ref_obb_obb(a.ctypes.data, b.ctypes.data)
+        ba = lib.ref_obb_obb(b.ctypes.data, a.ctypes.data)
+        assert ab == ba
+        dist = math.hypot(float(a["cx"][0] - b["cx"][0]), float(a["cy"][0] - b["cy"][0]))
+        if dist < min(float(a["hw"][0]), float(b["hw"][0])):
+            assert ab == 1
+        if dist > math.hypot(float(a["hl"][0]), float(a["hw"][0])) + math.hypot(float(b["hl"][0]), float(b["hw"][0])):
+            assert ab == 0

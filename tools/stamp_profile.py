@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""In-kernel phase stamps of the fused step kernel (diagnostic build, -DMD_STAMP).  Builds a separate
+library, runs the bench workload, prints per-phase cycle shares (mean / p50 / max over envs).  Read
+SHARES from it, never the run time of this build."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PHASES = ["stage-in", "trigger", "idm", "integrate", "localize", "contacts", "traffic", "observe", "lidar",
+          "barrier", "write-back"]
+
+
+def main():
+    import numpy as np
+    out = os.path.join(ROOT, "gpurun_out", "libmdstep_stamp.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+                           "-fvisibility=hidden", "-std=c++17", "-DMD_STAMP"] + os.environ.get("MD_EXTRA_FLAGS", "").split() + [ "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "metadrive_ped_amd", "csrc", "mdstep.hip"), "-o", out])
+    from metadrive_ped_amd import _lib
+    _lib.LIB_PATH = out
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
+    from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2
+    d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
+    d["Curve"], d["Straight"] = 0.6, 0.4
+    E = int(os.environ.get("ENVS", "4096"))
+    cfg = make_config(dict(num_envs=E, num_scenarios=min(E, 512), block_dist_config=d, mover_capacity=32, horizon=1000))
+    eng = BatchedEngine(cfg, host=HostScene(cfg))
+    eng.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = torch.rand(16, E, 1, 2, generator=g) * 2 - 1
+    acts[..., 1] = acts[..., 1].abs() * 0.9 + 0.1
+    acts[..., 0] *= 0.25
+    acts = acts.cuda()
+    for i in range(80):
+        eng.step(acts[i % 16])
+    buf = torch.zeros(E * 16, dtype=torch.int64, device="cuda")
+    eng.lib.md_debug_set_stamp_buffer.argtypes = [C.c_void_p]
+    assert eng.lib.md_debug_set_stamp_buffer(buf.data_ptr()) == 0
+    eng.step(acts[0])
+    torch.cuda.synchronize()
+    st = buf.cpu().numpy().reshape(E, 16)[:, :12].astype(np.int64)
+    d = np.diff(st, axis=1)
+    tot = st[:, 11] - st[:, 0]
+    print("per-env cycles: mean %.0f  p50 %.0f  p99 %.0f  max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
+    print("kernel span (first start -> last end): %.0f cycles" % (st[:, 11].max() - st[:, 0].min()))
+    for i, name in enumerate(PHASES):
+        x = d[:, i]
+        print("%-11s mean %8.0f  p50 %8.0f  p99 %8.0f  max %8.0f   share %5.1f%%" %
+              (name, x.mean(), np.median(x), np.percentile(x, 99), x.max(), 100.0 * x.sum() / tot.sum()))
+    flags = eng.shape_f.view(torch.int32)[..., 6]
+    drv = (((flags & 0x10) != 0) & ((flags & 0x40) == 0) & ((flags & 0xF) == 1)).sum(dim=1).cpu().numpy()
+    print("driving vehicles/env: mean %.2f max %d" % (drv.mean(), drv.max()))
+    idx = np.argsort(tot)[-3:]
+    for i in idx:
+        print("slow env", i, "drv", drv[i], "phases", d[i].tolist())
+
+
+if __name__ == "__main__":
+    main()
