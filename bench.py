@@ -39,10 +39,10 @@ def parse():
     p.add_argument("--steps", type=int, default=300)
     p.add_argument("--warmup", type=int, default=30)
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    p.add_argument("--cap", type=int, default=32, help="mover slots per env")
+    p.add_argument("--cap", type=int, default=0, help="mover slots per env (0 = smallest that fits)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-envs", type=int, default=1024)
-    p.add_argument("--cpu-steps", type=int, default=60)
+    p.add_argument("--cpu-envs", type=int, default=2048)
+    p.add_argument("--cpu-steps", type=int, default=100)
     return p.parse_args()
 
 
@@ -188,7 +188,8 @@ def main():
         ccfg["num_envs"] = n_cpu
         host = HostScene(ccfg)
         orc = ob.OracleWorld(host)
-        cores = os.cpu_count() or 1
+        # the GPU box gives one GPU's job a 16-CPU share, whatever os.cpu_count() says
+        cores = min(len(os.sched_getaffinity(0)), 16)
         orc.reset()
         acts = actions[:, :n_cpu].cpu().numpy()
         t0 = time.perf_counter()

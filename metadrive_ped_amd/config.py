@@ -91,7 +91,7 @@ METADRIVE_DEFAULT_CONFIG = dict(
 BATCH_DEFAULT_CONFIG = dict(
     num_envs=1,             # E: environments stepped in lockstep by this process (this GPU's shard)
     env_seed_offset=0,      # global index of this shard's first env (seed = start_seed + (offset + e) % num_scenarios)
-    mover_capacity=64,      # slots per env: agents + traffic + props
+    mover_capacity=0,       # slots per env (agents + traffic + props); 0 = smallest multiple of 8 that fits every env
     auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
     device="cuda:0",
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
@@ -141,6 +141,6 @@ def make_config(user=None):
         cfg["block_dist_config"] = BlockDist()
     elif isinstance(cfg["block_dist_config"], dict):
         cfg["block_dist_config"] = BlockDist(cfg["block_dist_config"])
-    if cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]:
-        raise ValueError("mover_capacity must be in [num_agents, 128]")
+    if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
+        raise ValueError("mover_capacity must be 0 (auto) or in [num_agents, 128]")
     return cfg

@@ -36,7 +36,7 @@ class HostScene:
     def __init__(self, cfg):
         self.cfg = cfg
         E = cfg["num_envs"]
-        cap = cfg["mover_capacity"]
+        cap = cfg["mover_capacity"] or abi.MD_MAX_CAP  # 0 = auto: build with the maximum, trim below
         A = cfg["num_agents"]
         self.E, self.cap, self.A = E, cap, A
         self.n_beams = int(cfg["vehicle_config"]["lidar"]["num_lasers"]) if cfg["vehicle_config"]["lidar"]["distance"] > 0 else 0
@@ -68,6 +68,12 @@ class HostScene:
             map_of_seed[s] = len(tables)
             tables.append(mt)
             scenes[s] = sc
+        if not cfg["mover_capacity"]:
+            need = max(A + sc.n_traffic for sc in scenes.values())
+            cap = min(abi.MD_MAX_CAP, max(8, (need + 7) // 8 * 8))
+            for sc in scenes.values():
+                sc.trim(cap)
+            self.cap = cap
         self.map_tables = tables
         self.scenes = scenes
         env_map = [map_of_seed[s] for s in seeds]

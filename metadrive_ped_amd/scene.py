@@ -130,6 +130,13 @@ class EnvScene:
                     slot += 1
         self.n_traffic = slot - A
 
+    def trim(self, cap):
+        """Shrink the slot arrays to `cap` (>= used slots)."""
+        assert cap >= self.n_traffic + 1
+        for k in ("shape", "dyn", "param", "nav", "pid", "route_nodes", "route_roads", "final_lane", "idm_rand"):
+            setattr(self, k, getattr(self, k)[:cap].copy())
+        self.vehicle_cfgs = self.vehicle_cfgs[:cap]
+
     def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags):
         t = self.tables
         pg_map = t.pg_map

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--cap", type=int, default=32)
+    ap.add_argument("--cap", type=int, default=0)
     ap.add_argument("--warm", type=int, default=80)
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
