@@ -93,36 +93,90 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
 }
 
 
-MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c, int a,
-                             int just_reset) {
+/* The observation needs nine mutually independent geometric evaluations (Frenet transforms against
+ * five different lanes, two checkpoint projections, heading difference, yaw rate / energy).  They
+ * are split out as "tasks" so that the HIP kernel can run them on nine lanes of a wave at once and
+ * combine on one lane, while the oracle simply loops over them: same code, same bits. */
+#define MD_OBS_TASKS 9
+
+typedef struct MdObsCtx {
+    const MdLane *lane, *ref0, *ref_last, *next0, *fin, *rl;
+    float cur_w, cur_n, positive_road;
+    int valid;
+} MdObsCtx;
+
+MD_HD void md_observe_ctx(const MdLane* lanes, const MdRoad* roads, const MdState* s, int n, MdObsCtx* k) {
+    const MdShape* sh = &s->shape[n];
+    const MdNav* nav = &s->nav[n];
+    k->valid = md_drives(sh->flags) && nav->lane >= 0;
+    k->lane = k->ref0 = k->ref_last = k->next0 = k->fin = k->rl = lanes;
+    k->cur_w = k->cur_n = k->positive_road = 0.0f;
+    if (!k->valid) return;
+    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
+    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    int has_next = nav->ck1 != nav->ck0;
+    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : cur_road;
+    k->lane = &lanes[nav->lane];
+    k->ref0 = &lanes[cur_road->first_lane];
+    k->ref_last = &lanes[cur_road->first_lane + cur_road->n_lanes - 1];
+    k->next0 = &lanes[next_road->first_lane];
+    k->fin = &lanes[s->final_lane[n]];
+    k->cur_w = k->lane->width; /* get_current_lane_width = current_lane.width */
+    k->cur_n = (float)cur_road->n_lanes;
+    /* reward lane (metadrive_env.py:248-254) */
+    k->positive_road = 1.0f;
+    if (k->lane->road == rroads[nav->ck0]) k->rl = k->lane;
+    else {
+        k->rl = k->ref0;
+        k->positive_road = cur_road->negative ? -1.0f : 1.0f;
+    }
+}
+
+MD_HD void md_observe_task(int task, const MdObsCtx* k, const MdState* s, const MdConfig* c, int n, float* out5) {
+    const MdShape* sh = &s->shape[n];
+    const MdDyn* d = &s->dyn[n];
+    float x = sh->cx, y = sh->cy;
+    out5[0] = out5[1] = out5[2] = out5[3] = out5[4] = 0.0f;
+    if (!k->valid) return;
+    /* Grouped so that lanes of a wave running different tasks share code paths: five tasks are the
+     * same Frenet transform on different (lane, point) pairs, two are the same checkpoint projection. */
+    if (task == 0 || task == 2 || task == 5 || task == 6 || task == 7) {
+        const MdLane* L = (task == 0) ? k->ref0 : ((task == 2) ? k->lane : ((task == 5) ? k->fin : k->rl));
+        float px = (task == 6) ? d->last_x : x;
+        float py = (task == 6) ? d->last_y : y;
+        md_lane_local(L, px, py, &out5[0], &out5[1]);
+    } else if (task == 3 || task == 4) {
+        md_navi_for_checkpoint((task == 3) ? k->ref0 : k->next0, (k->cur_n / 2.0f - 0.5f) * k->cur_w, x, y, sh->c, sh->s,
+                               k->cur_n, k->cur_w, c->curve_radius_max, c->curve_angle_max, out5);
+    } else if (task == 1) {
+        out5[0] = md_heading_diff(k->ref_last, x, y, sh->c, sh->s); /* obs[2] */
+    } else if (task == 8) {
+        float cosb = (sh->c * d->last_c + sh->s * d->last_s) / (md_norm(sh->c, sh->s) * md_norm(d->last_c, d->last_s));
+        float beta = md_acos(md_clip(cosb, 0.0f, 1.0f));
+        out5[0] = md_clip(beta / 0.1f, 0.0f, 1.0f); /* obs[7] yaw rate */
+        out5[1] = md_step_energy(md_fabs(d->speed) * 3.6f, md_norm(d->last_x - x, d->last_y - y));
+    }
+}
+
+MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfig* c, int a, int just_reset,
+                              const float (*r)[5]) {
     int n = a;
     int ai = a; /* env-local view: agent a of this env */
     float* obs = s->obs + (size_t)ai * c->obs_dim;
     float* info = s->step_info + (size_t)ai * 8;
-    MdShape* sh = &s->shape[n];
     MdDyn* d = &s->dyn[n];
     MdNav* nav = &s->nav[n];
-    if (!md_drives(sh->flags) || nav->lane < 0) {
+    if (!k->valid) {
         for (int i = 0; i < 19; ++i) obs[i] = 0.0f;
         s->reward[ai] = 0.0f;
         s->cost[ai] = 0.0f;
         for (int i = 0; i < 8; ++i) info[i] = 0.0f;
         return;
     }
-    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
-    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
-    int has_next = nav->ck1 != nav->ck0;
-    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : cur_road;
-    const MdLane* lane = &lanes[nav->lane];
-    const MdLane* ref0 = &lanes[cur_road->first_lane];
-    const MdLane* ref_last = &lanes[cur_road->first_lane + cur_road->n_lanes - 1];
-    float cur_w = lane->width; /* get_current_lane_width = current_lane.width */
-    float cur_n = (float)cur_road->n_lanes;
-    float x = sh->cx, y = sh->cy;
+    float cur_w = k->cur_w, cur_n = k->cur_n;
 
     /* dist to left/right of the route (base_vehicle.py:491-499) */
-    float s0, lat0;
-    md_lane_local(ref0, x, y, &s0, &lat0);
+    float lat0 = r[0][1];
     float to_left = lat0 + cur_w / 2.0f;
     float to_right = cur_w * cur_n - to_left;
     uint32_t fl = s->flags[n] & (MD_FL_CRASH_VEHICLE | MD_FL_CRASH_OBJECT | MD_FL_CRASH_HUMAN | MD_FL_CRASH_BUILDING |
@@ -135,32 +189,23 @@ MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdSt
     const MdParam* P = &s->param[n];
     obs[0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
     obs[1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
-    obs[2] = md_heading_diff(ref_last, x, y, sh->c, sh->s);
+    obs[2] = r[1][0];
     obs[3] = md_clip((speed_kmh + 1.0f) / (P->max_speed_kmh + 1.0f), 0.0f, 1.0f);
     obs[4] = md_clip((d->steering / 60.0f + 1.0f) / 2.0f, 0.0f, 1.0f); /* MAX_STEERING = 60 (base_vehicle.py:80) */
     obs[5] = md_clip((s->action[2 * n] + 1.0f) / 2.0f, 0.0f, 1.0f);
     obs[6] = md_clip((s->action[2 * n + 1] + 1.0f) / 2.0f, 0.0f, 1.0f);
-    {
-        float cosb = (sh->c * d->last_c + sh->s * d->last_s) / (md_norm(sh->c, sh->s) * md_norm(d->last_c, d->last_s));
-        float beta = md_acos(md_clip(cosb, 0.0f, 1.0f));
-        obs[7] = md_clip(beta / 0.1f, 0.0f, 1.0f);
-    }
-    float ls, llat;
-    md_lane_local(lane, x, y, &ls, &llat);
+    obs[7] = r[8][0];
+    float ls = r[2][0], llat = r[2][1];
     obs[8] = md_clip((llat * 2.0f / c->max_lane_width + 1.0f) / 2.0f, 0.0f, 1.0f);
-
     /* ---- navi (node_network_navigation.py:160-168, 243-292) ---- */
-    float later_middle = (cur_n / 2.0f - 0.5f) * cur_w;
-    md_navi_for_checkpoint(ref0, later_middle, x, y, sh->c, sh->s, cur_n, cur_w, c->curve_radius_max, c->curve_angle_max,
-                           obs + 9);
-    md_navi_for_checkpoint(&lanes[next_road->first_lane], later_middle, x, y, sh->c, sh->s, cur_n, cur_w,
-                           c->curve_radius_max, c->curve_angle_max, obs + 14);
+    for (int i = 0; i < 5; ++i) {
+        obs[9 + i] = r[3][i];
+        obs[14 + i] = r[4][i];
+    }
 
     /* ---- arrive destination (metadrive_env.py:213-227) ---- */
-    const MdLane* fin = &lanes[s->final_lane[n]];
-    float fs, flat;
-    md_lane_local(fin, x, y, &fs, &flat);
-    int arrive = (fin->length - 5.0f < fs) && (fs < fin->length + 5.0f) && (cur_w / 2.0f >= flat) &&
+    float fs = r[5][0], flat = r[5][1];
+    int arrive = (k->fin->length - 5.0f < fs) && (fs < k->fin->length + 5.0f) && (cur_w / 2.0f >= flat) &&
                  (flat >= (0.5f - cur_n) * cur_w);
     /* ---- out of road (metadrive_env.py:229-237) ---- */
     int out_of_road = !(fl & MD_FL_ON_LANE);
@@ -171,16 +216,8 @@ MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdSt
     if (out_of_road) fl |= MD_FL_OUT_OF_ROAD;
 
     /* ---- reward (metadrive_env.py:239-279) ---- */
-    const MdLane* rl;
-    float positive_road = 1.0f;
-    if (lane->road == rroads[nav->ck0]) rl = lane;
-    else {
-        rl = ref0;
-        positive_road = cur_road->negative ? -1.0f : 1.0f;
-    }
-    float long_last, tmp, long_now, lateral_now;
-    md_lane_local(rl, d->last_x, d->last_y, &long_last, &tmp);
-    md_lane_local(rl, x, y, &long_now, &lateral_now);
+    float positive_road = k->positive_road;
+    float long_last = r[6][0], long_now = r[7][0], lateral_now = r[7][1];
     float lateral_factor = 1.0f;
     if (c->use_lateral_reward) lateral_factor = md_clip(1.0f - 2.0f * md_fabs(lateral_now) / cur_w, 0.0f, 1.0f);
     float reward = 0.0f;
@@ -228,8 +265,7 @@ MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdSt
     s->cost[ai] = cost;
 
     /* ---- info (base_vehicle.py:243-271) ---- */
-    float step_energy = md_step_energy(speed_kmh, md_norm(d->last_x - x, d->last_y - y));
-    if (just_reset) step_energy = 0.0f;
+    float step_energy = just_reset ? 0.0f : r[8][1];
     s->pid[n].energy += step_energy;
     info[0] = step_reward;
     info[1] = md_fabs(d->speed);
@@ -242,6 +278,15 @@ MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdSt
     if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[0] = 1;
 }
 
+/* serial form (oracle): all tasks, then combine */
+MD_HD void md_observe_agent(const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c, int a,
+                             int just_reset) {
+    MdObsCtx k;
+    float r[MD_OBS_TASKS][5];
+    md_observe_ctx(lanes, roads, s, a, &k);
+    for (int t = 0; t < MD_OBS_TASKS; ++t) md_observe_task(t, &k, s, c, a, r[t]);
+    md_observe_combine(&k, s, c, a, just_reset, (const float (*)[5])r);
+}
 
 /* ------------------------------------------------------------------------------------------
  * IDM traffic policy: IDMPolicy.act (policy/idm_policy.py:235-402) with FrontBackObjects
@@ -326,9 +371,8 @@ MD_HD int md_fb_neighbour(const MdLane* L, const MdLane* OL, float cur_long, flo
 
 /* Stage A */
 MD_HD void md_idm_plan(const MdWorld* w, const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c,
-                        int e, int slot, MdIdmPlan* p) {
+                        int m, int slot, MdIdmPlan* p) {
     MdNav* nav = &s->nav[slot];
-    int m = w->env_map[e];
     const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
     const MdRoad* cur_road = &roads[rroads[nav->ck0]];
     int success;
@@ -568,7 +612,7 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
     FrontBack fb;
     const MdLane* lanes = w->lanes + w->lane_off[w->env_map[e]];
     const MdRoad* roads = w->roads + w->road_off[w->env_map[e]];
-    md_idm_plan(w, lanes, roads, s, c, e, slot, &plan);
+    md_idm_plan(w, lanes, roads, s, c, w->env_map[e], slot, &plan);
     for (int i = 0; i < 3; ++i) {
         fb.front[i] = fb.back[i] = -1;
         fb.exist[i] = 0;

@@ -190,6 +190,11 @@ MD_HD int md_point_in_hull(float x, float y, const float* xy, int n) {
     return n >= 3;
 }
 
+/* hull vertices of a lane: inline copy for 4-vertex hulls, else the CSR table */
+MD_HD const float* md_lane_hull(const MdLane* L, const float* hull_xy) {
+    return (L->hull_n == 4) ? L->hull4 : hull_xy + 2 * (size_t)L->hull_off;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Lane Frenet math: StraightLane.local_coordinates (lane/straight_lane.py:69-74),
  * CircularLane.local_coordinates (lane/circular_lane.py:71-121), heading_theta_at

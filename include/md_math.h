@@ -163,8 +163,12 @@ MD_HD float md_acos(float x) {
 
 /* metadrive/utils/math.py:29-41: wrap to (-pi, pi] via python-style modulo */
 MD_HD float md_wrap_to_pi(float x) {
-    float a = x - MD_TWO_PI_F * md_floor(x / MD_TWO_PI_F);
-    if (a < 0.0f) a = 0.0f; /* guard rounding */
+    /* multiply by 1/(2 pi) instead of an IEEE division (10+ dependent instructions on the GPU); an
+     * off-by-one of the floor at an exact multiple only moves the result by one ulp-sized step
+     * across the +-pi seam, which the two guards below absorb */
+    float a = x - MD_TWO_PI_F * md_floor(x * 0.15915494309189535f);
+    if (a < 0.0f) a += MD_TWO_PI_F; /* guard rounding */
+    if (a >= MD_TWO_PI_F) a -= MD_TWO_PI_F;
     if (a > MD_PI_F) a -= MD_TWO_PI_F;
     return a;
 }

@@ -139,7 +139,7 @@ typedef struct MdPid {
     float energy;        /* episode energy consumption                                          */
 } MdPid;
 
-/* 128-byte lane record (component/lane/straight_lane.py, circular_lane.py). */
+/* 160-byte lane record (component/lane/straight_lane.py, circular_lane.py). */
 typedef struct MdLane {
     int32_t type;        /* 0 straight, 1 circular                                              */
     int32_t road;        /* map-local road id                                                   */
@@ -160,6 +160,8 @@ typedef struct MdLane {
     float spare0;
     float elx, ely;      /* unit lateral (right-hand) vector at the lane end: position(L, lat) = e + lat*el */
     float spare[4];
+    float hull4[8];      /* hull_n == 4 (straight lanes): the four hull vertices inline, so that the
+                            containment test needs no second table lookup                         */
 } MdLane;
 
 /* 32-byte road record (component/road_network/road.py). */

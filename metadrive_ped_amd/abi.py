@@ -57,14 +57,14 @@ LANE_DT = np.dtype([("type", i4), ("road", i4), ("idx", i4), ("n_in_road", i4), 
                     ("by", f4), ("length", f4), ("width", f4), ("end_phase", f4), ("dirsign", f4), ("angle", f4),
                     ("heading", f4), ("sx", f4), ("sy", f4), ("ex", f4), ("ey", f4), ("x0", f4), ("y0", f4),
                     ("x1", f4), ("y1", f4), ("hull_off", i4), ("hull_n", i4), ("end_phase_w", f4), ("spare0", f4),
-                    ("elx", f4), ("ely", f4), ("spare", f4, (4, ))])
+                    ("elx", f4), ("ely", f4), ("spare", f4, (4, )), ("hull4", f4, (8, ))])
 ROAD_DT = np.dtype([("first_lane", i4), ("n_lanes", i4), ("start_node", i4), ("end_node", i4), ("negative", i4),
                     ("block", i4), ("spare", i4, (2, ))])
 GRID_DT = np.dtype([("x0", f4), ("y0", f4), ("inv_cell", f4), ("nx", i4), ("ny", i4), ("cell_base", i4),
                     ("spare", i4, (2, ))])
 
 assert SHAPE_DT.itemsize == 32 and DYN_DT.itemsize == 32 and PARAM_DT.itemsize == 32
-assert NAV_DT.itemsize == 64 and PID_DT.itemsize == 32 and LANE_DT.itemsize == 128
+assert NAV_DT.itemsize == 64 and PID_DT.itemsize == 32 and LANE_DT.itemsize == 160
 assert ROAD_DT.itemsize == 32 and GRID_DT.itemsize == 32
 
 P = C.c_void_p

@@ -52,10 +52,15 @@ thread_local char g_err[256] = "ok";
 __device__ unsigned long long* g_stamp_buf = nullptr;
 #define MD_STAMP_AT(i)                                                                         \
     do {                                                                                       \
-        if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define MD_FINE_STAMP(cond, i)                                                                 \
+    do {                                                                                       \
+        if ((cond) && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 32 + 16 + (i)] = __builtin_readcyclecounter(); \
     } while (0)
 #else
 #define MD_STAMP_AT(i) do { } while (0)
+#define MD_FINE_STAMP(cond, i) do { } while (0)
 #endif
 
 __device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src, 64); }
@@ -231,6 +236,7 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
     const bool has_next = nav.ck1 != nav.ck0;
     const int next_road = has_next ? rroads[nav.ck1] : -1;
 
+    MD_FINE_STAMP(n == 0 && lane_id == 0, 0);
     const MdGrid g = w.grid[m];
     const int gx = (int)md_floor((sh.cx - g.x0) * g.inv_cell);
     const int gy = (int)md_floor((sh.cy - g.y0) * g.inv_cell);
@@ -240,34 +246,41 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
         it0 = w.cell_start[cell];
         it1 = w.cell_start[cell + 1];
     }
+    MD_FINE_STAMP(n == 0 && lane_id == 0 && it1 >= 0, 1);
     int on_lane = 0;
     int best_any = -1, best_cur = -1, best_next = -1;
     float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
-    // Candidate lanes of the cell: each LANE fetches one cell item and its lane record's hull AABB
-    // (three dependent loads done 64-wide instead of once per candidate), survivors are visited in
-    // ascending lane id through the ballot mask (ties in distance resolve to the lowest lane id, like
-    // the oracle's ascending scan).
+    // Candidate lanes of the cell: each LANE fetches one cell item and tests its lane record's hull
+    // AABB (records are in LDS); survivors are visited in ascending lane id through the ballot mask
+    // (ties in distance resolve to the lowest lane id, like the oracle's ascending scan).
+    //   pass A  hull containment of every surviving candidate (edges spread over the 64 lanes, ballot
+    //           vote; 4-vertex hulls come inline from the lane record, no second lookup)
+    //   pass B  ONE batched Frenet evaluation: lane k evaluates the k-th contained candidate
+    //   pass C  uniform selection over the (few) contained candidates
     for (int itb = it0; itb < it1; itb += 64) {
         const int it = itb + lane_id;
-        int l = -1, h_off = 0, h_n = 0;
+        int l = -1;
         bool pass = false;
         if (it < it1) {
             l = w.cell_items[it];
             if (l >= 0) {
                 const MdLane* L = &lanes[l];
                 pass = !(sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1);
-                h_off = L->hull_off;
-                h_n = L->hull_n;
             }
         }
         unsigned long long mask = __ballot(pass);
+        MD_FINE_STAMP(n == 0 && lane_id == 0, 2);
+#ifdef MD_STAMP
+        if (n == 0 && lane_id == 0 && g_stamp_buf)
+            g_stamp_buf[(size_t)blockIdx.x * 32 + 16 + 15] = (unsigned long long)__popcll(mask) | ((unsigned long long)(it1 - it0) << 32);
+#endif
+        unsigned long long inside = 0ull;  // bit k: candidate held by lane k contains the point
         while (mask) {
             const int k = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int lk = bcast_i(l, k);
-            const int hn = bcast_i(h_n, k);
-            const float* xy = w.hull_xy + 2 * (size_t)bcast_i(h_off, k);
-            // hull containment: edges spread over the 64 lanes, ballot vote
+            const MdLane* L = &lanes[bcast_i(l, k)];
+            const int hn = L->hull_n;
+            const float* xy = md_lane_hull(L, w.hull_xy);
             bool outside = false;
             for (int i = lane_id; i < hn; i += 64) {
                 const int j = (i + 1 == hn) ? 0 : i + 1;
@@ -275,22 +288,40 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
                 const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
                 if (cr < 0.0f) outside = true;
             }
-            if (__ballot(outside) != 0ull || hn < 3) continue;
-            on_lane = 1;
-            const MdLane* L = &lanes[lk];
+            if (__ballot(outside) == 0ull && hn >= 3) inside |= 1ull << k;
+        }
+        if (inside == 0ull) continue;
+        on_lane = 1;
+        // pass B: my lane's candidate (if contained): Frenet coordinates, heading filter, L1 distance
+        float my_dist = 3.0e38f;
+        int my_road = -1;
+        if ((inside >> lane_id) & 1ull) {
+            const MdLane* L = &lanes[l];
             float ls, llat;
             md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
             const float lh = md_lane_heading_at(L, ls);
             float hs_, hc_;
             md_sincos(lh, &hs_, &hc_);
             const float cosangle = hc_ * sh.c + hs_ * sh.s;
-            if (!(cosangle > 0.0f)) continue;
-            const float dist = md_lane_distance(L, ls, llat);
+            if (cosangle > 0.0f) {
+                my_dist = md_lane_distance(L, ls, llat);
+                my_road = L->road;
+            }
+        }
+        // pass C
+        while (inside) {
+            const int k = __ffsll((long long)inside) - 1;
+            inside &= inside - 1;
+            const float dist = bcast_f(my_dist, k);
+            const int road = bcast_i(my_road, k);
+            const int lk = bcast_i(l, k);
+            if (road < 0) continue;  // failed the heading filter
             if (dist < d_any) { d_any = dist; best_any = lk; }
-            if (L->road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
-            if (has_next && L->road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
+            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
+            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
         }
     }
+    MD_FINE_STAMP(n == 0 && lane_id == 0, 3);
     if (lane_id != 0) return;  // everything below is wave-uniform; lane 0 commits
     int lane = -1;
     if (best_cur >= 0) lane = best_cur;
@@ -415,18 +446,22 @@ __device__ __forceinline__ void wave_argmin(float& key, int& slot) {
 }
 
 __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
-                                 const MdConfig& c, int e, int slot, int lane_id) {
+                                 const MdConfig& c, int m, int slot, int lane_id) {
     constexpr float kInf = 3.0e38f;
     MdIdmPlan plan;
     plan.success = plan.use_ref = plan.fail = 0;
     plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
-    if (lane_id == 0) md_idm_plan(&w, lanes, roads, &s, &c, e, slot, &plan);
+    const bool st_ = (slot == c.agents_per_env) && lane_id == 0;
+    (void)st_;
+    MD_FINE_STAMP(st_, 4);
+    if (lane_id == 0) md_idm_plan(&w, lanes, roads, &s, &c, m, slot, &plan);
     plan.success = bcast_i(plan.success, 0);
     plan.use_ref = bcast_i(plan.use_ref, 0);
     plan.fail = bcast_i(plan.fail, 0);
     plan.ids[0] = bcast_i(plan.ids[0], 0);
     plan.ids[1] = bcast_i(plan.ids[1], 0);
     plan.ids[2] = bcast_i(plan.ids[2], 0);
+    MD_FINE_STAMP(st_, 5);
     FrontBack fb;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -436,54 +471,157 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const Md
     }
     if (!plan.fail) {
         const float px = s.shape[slot].cx, py = s.shape[slot].cy;
+        // (1) ego longitudinal on the three scanned lanes: lanes 0..2 evaluate one each, then broadcast
+        float my_cur = 0.0f;
+        {
+            const int my_id = (lane_id == 0) ? plan.ids[0] : ((lane_id == 1) ? plan.ids[1] : ((lane_id == 2) ? plan.ids[2] : -1));
+            if (my_id >= 0) {
+                float tmp;
+                md_lane_local(&lanes[my_id], px, py, &my_cur, &tmp);
+            }
+        }
+        float cur_long[3], left_long[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            if (plan.ids[i] < 0) continue;  // wave-uniform
-            const MdLane* L = &lanes[plan.ids[i]];
-            float cur_long, tmp;
-            md_lane_local(L, px, py, &cur_long, &tmp);
-            const float left_long = L->length - cur_long;
-            int found_front = 0, found_back = 0;
-            // pass 1: objects on the same lane
-            for (int j0 = 0; j0 < c.cap; j0 += 64) {
-                const int j = j0 + lane_id;
-                float kf = kInf, kb = kInf;
-                if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py) &&
-                    md_obj_lane_of(&s, j) == plan.ids[i]) {
-                    const float lg = md_fb_same_lane_gap(L, cur_long, &s.shape[j]);
-                    if (lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
-                    if (lg < 0.0f && md_fabs(lg) < IDM_MAX_LONG_DIST) kb = md_fabs(lg);
-                }
-                int jf = j, jb = j;
-                wave_argmin(kf, jf);
-                wave_argmin(kb, jb);
-                if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; found_front = 1; }
-                if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; found_back = 1; }
-            }
-            if (found_front && found_back) continue;
-            // pass 2: objects on the successor / predecessor lane
-            for (int j0 = 0; j0 < c.cap; j0 += 64) {
-                const int j = j0 + lane_id;
-                float kf = kInf, kb = kInf;
-                if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py)) {
+            cur_long[i] = bcast_f(my_cur, i);
+            left_long[i] = (plan.ids[i] >= 0) ? lanes[plan.ids[i]].length - cur_long[i] : 0.0f;
+        }
+        const int npairs = c.cap * 3;
+        if (npairs <= 64) {
+            // (2) every (scanned lane i, object j) pair on its own lane of the wave: ONE Frenet evaluation
+            //     per pair (on lane i for a same-lane object, on the object's lane for a connected one)
+            float val = 0.0f;
+            int meta = 0;  // bit0 same-lane, bit1 lane i precedes obj lane, bit2 obj lane precedes lane i, bits 4-5 i, bits 8.. j
+            {
+                const int p = lane_id;
+                const int i = p / c.cap;
+                const int j = p - i * c.cap;
+                const int id_i = (i == 0) ? plan.ids[0] : ((i == 1) ? plan.ids[1] : plan.ids[2]);
+                const float cur_i = (i == 0) ? cur_long[0] : ((i == 1) ? cur_long[1] : cur_long[2]);
+                if (p < npairs && id_i >= 0 && j != slot && md_idm_is_candidate(&s.shape[j], px, py)) {
                     const int ol = md_obj_lane_of(&s, j);
-                    if (ol >= 0 && ol != plan.ids[i]) {
-                        float lg;
-                        const int cls = md_fb_neighbour(L, &lanes[ol], cur_long, left_long, &s.shape[j], !found_front,
-                                                        !found_back, &lg);
-                        if (cls == 1 && lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
-                        if (cls == 2 && lg < IDM_MAX_LONG_DIST) kb = lg;
+                    const MdLane* L = &lanes[id_i];
+                    int mt = (i << 4) | (j << 8);
+                    // one Frenet evaluation per pair: on lane i for a same-lane object, else on the object's lane
+                    const MdLane* EL = L;
+                    if (ol == id_i) mt |= 1;
+                    else if (ol >= 0) {
+                        EL = &lanes[ol];
+                        mt |= (md_lane_is_previous_of(L, EL) ? 2 : 0) | (md_lane_is_previous_of(EL, L) ? 4 : 0);
+                    }
+                    if (mt & 7) {
+                        float os, ot;
+                        md_lane_local(EL, s.shape[j].cx, s.shape[j].cy, &os, &ot);
+                        val = (mt & 1) ? os - cur_i : os;
+                    }
+                    meta = mt;
+                }
+            }
+            // (3) per scanned lane: arg-min reductions (same-lane objects first, connected lanes only if none)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (plan.ids[i] < 0) continue;  // wave-uniform
+                int found_front = 0, found_back = 0;
+                const bool mine = ((meta >> 4) & 3) == i;
+                {
+                    const bool same = mine && (meta & 1);
+                    float kf = (same && val > 0.0f && val < IDM_MAX_LONG_DIST) ? val : kInf;
+                    float kb = (same && val < 0.0f && md_fabs(val) < IDM_MAX_LONG_DIST) ? md_fabs(val) : kInf;
+                    int jf = meta >> 8, jb = meta >> 8;
+                    wave_argmin(kf, jf);
+                    wave_argmin(kb, jb);
+                    if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; found_front = 1; }
+                    if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; found_back = 1; }
+                }
+                if (found_front && found_back) continue;
+                float kf = kInf, kb = kInf;
+                if (mine && !(meta & 1) && (meta & 6)) {
+                    // md_fb_neighbour's choice: front if (need_front && L precedes OL), else back if (need_back && OL precedes L)
+                    if (!found_front && (meta & 2)) {
+                        const float lg = val + left_long[i];
+                        if (lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
+                    } else if (!found_back && (meta & 4)) {
+                        const float lg = lanes[md_obj_lane_of(&s, meta >> 8)].length - val + cur_long[i];
+                        if (lg < IDM_MAX_LONG_DIST) kb = lg;
                     }
                 }
-                int jf = j, jb = j;
+                int jf = meta >> 8, jb = meta >> 8;
                 wave_argmin(kf, jf);
                 wave_argmin(kb, jb);
                 if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; }
                 if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; }
             }
+        } else {
+            // general capacity: per scanned lane, lanes = objects (two passes, chunks of 64 objects)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (plan.ids[i] < 0) continue;  // wave-uniform
+                const MdLane* L = &lanes[plan.ids[i]];
+                int found_front = 0, found_back = 0;
+                for (int j0 = 0; j0 < c.cap; j0 += 64) {
+                    const int j = j0 + lane_id;
+                    float kf = kInf, kb = kInf;
+                    if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py) &&
+                        md_obj_lane_of(&s, j) == plan.ids[i]) {
+                        const float lg = md_fb_same_lane_gap(L, cur_long[i], &s.shape[j]);
+                        if (lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
+                        if (lg < 0.0f && md_fabs(lg) < IDM_MAX_LONG_DIST) kb = md_fabs(lg);
+                    }
+                    int jf = j, jb = j;
+                    wave_argmin(kf, jf);
+                    wave_argmin(kb, jb);
+                    if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; found_front = 1; }
+                    if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; found_back = 1; }
+                }
+                if (found_front && found_back) continue;
+                for (int j0 = 0; j0 < c.cap; j0 += 64) {
+                    const int j = j0 + lane_id;
+                    float kf = kInf, kb = kInf;
+                    if (j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j], px, py)) {
+                        const int ol = md_obj_lane_of(&s, j);
+                        if (ol >= 0 && ol != plan.ids[i]) {
+                            float lg;
+                            const int cls = md_fb_neighbour(L, &lanes[ol], cur_long[i], left_long[i], &s.shape[j],
+                                                            !found_front, !found_back, &lg);
+                            if (cls == 1 && lg > 0.0f && lg < IDM_MAX_LONG_DIST) kf = lg;
+                            if (cls == 2 && lg < IDM_MAX_LONG_DIST) kb = lg;
+                        }
+                    }
+                    int jf = j, jb = j;
+                    wave_argmin(kf, jf);
+                    wave_argmin(kb, jb);
+                    if (kf < fb.front_d[i]) { fb.front_d[i] = kf; fb.front[i] = jf; }
+                    if (kb < fb.back_d[i]) { fb.back_d[i] = kb; fb.back[i] = jb; }
+                }
+            }
         }
     }
+    MD_FINE_STAMP(st_, 6);
     if (lane_id == 0) md_idm_decide(lanes, roads, &s, slot, &plan, &fb);
+    MD_FINE_STAMP(st_, 7);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Observation / reward / done of one agent by one wave: the nine independent geometric evaluations
+// (md_observe_task) run on lanes 0..8 at once, lane 0 gathers them with v_readlane and combines.
+// ------------------------------------------------------------------------------------------------
+__device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
+                                   int just_reset, int lane_id, float* wave_scratch /* LDS, MD_OBS_TASKS*5 floats */) {
+    MdObsCtx k;
+    md_observe_ctx(lanes, roads, &s, a, &k);
+    if (lane_id < MD_OBS_TASKS) {
+        float mine[5];
+        md_observe_task(lane_id, &k, &s, &c, a, mine);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wave_scratch[lane_id * 5 + i] = mine[i];
+    }
+    // same wave: the LDS unit executes a wave's ds_write / ds_read in order; the fence keeps the
+    // compiler from moving lane 0's reads above the other lanes' writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane_id == 0) md_observe_combine(&k, &s, &c, a, just_reset, (const float (*)[5])wave_scratch);
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,6 +697,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     int32_t* l_rroads = reinterpret_cast<int32_t*>(l_flags + ((cap + 3) & ~3));
     MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
     MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + w.max_lanes);
+    float* l_scratch = reinterpret_cast<float*>(l_roads + w.max_roads) + wave * 48;  // per-wave observe results
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
     constexpr bool kLidarOnly = (PH == PH_LIDAR);
@@ -627,7 +766,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         MD_STAMP_AT(2);
         for (int j = c.agents_per_env + wave; j < cap; j += kWaves) {
             const int f = s.shape[j].flags;  // wave-uniform
-            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, e, j, lane);
+            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane);
         }
         __syncthreads();
     }
@@ -656,7 +795,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     }
     MD_STAMP_AT(7);
     if (PH & PH_OBSERVE) {
-        for (int a = tid; a < c.agents_per_env; a += kBlock) md_observe_agent(lanes, roads, &s, &c, a, just_reset);
+        for (int a = wave; a < c.agents_per_env; a += kWaves) observe_agent_wave(lanes, roads, s, c, a, just_reset, lane, l_scratch);
         MD_STAMP_AT(8);
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
@@ -730,7 +869,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
            void* stream) {
     const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
-                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 16;
+                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 4 * 48 * 4 + 16;
     if (lds > 64 * 1024 || w->max_lanes <= 0 || w->max_roads <= 0) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);

@@ -177,6 +177,8 @@ class MapTables:
                 r["heading"] = l.heading
             hull = convex_hull(l.polygon()).astype(np.float32)
             r["hull_off"], r["hull_n"] = hull_off, len(hull)
+            if len(hull) == 4:
+                r["hull4"] = hull.reshape(-1)
             r["x0"], r["y0"] = hull[:, 0].min(), hull[:, 1].min()
             r["x1"], r["y1"] = hull[:, 0].max(), hull[:, 1].max()
             hull_pts.append(hull)

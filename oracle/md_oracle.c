@@ -136,7 +136,7 @@ static void localize_mover(const MdWorld* w, const MdState* s, const MdConfig* c
     for (int l = 0; l < nl; ++l) {
         const MdLane* L = &lanes[l];
         if (sh->cx < L->x0 || sh->cx > L->x1 || sh->cy < L->y0 || sh->cy > L->y1) continue;
-        if (!md_point_in_hull(sh->cx, sh->cy, w->hull_xy + 2 * (size_t)L->hull_off, L->hull_n)) continue;
+        if (!md_point_in_hull(sh->cx, sh->cy, md_lane_hull(L, w->hull_xy), L->hull_n)) continue;
         on_lane = 1;
         float ls, llat;
         md_lane_local(L, sh->cx, sh->cy, &ls, &llat);

@@ -40,12 +40,14 @@ def main():
     acts = acts.cuda()
     for i in range(80):
         eng.step(acts[i % 16])
-    buf = torch.zeros(E * 16, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(E * 32, dtype=torch.int64, device="cuda")
     eng.lib.md_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     assert eng.lib.md_debug_set_stamp_buffer(buf.data_ptr()) == 0
     eng.step(acts[0])
     torch.cuda.synchronize()
-    st = buf.cpu().numpy().reshape(E, 16)[:, :12].astype(np.int64)
+    raw = buf.cpu().numpy().reshape(E, 32)
+    st = raw[:, :12].astype(np.int64)
+    fine = raw[:, 16:].astype(np.int64)
     d = np.diff(st, axis=1)
     tot = st[:, 11] - st[:, 0]
     print("per-env cycles: mean %.0f  p50 %.0f  p99 %.0f  max %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
@@ -54,6 +56,16 @@ def main():
         x = d[:, i]
         print("%-11s mean %8.0f  p50 %8.0f  p99 %8.0f  max %8.0f   share %5.1f%%" %
               (name, x.mean(), np.median(x), np.percentile(x, 99), x.max(), 100.0 * x.sum() / tot.sum()))
+    ok = (fine[:, 0] > 0) & (fine[:, 3] > 0)
+    lf = fine[ok]
+    print("localize(agent) fine: grid+cell loads %.0f | items+AABB %.0f | hull tests+frenet %.0f  (p50 cycles); candidates p50 %d, cell items p50 %d" % (
+        np.median(lf[:, 1] - lf[:, 0]), np.median(lf[:, 2] - lf[:, 1]), np.median(lf[:, 3] - lf[:, 2]),
+        np.median(lf[:, 15] & 0xffffffff), np.median(lf[:, 15] >> 32)))
+    ok = (fine[:, 4] > 0) & (fine[:, 7] > fine[:, 4])
+    li = fine[ok]
+    if len(li):
+        print("idm(first traffic slot) fine over %d envs: plan %.0f | scan %.0f | decide %.0f (p50 cycles)" % (
+            len(li), np.median(li[:, 5] - li[:, 4]), np.median(li[:, 6] - li[:, 5]), np.median(li[:, 7] - li[:, 6])))
     flags = eng.shape_f.view(torch.int32)[..., 6]
     drv = (((flags & 0x10) != 0) & ((flags & 0x40) == 0) & ((flags & 0xF) == 1)).sum(dim=1).cpu().numpy()
     print("driving vehicles/env: mean %.2f max %d" % (drv.mean(), drv.max()))
