@@ -272,7 +272,8 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     info[2] = step_energy;
     info[3] = s->pid[n].energy;
     info[4] = just_reset ? 0.0f : info[4] + reward;
-    info[5] = llat;
+    info[5] = just_reset ? 0.0f : info[5] + cost; /* SafeMetaDriveEnv total_cost (envs/safe_metadrive_env.py:31-35) */
+    (void)llat;
     info[6] = ls;
     info[7] = (float)nav->steps;
     if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[0] = 1;

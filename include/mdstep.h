@@ -224,7 +224,7 @@ typedef struct MdState {
     float* obs;                /* [n_envs*agents_per_env][obs_dim]                               */
     float* reward;             /* [n_envs*agents_per_env]                                        */
     float* cost;               /* [n_envs*agents_per_env]                                        */
-    float* step_info;          /* [n_envs*agents_per_env][8] step_reward, velocity, step_energy, episode_energy, episode_reward, lateral, long, spare */
+    float* step_info;          /* [n_envs*agents_per_env][8] step_reward, velocity, step_energy, episode_energy, episode_reward, total_cost, long, episode_length */
     int32_t* need_reset;       /* [n_envs] 1 = restore the env from the snapshot before stepping  */
     /* reset snapshot (same layouts) restored by md_step when need_reset[e] != 0                  */
     const MdShape* shape0;

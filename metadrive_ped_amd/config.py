@@ -99,7 +99,7 @@ BATCH_DEFAULT_CONFIG = dict(
 
 _OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False, discrete_action=False,
                  use_multi_discrete=False, random_lane_width=False, random_lane_num=False,
-                 need_inverse_traffic=False, random_traffic=False, accident_prob=0.0)
+                 need_inverse_traffic=False, random_traffic=False)
 
 
 def _merge(dst, src, path=""):

@@ -53,7 +53,8 @@ class HostScene:
                          agent_vehicle_model=cfg["vehicle_config"]["vehicle_model"],
                          spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
-                         traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"])
+                         traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
+                         accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"])
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
         if len(jobs) >= 64 and workers > 1:
@@ -69,7 +70,7 @@ class HostScene:
             tables.append(mt)
             scenes[s] = sc
         if not cfg["mover_capacity"]:
-            need = max(A + sc.n_traffic for sc in scenes.values())
+            need = max(A + sc.n_traffic + sc.n_props for sc in scenes.values())
             cap = min(abi.MD_MAX_CAP, max(8, (need + 7) // 8 * 8))
             for sc in scenes.values():
                 sc.trim(cap)

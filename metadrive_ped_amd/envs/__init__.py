@@ -1,1 +1,1 @@
-from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv  # noqa: F401
+from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv, BatchedSafeMetaDriveEnv  # noqa: F401

@@ -96,7 +96,7 @@ class BatchedMetaDriveEnv:
         info = {
             "velocity": si[:, 1], "steering": e.dyn_f[:, 0, 2], "acceleration": e.dyn_f[:, 0, 3],
             "step_energy": si[:, 2], "episode_energy": si[:, 3], "step_reward": si[:, 0], "episode_reward": si[:, 4],
-            "episode_length": e.nav_i[:, 0, 8], "cost": e.cost[:, 0],
+            "episode_length": e.nav_i[:, 0, 8], "cost": e.cost[:, 0], "total_cost": si[:, 5],
             "crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
             "crash_building": bit(abi.FL_CRASH_BUILDING), "crash_human": bit(abi.FL_CRASH_HUMAN),
             "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
@@ -112,3 +112,20 @@ class BatchedMetaDriveEnv:
     @property
     def current_seeds(self):
         return list(self.engine.host.seeds)
+
+
+class BatchedSafeMetaDriveEnv(BatchedMetaDriveEnv):
+    """SafeMetaDriveEnv (metadrive/envs/safe_metadrive_env.py:7-35): accident scenes on the road (cones,
+    broken-down vehicle + warning tripod, barrier), crashes cost but do not terminate, info["total_cost"]
+    accumulates the episode cost."""
+    SAFE_DEFAULTS = dict(num_scenarios=100, accident_prob=0.8, traffic_density=0.05, crash_vehicle_done=False,
+                         crash_object_done=False)
+
+    @classmethod
+    def default_config(cls):
+        return make_config(dict(cls.SAFE_DEFAULTS))
+
+    def __init__(self, config=None):
+        merged = dict(self.SAFE_DEFAULTS)
+        merged.update(config or {})
+        super().__init__(merged)

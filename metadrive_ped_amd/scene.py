@@ -78,9 +78,17 @@ class EnvScene:
         self.vehicle_cfgs = [None] * cap
 
         engine = Randomizable(seed)          # BaseEngine is a Randomizable seeded with the scenario index
+        object_mgr = Randomizable(seed)
         agent_mgr = Randomizable(seed)
         traffic_mgr = Randomizable(seed)
         dt = cfg["physics_world_step_size"]
+        self._dt = dt
+        self._next_prop_slot = cap - 1       # props fill the slot array from the top down
+        self.accident_lanes = []
+
+        # ---- static props (TrafficObjectManager, PRIORITY 9: before agents and traffic) ----
+        if abs(cfg.get("accident_prob", 0.0)) >= 1e-2:
+            self._object_scenes(cfg, engine, object_mgr, traffic_mgr)
 
         # ---- agents (single agent: slot 0) ----
         assert A == 1, "multi-agent scenes are built by the MARL scene builder"
@@ -106,6 +114,8 @@ class EnvScene:
                 potential = []
                 for lanes in trigger_lanes:
                     for l in lanes:
+                        if l in self.accident_lanes:   # traffic_manager.py:247-248
+                            continue
                         total_num = int(l.length / VEHICLE_GAP)
                         potential += [(l.index, i * VEHICLE_GAP) for i in range(total_num)]
                 total_length = sum(l.length for lanes in trigger_lanes for l in lanes)
@@ -118,7 +128,7 @@ class EnvScene:
                     vtype = str(traffic_mgr.np_random.choice(TRAFFIC_TYPE_KEYS, p=TRAFFIC_TYPE_P))
                     vseed = engine.generate_seed()
                     policy_seed = traffic_mgr.generate_seed()
-                    if slot >= cap:
+                    if slot > self._next_prop_slot:
                         raise ValueError("env seed {}: more than cap={} movers; raise `mover_capacity`".format(seed, cap))
                     self._place_vehicle(slot, vtype, vseed, lane_index, float(long), 0.0, dt,
                                         abi.F_ALIVE | abi.F_PENDING)
@@ -130,12 +140,126 @@ class EnvScene:
                     slot += 1
         self.n_traffic = slot - A
 
+    @property
+    def n_props(self):
+        return len(self.shape) - 1 - self._next_prop_slot
+
     def trim(self, cap):
-        """Shrink the slot arrays to `cap` (>= used slots)."""
-        assert cap >= self.n_traffic + 1
+        """Shrink the slot arrays to `cap`: vehicles keep their low slots, props keep filling from the top."""
+        old = len(self.shape)
+        used_low = 1 + self.n_traffic
+        n_props = self.n_props
+        assert cap >= used_low + n_props
         for k in ("shape", "dyn", "param", "nav", "pid", "route_nodes", "route_roads", "final_lane", "idm_rand"):
-            setattr(self, k, getattr(self, k)[:cap].copy())
-        self.vehicle_cfgs = self.vehicle_cfgs[:cap]
+            arr = getattr(self, k)
+            new = arr[:cap].copy()
+            if n_props:
+                new[cap - n_props:] = arr[old - n_props:]
+            setattr(self, k, new)
+        cfgs = self.vehicle_cfgs[:cap]
+        if n_props:
+            cfgs[cap - n_props:] = self.vehicle_cfgs[old - n_props:]
+        self.vehicle_cfgs = cfgs
+        self._next_prop_slot = cap - 1 - n_props
+
+    # -- TrafficObjectManager.reset (manager/object_manager.py:40-151) ---------------------------
+    ALERT_DIST, ACCIDENT_AREA_LEN, CONE_LONGITUDE, CONE_LATERAL, PROHIBIT_SCENE_PROB = 10, 10, 2, 1, 0.67
+
+    def _object_scenes(self, cfg, engine, object_mgr, traffic_mgr):
+        if not cfg.get("static_traffic_object", True):
+            raise NotImplementedError("static_traffic_object=False (props that react to collisions) is not built")
+        t = self.tables
+        pg_map = t.pg_map
+        rng = object_mgr.np_random
+        prob = cfg["accident_prob"]
+        for block in pg_map.blocks:
+            if block.ID not in ("S", "C", "r", "R"):
+                continue
+            if rng.rand() > prob:
+                continue
+            node0 = "{}{}0_0_".format(block.index, block.ID)
+            node1 = "{}{}0_1_".format(block.index, block.ID)
+            road_1 = (block.pre_socket.positive[1], node0)
+            road_2 = (node0, node1) if block.ID != "S" else None
+            is_ramp = block.ID in ("r", "R")
+            if rng.rand() > self.PROHIBIT_SCENE_PROB:
+                if block.ID != "C":
+                    accident_road = [road_1, road_2][int(rng.choice(2))]
+                else:
+                    accident_road = road_2
+                accident_road = road_1 if accident_road is None else accident_road
+                on_left = bool(rng.rand() > 0.5 or (accident_road is road_2 and is_ramp))
+                lanes = pg_map.net.lanes(*accident_road)
+                lane = lanes[0 if on_left else -1]
+                longitude = lane.length - self.ACCIDENT_AREA_LEN - 5
+                self.accident_lanes.append(lane)
+                self._prohibit_scene(engine, lane, longitude, pg_map.lane_width, on_left)
+            else:
+                accident_road = [road_1, road_2][int(rng.choice(2))]
+                accident_road = road_1 if accident_road is None else accident_road
+                on_left = bool(rng.rand() > 0.5 or (accident_road is road_2 and is_ramp))
+                lanes = pg_map.net.lanes(*accident_road)
+                if len(lanes) - 1 == 0:
+                    idx = -1
+                else:
+                    idx = int(rng.randint(0, len(lanes) - 1)) if on_left else -1
+                lane = lanes[idx]
+                self.accident_lanes.append(lane)
+                longitude = rng.rand() * lane.length / 2 + lane.length / 2
+                if rng.rand() > 0.5:
+                    # break_down_scene: vehicle type comes from the TRAFFIC manager's stream (object_manager.py:96-98)
+                    vtype = str(traffic_mgr.np_random.choice(TRAFFIC_TYPE_KEYS, p=TRAFFIC_TYPE_P))
+                    vseed = engine.generate_seed()
+                    slot = self._take_prop_slot()
+                    self._place_vehicle(slot, vtype, vseed, lane.index, float(longitude), 0.0, self._dt,
+                                        abi.F_ALIVE | abi.F_STATIC)
+                    self.shape[slot]["aux"] = t.lane_id[tuple(lane.index)]
+                    engine.generate_seed()
+                    self._place_prop(abi.KIND_WARNING, lane, longitude - self.ALERT_DIST, 0.0)
+                else:
+                    engine.generate_seed()
+                    self._place_prop(abi.KIND_BARRIER, lane, longitude, 0.0)
+
+    def _prohibit_scene(self, engine, lane, longitude_position, lateral_len, on_left):
+        lat_num = int(lateral_len / self.CONE_LATERAL)
+        longitude_num = int(self.ACCIDENT_AREA_LEN / self.CONE_LONGITUDE)
+        lat_1 = [lat * self.CONE_LATERAL for lat in range(lat_num)]
+        lat_2 = [lat_num * self.CONE_LATERAL] * (longitude_num + 1)
+        lat_3 = [(lat_num - lat - 1) * self.CONE_LATERAL for lat in range(int(lat_num))]
+        total_long_num = lat_num * 2 + longitude_num + 1
+        pos = [(lg * self.CONE_LONGITUDE, lat - lane.width / 2)
+               for lg, lat in zip(range(-int(total_long_num / 2), int(total_long_num / 2)), lat_1 + lat_2 + lat_3)]
+        left = 1 if on_left else -1
+        for p in pos:
+            engine.generate_seed()
+            self._place_prop(abi.KIND_CONE, lane, p[0] + longitude_position, left * p[1])
+
+    def _take_prop_slot(self):
+        slot = self._next_prop_slot
+        if slot < 1:
+            raise ValueError("env seed {}: no free slot for props; raise `mover_capacity`".format(self.seed))
+        self._next_prop_slot -= 1
+        return slot
+
+    def _place_prop(self, kind, lane, longitude, lateral):
+        """Cone r=0.2, warning r=0.5 (cylinders), barrier box 0.3 (along lane) x 2.0
+        (component/static_object/traffic_object.py:43-177)."""
+        slot = self._take_prop_slot()
+        pos = lane.position(longitude, lateral)
+        heading = wrap_to_pi(lane.heading_theta_at(longitude))
+        sh = self.shape[slot]
+        sh["cx"], sh["cy"] = pos
+        sh["c"], sh["s"] = math.cos(heading), math.sin(heading)
+        if kind == abi.KIND_CONE:
+            sh["hl"] = sh["hw"] = 0.2
+        elif kind == abi.KIND_WARNING:
+            sh["hl"] = sh["hw"] = 0.5
+        else:
+            sh["hl"], sh["hw"] = 0.15, 1.0
+        sh["flags"] = kind | abi.F_ALIVE | abi.F_STATIC
+        sh["aux"] = self.tables.lane_id[tuple(lane.index)]
+        self.dyn[slot]["heading"] = heading
+        return slot
 
     def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags):
         t = self.tables

@@ -315,7 +315,62 @@ def section_agent_step():
     dump("agent_step.json", dict(navi_dims_supplied_by_generator=[0, 1, 5, 6], cases=cases))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step)
+def section_objects():
+    """SafeMetaDrive prop scenes: TrafficObjectManager.reset on BIG maps, with the
+    manager's own seeded stream.  spawn_object is replaced by a recorder (it would create Bullet
+    bodies); the placement arithmetic, the scene choice and the RNG consumption are the reference's."""
+    from types import SimpleNamespace
+    import metadrive.manager.object_manager as om
+    from metadrive.manager.object_manager import TrafficObjectManager
+    from metadrive.component.vehicle.vehicle_type import random_vehicle_type
+    from metadrive.utils.random_utils import get_np_random
+    dist_cls, d = cs_dist(0.6, 0.4)
+    cases = []
+    for seed in range(0, 16):
+        big, net = build_reference_map(seed, 3, 3.5, 50, "block_num", 3, dist_cls)
+        for f, td in net.graph.items():
+            for t, lanes in td.items():
+                for i, l in enumerate(lanes):
+                    l.index = (f, t, i)
+        spawned = []
+        traffic_rng = get_np_random(seed)
+
+        class Rec(TrafficObjectManager):
+            def __init__(self):  # no engine / BaseManager machinery
+                self.np_random = get_np_random(seed)
+                self.accident_prob = 0.8
+                self.accident_lanes = []
+
+            def spawn_object(self, cls, **kw):
+                rec = dict(cls=cls if isinstance(cls, str) else cls.__name__)
+                if "position" in kw:
+                    rec.update(position=[float(kw["position"][0]), float(kw["position"][1])],
+                               heading=float(kw["heading_theta"]), lane=list(kw["lane"].index))
+                else:
+                    rec.update(lane=list(kw["vehicle_config"]["spawn_lane_index"]),
+                               longitude=float(kw["vehicle_config"]["spawn_longitude"]))
+                spawned.append(rec)
+                return MagicMock()
+
+        mgr = Rec()
+        map_ = SimpleNamespace(blocks=big.blocks, road_network=net, config={"lane_width": 3.5}, LANE_WIDTH="lane_width")
+        tm = SimpleNamespace(random_vehicle_type=lambda: {"SVehicle": "s", "MVehicle": "m", "LVehicle": "l", "XLVehicle": "xl",
+                                                          "DefaultVehicle": "default"}[
+            random_vehicle_type(traffic_rng, [0.2, 0.3, 0.3, 0.2, 0.0]).__name__])
+        fake_engine = SimpleNamespace(current_map=map_, global_config={"static_traffic_object": True}, traffic_manager=tm)
+        Rec.engine = property(lambda self: fake_engine)
+        old = om.get_engine
+        om.get_engine = lambda: fake_engine
+        try:
+            TrafficObjectManager.reset(mgr)
+        finally:
+            om.get_engine = old
+        cases.append(dict(seed=seed, objects=spawned, accident_lanes=[list(l.index) for l in mgr.accident_lanes],
+                          traffic_stream_next=float(traffic_rng.rand()), object_stream_next=float(mgr.np_random.rand())))
+    dump("objects.json", dict(accident_prob=0.8, cases=cases))
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

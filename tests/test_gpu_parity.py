@@ -73,3 +73,29 @@ def test_single_phase_entry_points(cs_dist):
         ref = orc.lidar()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32)), "lidar t=%d" % t
     assert_state_equal(eng.download_state(), orc.state, where="final")
+
+
+def test_safe_env_rollout_parity(cs_dist):
+    """SafeMetaDrive config (props on the road, crashes do not terminate): cones / tripods / barriers /
+    broken-down vehicles are seen by the lidar, hit by the contact test and scanned by the IDM."""
+    import torch
+    from metadrive_ped_amd import abi
+    E = 40
+    eng, orc = _engine_and_oracle(cs_dist, num_envs=E, num_scenarios=E, accident_prob=0.8, traffic_density=0.05,
+                                  crash_vehicle_done=False, crash_object_done=False, horizon=200)
+    kinds = eng.host.state["shape0"]["flags"] & abi.KIND_MASK
+    assert (kinds == abi.KIND_CONE).sum() > 50 and (kinds == abi.KIND_BARRIER).sum() > 3
+    eng.reset()
+    orc.reset()
+    hit_obj = False
+    for t in range(260):
+        a = scripted_actions(E, 1, t, seed=11)
+        a[:, :, 0] *= 0.3
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 20 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="safe step %d" % t)
+        hit_obj |= bool(((orc.state["flags"].reshape(E, -1)[:, 0] & abi.FL_CRASH_OBJECT) != 0).any())
+    assert_state_equal(eng.download_state(), orc.state, where="safe final")
+    assert hit_obj
+    assert (orc.state["step_info"][:, 5] > 0).any()          # total_cost accumulates
