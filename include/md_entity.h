@@ -46,6 +46,13 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.dyn0 = g->dyn0 ? g->dyn0 + b : 0;
     v.nav0 = g->nav0 ? g->nav0 + b : 0;
     v.pid0 = g->pid0 ? g->pid0 + b : 0;
+    v.route_nodes0 = g->route_nodes0 ? g->route_nodes0 + b * MD_ROUTE_LEN : 0;
+    v.route_roads0 = g->route_roads0 ? g->route_roads0 + b * MD_ROUTE_LEN : 0;
+    v.final_lane0 = g->final_lane0 ? g->final_lane0 + b : 0;
+    v.rng = g->rng ? g->rng + e : 0;
+    v.env_steps = g->env_steps ? g->env_steps + e : 0;
+    v.agent_id = g->agent_id ? g->agent_id + b : 0;
+    v.next_agent_id = g->next_agent_id ? g->next_agent_id + e : 0;
     return v;
 }
 
@@ -69,7 +76,7 @@ MD_HD float md_sanitize(float a) { /* utils/math.py:16-26 safe_clip_for_small_ar
 
 MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     MdShape* sh = &s->shape[n];
-    if (!md_drives(sh->flags)) return;
+    if (!md_drives(sh->flags) || (sh->flags & MD_F_SPAWNED)) return;
     MdDyn* d = &s->dyn[n];
     float steer = md_sanitize(s->action[2 * n]);
     float thr = md_sanitize(s->action[2 * n + 1]);
@@ -158,9 +165,13 @@ MD_HD void md_observe_task(int task, const MdObsCtx* k, const MdState* s, const 
     }
 }
 
-MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfig* c, int a, int just_reset,
+MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfig* c, int a, int env_just_reset,
                               const float (*r)[5]) {
     int n = a;
+    /* a vehicle (re)spawned at the start of this step only reports its first observation
+     * (multi_agent_metadrive.py:190-212: new_obs, reward 0, not terminated) */
+    int just_reset = env_just_reset || ((s->shape[n].flags & MD_F_SPAWNED) != 0);
+    s->shape[n].flags &= ~MD_F_SPAWNED;
     int ai = a; /* env-local view: agent a of this env */
     float* obs = s->obs + (size_t)ai * c->obs_dim;
     float* info = s->step_info + (size_t)ai * 8;
@@ -245,6 +256,13 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     if ((fl & MD_FL_CRASH_OBJECT) && c->crash_object_done) done = 1;
     if (fl & MD_FL_CRASH_BUILDING) done = 1;
     if ((fl & MD_FL_CRASH_HUMAN) && c->crash_human_done) done = 1;
+    if (c->is_multi_agent && !max_step) {
+        /* MultiAgentMetaDrive.done_function (multi_agent_metadrive.py:114-128) */
+        int crash = (fl & (MD_FL_CRASH_VEHICLE | MD_FL_CRASH_OBJECT | MD_FL_CRASH_BUILDING | MD_FL_CRASH_SIDEWALK |
+                           MD_FL_CRASH_HUMAN)) != 0;
+        if (crash && !c->crash_done && !(arrive || out_of_road)) done = 0;
+        if (out_of_road && !c->out_of_road_done && !arrive) done = 0;
+    }
     if (max_step) {
         fl |= MD_FL_MAX_STEP;
         if (c->truncate_as_terminate) done = 1;
@@ -276,7 +294,8 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     (void)llat;
     info[6] = ls;
     info[7] = (float)nav->steps;
-    if (c->auto_reset && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED))) s->need_reset[0] = 1;
+    if (c->auto_reset && !c->is_multi_agent && !just_reset && (fl & (MD_FL_TERMINATED | MD_FL_TRUNCATED)))
+        s->need_reset[0] = 1;
 }
 
 /* serial form (oracle): all tasks, then combine */
@@ -621,6 +640,131 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
     }
     if (!plan.fail) md_find_front_back(s, c, lanes, slot, &plan, s->shape[slot].cx, s->shape[slot].cy, &fb);
     md_idm_decide(lanes, roads, s, slot, &plan, &fb);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-agent lifecycle of one env at the START of a step (serial; one thread per env on the GPU).
+ * References in include/mdstep.h at md_lifecycle.  Random draws (which free spawn place, which
+ * destination) come from a per-env xorshift32 stream: the reference uses an UNSEEDED RandomState for
+ * both (spawn_manager.py:217-220, multi_agent_metadrive.py:199), so any stream is admissible and
+ * this one is reproducible.
+ * -----------------------------------------------------------------------------------------*/
+MD_HD uint32_t md_rng_next(uint32_t* st) {
+    uint32_t x = *st;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    *st = x;
+    return x;
+}
+
+#define MD_RESPAWN_HALF_LEN 4.0f  /* RESPAWN_REGION_LONGITUDE / 2 (spawn_manager.py:28) */
+#define MD_RESPAWN_HALF_WID 1.5f  /* RESPAWN_REGION_LATERAL / 2 */
+
+MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* c, int m) {
+    const int A = c->agents_per_env;
+    s->env_steps[0] += 1;
+    int active = 0, dying = 0;
+    for (int a = 0; a < A; ++a) {
+        MdShape* sh = &s->shape[a];
+        MdNav* nav = &s->nav[a];
+        if (!(sh->flags & MD_F_ALIVE)) continue;
+        if (!(sh->flags & MD_F_STATIC)) {
+            /* active: did it finish at the previous step? (_after_vehicle_done / _finish) */
+            uint32_t fl = s->flags[a];
+            if (nav->done || (fl & MD_FL_TRUNCATED)) {
+                if ((fl & MD_FL_ARRIVE_DEST) || c->delay_done <= 0) {
+                    sh->flags &= ~MD_F_ALIVE;
+                    continue;
+                }
+                sh->flags |= MD_F_STATIC;
+                nav->timer = c->delay_done;
+                s->dyn[a].speed = 0.0f;
+            } else {
+                active++;
+                continue;
+            }
+        }
+        /* dying: countdown (VehicleAgentManager.before_step) */
+        nav->timer -= 1;
+        if (nav->timer <= 0) sh->flags &= ~MD_F_ALIVE;
+        else dying++;
+    }
+    const int horizon_open = !(c->horizon > 0 && s->env_steps[0] >= c->horizon);
+    if (c->allow_respawn && horizon_open && w->spawn_off) {
+        const int p0 = w->spawn_off[m], np_ = w->spawn_off[m + 1] - p0;
+        uint32_t used = 0; /* spawn_places_used, reset every step */
+        while (active + dying < A) {
+            /* safe places: not used this step and no vehicle chassis inside the 8 m x 3 m region */
+            int safe[32];
+            int n_safe = 0;
+            for (int p = 0; p < np_ && p < 32; ++p) {
+                if ((used >> p) & 1u) continue;
+                const float* pl = w->spawn_place + 8 * (size_t)(p0 + p);
+                int hit = 0;
+                for (int j = 0; j < c->cap && !hit; ++j) {
+                    const MdShape* o = &s->shape[j];
+                    if (!md_present(o->flags) || md_kind_of(o->flags) != MD_KIND_VEHICLE) continue;
+                    hit = md_obb_obb(pl[0], pl[1], pl[2], pl[3], MD_RESPAWN_HALF_LEN, MD_RESPAWN_HALF_WID, o->cx, o->cy, o->c,
+                                     o->s, o->hl, o->hw);
+                }
+                if (!hit) {
+                    safe[n_safe++] = p;
+                    used |= 1u << p; /* get_available_respawn_places marks every returned place as used */
+                }
+            }
+            if (n_safe == 0) break;
+            /* one vehicle per call of _respawn_single_vehicle; places found safe stay "used" this step */
+            const int p = safe[md_rng_next(s->rng) % (uint32_t)n_safe];
+            int slot = -1;
+            for (int a = 0; a < A; ++a)
+                if (!(s->shape[a].flags & MD_F_ALIVE)) { slot = a; break; }
+            if (slot < 0) break;
+            const float* pl = w->spawn_place + 8 * (size_t)(p0 + p);
+            const int dest = (int)(md_rng_next(s->rng) % (uint32_t)w->n_dest);
+            const size_t ri = ((size_t)(p0 + p) * w->n_dest + dest);
+            const int32_t* rt = w->spawn_route + ri * 2 * MD_ROUTE_LEN;
+            MdShape* sh = &s->shape[slot];
+            sh->cx = pl[0];
+            sh->cy = pl[1];
+            sh->c = pl[2];
+            sh->s = pl[3];
+            sh->flags = MD_KIND_VEHICLE | MD_F_ALIVE | MD_F_AGENT | MD_F_SPAWNED;
+            sh->aux = -1;
+            MdDyn* d = &s->dyn[slot];
+            d->heading = pl[4];
+            d->speed = 0.0f;
+            d->steering = 0.0f;
+            d->throttle = 0.0f;
+            d->last_x = pl[0];
+            d->last_y = pl[1];
+            d->last_c = pl[2];
+            d->last_s = pl[3];
+            MdNav* nav = &s->nav[slot];
+            nav->lane = w->spawn_lane[p0 + p];
+            nav->route_len = w->spawn_route_meta[2 * ri];
+            nav->ck0 = 0;
+            nav->ck1 = (nav->route_len <= 2) ? 0 : 1;
+            nav->target_lane = -1;
+            nav->timer = 0;
+            nav->steps = 0;
+            nav->done = 0;
+            s->final_lane[slot] = w->spawn_route_meta[2 * ri + 1];
+            for (int k = 0; k < MD_ROUTE_LEN; ++k) {
+                s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];
+                s->route_roads[(size_t)slot * MD_ROUTE_LEN + k] = rt[MD_ROUTE_LEN + k];
+            }
+            s->pid[slot].energy = 0.0f;
+            s->flags[slot] = 0;
+            s->action[2 * slot] = 0.0f;
+            s->action[2 * slot + 1] = 0.0f;
+            s->agent_id[slot] = s->next_agent_id[0];
+            s->next_agent_id[0] += 1;
+            active++;
+        }
+    }
+    /* episode over: nobody left and nobody can come back */
+    if (c->auto_reset && active == 0 && !(c->allow_respawn && horizon_open)) s->need_reset[0] = 1;
 }
 
 #endif /* MD_ENTITY_H */

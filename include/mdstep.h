@@ -60,6 +60,7 @@ extern "C" {
 #define MD_F_PENDING 0x40     /* traffic vehicle waiting for its block's trigger road            */
 #define MD_F_STATIC 0x80      /* never integrated (props, broken-down vehicles)                 */
 #define MD_F_CRASHED_ONCE 0x100 /* COST_ONCE object already counted (traffic_object.py)         */
+#define MD_F_SPAWNED 0x200    /* (re)spawned at the start of this step: not integrated, observe returns its reset obs */
 
 /* ---- per-step flag word (MdState.flags) --------------------------------------------------- */
 #define MD_FL_CRASH_VEHICLE 0x0001
@@ -205,6 +206,15 @@ typedef struct MdWorld {
     const float* beam_cs;      /* [n_beams][2] cos/sin of (2*pi*i/n_beams + phase)              */
     int32_t max_lanes;         /* largest lane count of any map (sizes the kernels' LDS lane table) */
     int32_t max_roads;         /* largest road count of any map                                 */
+    /* multi-agent respawn tables (SpawnManager.safe_spawn_places, manager/spawn_manager.py:123-161); NULL / 0
+     * for single-agent envs */
+    const int32_t* spawn_off;  /* [n_maps+1] CSR into the spawn-place arrays                     */
+    const float* spawn_place;  /* [n_places][8]: x, y, cos, sin, heading, 0, 0, 0 (slot 0 of each spawn road/lane) */
+    const int32_t* spawn_lane; /* [n_places] lane id (map-local)                                 */
+    const int32_t* spawn_route;/* [n_places][n_dest][2][MD_ROUTE_LEN]: checkpoint nodes, then roads */
+    const int32_t* spawn_route_meta; /* [n_places][n_dest][2]: route_len, final_lane              */
+    int32_t n_dest;            /* destinations per spawn place                                   */
+    int32_t pad0;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */
@@ -215,9 +225,9 @@ typedef struct MdState {
     MdNav* nav;
     MdPid* pid;
     float* action;             /* [N][2] steering, throttle_brake in [-1,1] (agents: caller-written) */
-    const int32_t* route_nodes;/* [N][MD_ROUTE_LEN] checkpoints as map-local node ids            */
-    const int32_t* route_roads;/* [N][MD_ROUTE_LEN] road id of (node j, node j+1), -1 past end   */
-    const int32_t* final_lane; /* [N] map-local id of navigation.final_lane                      */
+    int32_t* route_nodes;      /* [N][MD_ROUTE_LEN] checkpoints as map-local node ids (rewritten on respawn) */
+    int32_t* route_roads;      /* [N][MD_ROUTE_LEN] road id of (node j, node j+1), -1 past end   */
+    int32_t* final_lane;       /* [N] map-local id of navigation.final_lane                      */
     const int32_t* idm_rand;   /* [N][MD_IDM_RAND] pre-drawn np_random.randint(0, 25) values of each IDMPolicy
                                   (policy/idm_policy.py:285), consumed cyclically                 */
     uint32_t* flags;           /* [N] MD_FL_*                                                    */
@@ -231,6 +241,15 @@ typedef struct MdState {
     const MdDyn* dyn0;
     const MdNav* nav0;
     const MdPid* pid0;
+    /* multi-agent only */
+    const int32_t* route_nodes0; /* reset snapshot of the routes (respawn rewrites them)            */
+    const int32_t* route_roads0;
+    const int32_t* final_lane0;
+    uint32_t* rng;             /* [n_envs] xorshift32 state of the respawn draws (the reference draws these
+                                  from an unseeded RandomState: spawn_manager.py:217-220)            */
+    int32_t* env_steps;        /* [n_envs] engine.episode_step                                   */
+    int32_t* agent_id;         /* [N] running agent number held by the slot ("agent{k}")          */
+    int32_t* next_agent_id;    /* [n_envs] VehicleAgentManager.next_agent_count                   */
 } MdState;
 
 typedef struct MdConfig {
@@ -261,6 +280,12 @@ typedef struct MdConfig {
     float total_width;         /* (MAX_LANE_NUM+1)*MAX_LANE_WIDTH = 18 (state_obs.py:92)          */
     float curve_radius_max;    /* BlockParameterSpace.CURVE radius max = 60                      */
     float curve_angle_max;     /* BlockParameterSpace.CURVE angle max = 135 (deg)                */
+    /* multi-agent (envs/marl_envs/multi_agent_metadrive.py:12-61) */
+    int32_t is_multi_agent;
+    int32_t delay_done;        /* steps a finished vehicle stays in place as a static body (25)  */
+    int32_t allow_respawn;
+    int32_t crash_done, out_of_road_done;
+    int32_t pad1;
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */
@@ -316,6 +341,13 @@ int md_idm(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
 
 /* Traffic removal after the step: PGTrafficManager.after_step (manager/traffic_manager.py:94-122). */
 int md_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
+
+/* Multi-agent lifecycle at the start of a step: finished agents become static bodies for delay_done
+ * steps then vanish, free slots respawn at free spawn places: MultiAgentMetaDrive.step /
+ * _after_vehicle_done / _respawn_single_vehicle (envs/marl_envs/multi_agent_metadrive.py:130-212),
+ * VehicleAgentManager._finish / before_step (manager/agent_manager.py:115-128,189-202),
+ * SpawnManager.get_available_respawn_places (manager/spawn_manager.py:163-209). */
+int md_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream);
 
 /* One whole env.step() for all envs: BaseEnv.step (envs/base_env.py:426-463,586-623) =
  * [auto-reset] -> idm -> integrate -> localize -> contacts -> traffic_after_step -> observe -> lidar,

@@ -33,7 +33,7 @@ def load():
     lib.md_abi.argtypes = [C.POINTER(C.c_int32), C.c_int]
     lib.md_last_error.restype = C.c_char_p
     W, S, K = C.POINTER(abi.MdWorld), C.POINTER(abi.MdState), C.POINTER(abi.MdConfig)
-    for name in ("md_integrate", "md_localize", "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_step"):
+    for name in ("md_integrate", "md_localize", "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_lifecycle", "md_step"):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [W, S, K, C.c_void_p]

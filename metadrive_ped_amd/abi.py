@@ -19,7 +19,7 @@ MD_IDM_RAND = 8
 # mover kinds / flags
 KIND_NONE, KIND_VEHICLE, KIND_CONE, KIND_WARNING, KIND_BARRIER, KIND_PEDESTRIAN, KIND_CYCLIST = range(7)
 KIND_MASK = 0xF
-F_ALIVE, F_AGENT, F_PENDING, F_STATIC, F_CRASHED_ONCE = 0x10, 0x20, 0x40, 0x80, 0x100
+F_ALIVE, F_AGENT, F_PENDING, F_STATIC, F_CRASHED_ONCE, F_SPAWNED = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 
 # per-step flag word
 FL_CRASH_VEHICLE = 0x0001
@@ -77,6 +77,8 @@ class MdWorld(C.Structure):
         ("quad_off", P), ("quads", P), ("quad_kind", P), ("grid", P), ("cell_start", P), ("cell_items", P),
         ("node_adj_off", P), ("node_adj", P), ("node_off", P), ("beam_cs", P),
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
+        ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
+        ("n_dest", C.c_int32), ("pad0", C.c_int32),
     ]
 
 
@@ -85,6 +87,8 @@ class MdState(C.Structure):
         ("shape", P), ("dyn", P), ("param", P), ("nav", P), ("pid", P), ("action", P), ("route_nodes", P),
         ("route_roads", P), ("final_lane", P), ("idm_rand", P), ("flags", P), ("obs", P), ("reward", P), ("cost", P),
         ("step_info", P), ("need_reset", P), ("shape0", P), ("dyn0", P), ("nav0", P), ("pid0", P),
+        ("route_nodes0", P), ("route_roads0", P), ("final_lane0", P), ("rng", P), ("env_steps", P), ("agent_id", P),
+        ("next_agent_id", P),
     ]
 
 
@@ -102,6 +106,8 @@ class MdConfig(C.Structure):
         ("auto_reset", C.c_int32),
         ("max_lane_width", C.c_float), ("total_width", C.c_float), ("curve_radius_max", C.c_float),
         ("curve_angle_max", C.c_float),
+        ("is_multi_agent", C.c_int32), ("delay_done", C.c_int32), ("allow_respawn", C.c_int32),
+        ("crash_done", C.c_int32), ("out_of_road_done", C.c_int32), ("pad1", C.c_int32),
     ]
 
 
@@ -116,7 +122,7 @@ STATE_FIELDS = [f for f, t in MdState._fields_ if t is P]
 
 # symbols include/mdstep.h declares; tests check every one is exported
 ENTRY_POINTS = ["md_abi", "md_last_error", "md_probe_math", "md_lidar", "md_line_detector", "md_integrate", "md_localize",
-                "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_step"]
+                "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_lifecycle", "md_step"]
 
 
 def check_abi(abi_fn, what):

@@ -30,6 +30,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
+    marl_map=None,          # None | "roundabout" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",
@@ -85,6 +86,11 @@ METADRIVE_DEFAULT_CONFIG = dict(
     crash_object_done=True,
     crash_human_done=True,
     enable_idm_lane_change=True,
+    # multi-agent keys (envs/marl_envs/multi_agent_metadrive.py:12-61); inert for single-agent envs
+    crash_done=True,
+    out_of_road_done=True,
+    force_seed_spawn_manager=False,
+    spawn_roads=None,
 )
 
 # batched-engine keys (no counterpart in the reference: it steps one world per process)
@@ -141,6 +147,8 @@ def make_config(user=None):
         cfg["block_dist_config"] = BlockDist()
     elif isinstance(cfg["block_dist_config"], dict):
         cfg["block_dist_config"] = BlockDist(cfg["block_dist_config"])
+    if cfg["is_multi_agent"] and cfg["marl_map"] is None:
+        raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
         raise ValueError("mover_capacity must be 0 (auto) or in [num_agents, 128]")
     return cfg

@@ -41,7 +41,8 @@ enum Phase : int {
     PH_TRAFFIC = 32,
     PH_OBSERVE = 64,
     PH_LIDAR = 128,
-    PH_ALL = 255,
+    PH_LIFECYCLE = 256,
+    PH_ALL = 511,
 };
 
 thread_local char g_err[256] = "ok";
@@ -744,6 +745,24 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
             l_action[2 * j + 1] = 0.0f;
             l_flags[j] = 0u;
         }
+        if (c.is_multi_agent) {  // respawns rewrote the routes: restore them too
+            for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
+                gv.route_nodes[i] = gv.route_nodes0[i];
+#ifndef MD_NO_STAGE_MAP
+                l_rroads[i] = gv.route_roads0[i];
+#else
+                gv.route_roads[i] = gv.route_roads0[i];
+#endif
+            }
+            for (int j = tid; j < cap; j += kBlock) {
+                gv.final_lane[j] = gv.final_lane0[j];
+                gv.agent_id[j] = j;
+            }
+            if (tid == 0) {
+                gv.env_steps[0] = 0;
+                gv.next_agent_id[0] = c.agents_per_env;
+            }
+        }
     }
     MdState s = gv;  // env-local view whose hot arrays live in LDS
     s.shape = l_shape;
@@ -759,6 +778,11 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     }
     __syncthreads();
     MD_STAMP_AT(1);
+
+    if ((PH & PH_LIFECYCLE) && c.is_multi_agent && !just_reset) {
+        if (tid == 0) md_lifecycle_env(&w, &s, &c, w.env_map[e]);
+        __syncthreads();
+    }
 
     if ((PH & PH_IDM) && !just_reset) {
         if (wave == 0) trigger_env(lanes, s, c, lane);
@@ -808,16 +832,19 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     if (!kLidarOnly) {
         __syncthreads();
         MD_STAMP_AT(10);
-        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
-        if (PH & (PH_RESET | PH_INTEGRATE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
-        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
-        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
+        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+        if (PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
+        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
+#ifndef MD_NO_STAGE_MAP
+        if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent) copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
+#endif
         for (int j = tid; j < cap; j += kBlock) {
-            if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE)) {
+            if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_LIFECYCLE)) {
                 gv.action[2 * j] = l_action[2 * j];
                 gv.action[2 * j + 1] = l_action[2 * j + 1];
             }
-            if (PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE)) gv.flags[j] = l_flags[j];
+            if (PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE | PH_LIFECYCLE)) gv.flags[j] = l_flags[j];
         }
         if (do_reset && tid == 0) gv.need_reset[0] = 0;
     }
@@ -1057,6 +1084,32 @@ __attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* 
     return launch<PH_TRAFFIC>(w, s, c, nullptr, 0, 0, stream);
 }
 
+int check_marl(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    if (!c->is_multi_agent) return MD_OK;
+    NEED(s->rng); NEED(s->env_steps); NEED(s->agent_id); NEED(s->next_agent_id); NEED(s->route_nodes0);
+    NEED(s->route_roads0); NEED(s->final_lane0); NEED(s->final_lane);
+    if (c->allow_respawn) {
+        NEED(w->spawn_off); NEED(w->spawn_place); NEED(w->spawn_lane); NEED(w->spawn_route); NEED(w->spawn_route_meta);
+        if (w->n_dest <= 0) {
+            snprintf(g_err, sizeof g_err, "multi-agent respawn needs MdWorld.n_dest > 0");
+            return MD_EINVAL;
+        }
+    }
+    return MD_OK;
+}
+
+__attribute__((visibility("default"))) int md_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_state(s);
+    if (r != MD_OK) return r;
+    r = check_world(w);
+    if (r != MD_OK) return r;
+    r = check_marl(w, s, c);
+    if (r != MD_OK) return r;
+    return launch<PH_LIFECYCLE>(w, s, c, nullptr, 0, 0, stream);
+}
+
 __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdState* s, const MdConfig* c, void* stream) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
@@ -1069,6 +1122,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
     NEED(s->step_info); NEED(s->need_reset); NEED(w->node_adj_off); NEED(w->node_adj); NEED(w->node_off);
     if (c->n_beams > 0) NEED(w->beam_cs);
     NEED(s->shape0); NEED(s->dyn0); NEED(s->nav0); NEED(s->pid0);
+    r = check_marl(w, s, c);
+    if (r != MD_OK) return r;
     if (c->obs_dim != 19 + c->n_beams) {
         snprintf(g_err, sizeof g_err, "obs_dim=%d != 19 + n_beams=%d", c->obs_dim, c->n_beams);
         return MD_EINVAL;

@@ -21,6 +21,19 @@ from metadrive_ped_amd.scene import EnvScene
 STATE_ARRAY_SPECS = None  # filled below
 
 
+def _build_marl(cfg, scene_cfg, uniq):
+    """Multi-agent roundabout: one shared map, one scene per env seed."""
+    from metadrive_ped_amd.mapgen.pg import MARoundaboutMap
+    from metadrive_ped_amd.marl import ROUNDABOUT_SPAWN_ROADS, RoundaboutScene
+    from metadrive_ped_amd.mapgen.tables import spawn_tables
+    mc = cfg["map_config"]
+    pg = MARoundaboutMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
+    mt = MapTables(pg)
+    sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
+    scenes = {s: RoundaboutScene(s, mt, sc_cfg) for s in uniq}
+    return mt, scenes, spawn_tables(mt, ROUNDABOUT_SPAWN_ROADS, mc["lane_num"])
+
+
 def _build_one(job):
     """One scenario seed -> (MapTables, EnvScene).  Module-level so that a fork pool can run it."""
     s, mc, dist, scene_cfg = job
@@ -55,9 +68,16 @@ class HostScene:
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"])
+        self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
-        if len(jobs) >= 64 and workers > 1:
+        if cfg["is_multi_agent"]:
+            if not cfg["mover_capacity"]:
+                scene_cfg["cap"] = cap = A
+                self.cap = cap
+            mt, marl_scenes, self.spawn = _build_marl(cfg, scene_cfg, uniq)
+            built = [(mt, marl_scenes[s]) for s in uniq]
+        elif len(jobs) >= 64 and workers > 1:
             # reset-time host work only; fork BEFORE this process has touched the GPU (HostScene is built
             # ahead of the first device allocation in BatchedEngine.build)
             import multiprocessing as mp
@@ -66,10 +86,15 @@ class HostScene:
         else:
             built = [_build_one(j) for j in jobs]
         for s, (mt, sc) in zip(uniq, built):
-            map_of_seed[s] = len(tables)
-            tables.append(mt)
+            if cfg["is_multi_agent"]:
+                map_of_seed[s] = 0
+                if not tables:
+                    tables.append(mt)
+            else:
+                map_of_seed[s] = len(tables)
+                tables.append(mt)
             scenes[s] = sc
-        if not cfg["mover_capacity"]:
+        if not cfg["mover_capacity"] and not cfg["is_multi_agent"]:
             need = max(A + sc.n_traffic + sc.n_props for sc in scenes.values())
             cap = min(abi.MD_MAX_CAP, max(8, (need + 7) // 8 * 8))
             for sc in scenes.values():
@@ -79,6 +104,11 @@ class HostScene:
         self.scenes = scenes
         env_map = [map_of_seed[s] for s in seeds]
         self.world = WorldTables(tables, env_map, beam_table(self.n_beams))
+        if self.spawn is not None:
+            a = self.world.arrays
+            a["spawn_off"] = np.asarray([0, len(self.spawn["spawn_lane"])], np.int32)
+            for k in ("spawn_place", "spawn_lane", "spawn_route", "spawn_route_meta"):
+                a[k] = np.ascontiguousarray(self.spawn[k])
         N = E * cap
 
         def stack(field):
@@ -105,6 +135,15 @@ class HostScene:
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
         st["need_reset"] = np.ones(E, np.int32)
+        if cfg["is_multi_agent"]:
+            st["route_nodes0"] = st["route_nodes"].copy()
+            st["route_roads0"] = st["route_roads"].copy()
+            st["final_lane0"] = st["final_lane"].copy()
+            # xorshift32 needs a non-zero state; derive it from the env's scenario seed
+            st["rng"] = np.asarray([((s * 2654435761) ^ 0x9E3779B9) & 0xFFFFFFFF or 1 for s in seeds], np.uint32)
+            st["env_steps"] = np.zeros(E, np.int32)
+            st["agent_id"] = np.tile(np.arange(cap, dtype=np.int32), E)
+            st["next_agent_id"] = np.full(E, A, np.int32)
         self.state = st
         self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
 
@@ -133,6 +172,11 @@ def make_md_config(cfg, E, A, cap, n_beams):
     k.total_width = (3 + 1) * 4.5  # (MAX_LANE_NUM + 1) * MAX_LANE_WIDTH (obs/state_obs.py:92)
     k.curve_radius_max = 60.0   # BlockParameterSpace.CURVE radius max
     k.curve_angle_max = 135.0
+    k.is_multi_agent = int(bool(cfg["is_multi_agent"]))
+    k.delay_done = int(cfg["delay_done"])
+    k.allow_respawn = int(bool(cfg["allow_respawn"]))
+    k.crash_done = int(bool(cfg["crash_done"]))
+    k.out_of_road_done = int(bool(cfg["out_of_road_done"]))
     return k
 
 
@@ -144,6 +188,7 @@ def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
     road_off = np.asarray(world_arrays["road_off_host"])
     w.max_lanes = int(np.diff(lane_off).max())
     w.max_roads = int(np.diff(road_off).max())
+    w.n_dest = int(world_arrays.get("n_dest_host", 0))
     s = abi.MdState()
     abi.fill_struct(s, abi.STATE_FIELDS, state_arrays, ptr_of)
     return w, s, md_config
@@ -182,6 +227,7 @@ class BatchedEngine:
         ptr = lambda t: t.data_ptr()
         wd = dict(self.world_dev)
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
+        wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else 0
         self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         sd = self.state_dev
         # typed views for the env API
@@ -195,6 +241,7 @@ class BatchedEngine:
         self.shape_f = sd["shape"].view(torch.float32).view(self.E, self.cap, 8)
         self.dyn_f = sd["dyn"].view(torch.float32).view(self.E, self.cap, 8)
         self.nav_i = sd["nav"].view(torch.int32).view(self.E, self.cap, 16)
+        self.agent_id = sd["agent_id"].view(torch.int32).view(self.E, self.cap) if "agent_id" in sd else None
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

@@ -1,0 +1,122 @@
+"""BatchedMultiAgentRoundaboutEnv: MultiAgentRoundaboutEnv (envs/marl_envs/marl_inout_roundabout.py:144-153
+over MultiAgentMetaDrive, envs/marl_envs/multi_agent_metadrive.py:65-212) for E lock-stepped environments.
+
+The reference keys every per-agent value by a growing agent name ("agent0", ... "agent57"): a finished
+agent leaves the dicts, a respawned vehicle joins under a new name.  The batched form keeps A = num_agents
+fixed SLOTS per env; a slot is either active (holds a live agent), dying (its finished vehicle stays
+on the road as a static body for `delay_done` steps) or free.  Tensors are [E, A, ...]:
+
+    obs, reward, terminated, truncated, info = env.step(actions)        # actions [E, A, 2]
+    info["active"]    [E, A] bool   slot holds a live agent THIS step (only these rows are meaningful)
+    info["agent_id"]  [E, A] int    the k of the reference's "agent{k}" currently in the slot
+    info["spawned"]   [E, A] bool   slot was (re)filled at the start of this step: obs is its first obs
+    terminated/truncated            per slot; `terminated_all` / `truncated_all` [E] play the role of "__all__"
+
+`to_dicts(e, ...)` rebuilds the reference's dict-of-agents view of one env for drop-in code.
+"""
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.config import make_config
+from metadrive_ped_amd.envs.spaces import Box
+
+MULTI_AGENT_DEFAULTS = dict(
+    is_multi_agent=True, num_agents=40, crash_done=True, out_of_road_done=True, delay_done=25, allow_respawn=True,
+    horizon=1000, truncate_as_terminate=True, traffic_density=0.0, random_spawn_lane_index=False,
+    out_of_road_penalty=10.0, crash_vehicle_penalty=10.0, crash_object_penalty=10.0, crash_vehicle_cost=1.0,
+    crash_object_cost=1.0, out_of_road_cost=0.0, marl_map="roundabout",
+    map_config=dict(exit_length=60, lane_num=2),
+    vehicle_config=dict(vehicle_model="static_default", lidar=dict(num_lasers=72, distance=40, num_others=0)),
+)
+
+
+def _deep_update(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict) and isinstance(dst.get(k), dict):
+            _deep_update(dst[k], v)
+        else:
+            dst[k] = v
+    return dst
+
+
+class BatchedMultiAgentRoundaboutEnv:
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(copy.deepcopy(MULTI_AGENT_DEFAULTS))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), dict(config or {}))
+        self.config = make_config(merged)
+        self.num_envs = self.config["num_envs"]
+        self.num_agents = self.config["num_agents"]
+        lidar = self.config["vehicle_config"]["lidar"]
+        n = lidar["num_lasers"] if lidar["distance"] > 0 else 0
+        self.observation_space = Box(-0.0, 1.0, (19 + n, ), np.float32)
+        self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self.engine = None
+
+    def reset(self, seed=None):
+        if seed is not None:
+            self.config["start_seed"] = int(seed)
+            if self.engine is not None:
+                self.engine.host = None
+                self.engine.cfg = self.config
+                self.engine.build()
+        if self.engine is None:
+            from metadrive_ped_amd.engine import BatchedEngine
+            self.engine = BatchedEngine(self.config)
+        self.engine.reset()
+        return self.engine.obs, self._info()
+
+    def step(self, actions):
+        if self.engine is None:
+            raise RuntimeError("call reset() before step()")
+        torch = self.engine.torch
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
+        if tuple(a.shape) != (self.num_envs, self.num_agents, 2):
+            raise ValueError("actions must have shape [{}, {}, 2], got {}".format(self.num_envs, self.num_agents, tuple(a.shape)))
+        self.engine.step(a)
+        A = self.num_agents
+        fl = self.engine.flags[:, :A]
+        info = self._info()
+        terminated = ((fl & abi.FL_TERMINATED) != 0) & info["active"]
+        truncated = ((fl & abi.FL_TRUNCATED) != 0) & info["active"]
+        info["terminated_all"] = (terminated | ~info["active"]).all(dim=1)
+        info["truncated_all"] = (truncated | ~info["active"]).all(dim=1)
+        return self.engine.obs, self.engine.reward, terminated, truncated, info
+
+    def _info(self):
+        e = self.engine
+        A = self.num_agents
+        sf = e.shape_f.view(e.torch.int32)[:, :A, 6]
+        alive = (sf & abi.F_ALIVE) != 0
+        active = alive & ((sf & abi.F_STATIC) == 0)
+        fl = e.flags[:, :A]
+        bit = lambda m: (fl & m) != 0
+        return {
+            "active": active, "dying": alive & ~active, "agent_id": e.agent_id[:, :A],
+            "spawned": active & (e.nav_i[:, :A, 8] == 0),
+            "velocity": e.step_info[:, :, 1], "step_reward": e.step_info[:, :, 0], "episode_reward": e.step_info[:, :, 4],
+            "episode_length": e.nav_i[:, :A, 8], "cost": e.cost,
+            "crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
+            "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
+            "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
+        }
+
+    def to_dicts(self, e, obs, reward, terminated, truncated, info):
+        """The reference's per-agent dict view of env `e` (keys "agent{k}", plus "__all__")."""
+        act = info["active"][e].cpu().numpy()
+        ids = info["agent_id"][e].cpu().numpy()
+        o, r, tm, tc = {}, {}, {}, {}
+        for a in np.nonzero(act)[0]:
+            k = "agent{}".format(int(ids[a]))
+            o[k], r[k] = obs[e, a].cpu().numpy(), float(reward[e, a])
+            tm[k], tc[k] = bool(terminated[e, a]), bool(truncated[e, a])
+        tm["__all__"] = all(tm.values()) if tm else True
+        tc["__all__"] = all(tc.values()) if tc else True
+        return o, r, tm, tc
+
+    def close(self):
+        self.engine = None

@@ -24,7 +24,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from metadrive_ped_amd.mapgen.lanes import (COLOR_GREY, COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_SIDE,
+from metadrive_ped_amd.mapgen.lanes import (COLOR_GREY, COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_NONE, LINE_SIDE,
                                             CircularLane, StraightLane)
 from metadrive_ped_amd.pg_space import BlockParameterSpace, Parameter, sample_parameters
 from metadrive_ped_amd.rng import get_np_random
@@ -338,7 +338,108 @@ class Curve(Block):
         return ok
 
 
-BLOCK_CLASSES = {"Straight": Straight, "Curve": Curve}
+class Roundabout(Block):
+    """Four-arm roundabout (pgblock/roundabout.py:12-191): per arm an entry arc (radius_exit), a ring arc
+    (radius_big), an exit arc + exit straight, and the inner ring piece that closes the circle."""
+    ID = "O"
+    SPACE = BlockParameterSpace.ROUNDABOUT
+    EXIT_PART_LENGTH = 35
+
+    def __init__(self, *a, exit_part_length=None, extra_config=None, **k):
+        super().__init__(*a, **k)
+        self.exit_part_length = self.EXIT_PART_LENGTH if exit_part_length is None else exit_part_length
+        self.extra_config = dict(extra_config or {})
+        self.intermediate_spawn_places = []
+
+    def road_node(self, part, idx):
+        return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
+
+    def plug(self):
+        self.config.update(self.extra_config)  # construct_block(extra_config=...) (block/base_block.py:113-118)
+        self.intermediate_spawn_places = []
+        p = self.config
+        self.lane_width = self.basic_lane.width
+        ok = True
+        attach = self.pre_socket.positive
+        for i in range(4):
+            exit_road, success = self._build_part(attach, i, p[Parameter.radius_exit], p[Parameter.radius_inner], p[Parameter.angle])
+            ok = ok and success
+            if i < 3:
+                ok = create_adverse_road(exit_road, self.net, self.global_net) and ok
+                attach = negate_road(*exit_road)
+        self.respawn_roads = [s.negative for s in self.sockets.values()]
+        return ok
+
+    def _build_part(self, road, part_idx, radius_exit, radius_inner, angle):
+        ok = True
+        self._part, self._road = part_idx, 0
+        n = self.lane_num
+        w = self.lane_width
+        radius_big = (n * 2 - 1) * w + radius_inner
+        seg = (road[1], self.node())
+        lanes = self.global_net.lanes(*road) if part_idx == 0 else self.net.lanes(*road)
+        right = lanes[-1]
+        bend, straight = bend_then_straight(right, 10, radius_exit, np.deg2rad(angle), True, w, (LINE_BROKEN, LINE_SIDE))
+        ok = create_road_from(bend, n, seg, self.net, self.global_net) and ok
+        for k, lane in enumerate(self.net.lanes(*seg)):
+            lane.line_types = [LINE_NONE, LINE_SIDE] if k == n - 1 else [LINE_NONE, LINE_NONE]
+        # ring arc
+        tool = StraightLane(straight.position(-5, 0), straight.position(0, 0))
+        bend, to_next = bend_then_straight(tool, 10, radius_big, np.deg2rad(2 * angle - 90), False, w, (LINE_BROKEN, LINE_SIDE))
+        seg = (seg[1], self.node())
+        ok = create_road_from(bend, n, seg, self.net, self.global_net) and ok
+        self.intermediate_spawn_places.append(self.net.lanes(*seg))
+        # exit arc + exit straight
+        tool = StraightLane(to_next.position(-5, 0), to_next.position(0, 0))
+        bend, straight = bend_then_straight(tool, self.exit_part_length, radius_exit, np.deg2rad(angle), True, w,
+                                            (LINE_BROKEN, LINE_SIDE))
+        end = self.node() if part_idx < 3 else self.pre_socket.negative[0]
+        seg = (seg[1], end)
+        ok = create_road_from(bend, n, seg, self.net, self.global_net) and ok
+        for k, lane in enumerate(self.net.lanes(*seg)):
+            lane.line_types = [LINE_NONE, LINE_SIDE] if k == n - 1 else [LINE_NONE, LINE_NONE]
+        exit_road = (end, self.node())
+        if part_idx < 3:
+            ok = create_road_from(straight, n, exit_road, self.net, self.global_net) and ok
+            self.add_socket(Socket(exit_road, negate_road(*exit_road)))
+        # inner ring piece closing the circle
+        seg = (self.road_node(part_idx, 1), self.road_node((part_idx + 1) % 4, 0))
+        tool = StraightLane(to_next.position(-6, 0), to_next.position(0, 0))
+        beneath = (n * 2 - 1) * w / 2 + radius_exit
+        radius_seg = beneath / math.cos(np.deg2rad(angle)) - radius_exit
+        bend, _ = bend_then_straight(tool, 5, radius_seg, np.deg2rad(180 - 2 * angle), False, w, (LINE_BROKEN, LINE_SIDE))
+        create_road_from(bend, n, seg, self.net, self.global_net)
+        for k, lane in enumerate(self.net.lanes(*seg)):
+            if k == 0:
+                lane.line_types = [LINE_CONTINUOUS, LINE_BROKEN] if n > 1 else [LINE_CONTINUOUS, LINE_NONE]
+            else:
+                lane.line_types = [LINE_BROKEN, LINE_BROKEN]
+        return exit_road, ok
+
+    def intermediate_spawn_lanes(self):
+        return [self.net.lanes(*r) for r in self.respawn_roads] + self.intermediate_spawn_places
+
+
+BLOCK_CLASSES = {"Straight": Straight, "Curve": Curve, "Roundabout": Roundabout}
+
+
+class MARoundaboutMap:
+    """FirstPGBlock + one Roundabout with fixed parameters: the map of MultiAgentRoundaboutEnv
+    (envs/marl_envs/marl_inout_roundabout.py:27-60)."""
+    def __init__(self, lane_num=2, lane_width=3.5, exit_length=60):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        rb = Roundabout(1, list(first.sockets.values())[0], self.net, 1, exit_part_length=exit_length,
+                        extra_config={"exit_radius": 10, "inner_radius": 30, "angle": 70})
+        rb.construct()
+        self.blocks = [first, rb]
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
 
 
 class PGMap:
@@ -422,10 +523,15 @@ class PGMap:
 
     # ------------------------------------------------------------------------------------------
     def bfs_route(self, start_node, goal):
+        return bfs_route(self.net, start_node, goal)
+
+
+def bfs_route(net, start_node, goal):
+    if True:
         """NodeRoadNetwork.shortest_path / bfs_paths (road_network/node_road_network.py:242-271).
         Neighbour order follows graph insertion order (the reference iterates a set difference;
         PG maps built from I/S/C blocks are chains, so the shortest path is unique)."""
-        g = self.net.graph
+        g = net.graph
         queue = [(start_node, [start_node])]
         while queue:
             node, path = queue.pop(0)
@@ -439,3 +545,6 @@ class PGMap:
                 if nxt in g:
                     queue.append((nxt, path + [nxt]))
         return []
+
+
+MARoundaboutMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

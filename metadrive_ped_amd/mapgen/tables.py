@@ -250,6 +250,53 @@ class MapTables:
         self.cell_items = np.asarray(items, dtype=np.int32)
 
 
+RESPAWN_REGION_LONGITUDE = 8.0  # manager/spawn_manager.py:28
+
+
+def spawn_tables(mt, spawn_roads, lane_num):
+    """Respawn places (slot 0 of every spawn road x lane) and, for each, the route to every destination
+    (end node of the reversed spawn roads): SpawnManager._auto_fill_spawn_roads_randomly /
+    get_available_respawn_places (manager/spawn_manager.py:123-209), RoundaboutSpawnManager.
+    update_destination_for (envs/marl_envs/marl_inout_roundabout.py:136-141)."""
+    from metadrive_ped_amd.mapgen.pg import negate_road
+    pg = mt.pg_map
+    dests = [negate_road(*r)[1] for r in spawn_roads]
+    places, lanes, routes, meta = [], [], [], []
+    for road in spawn_roads:
+        for li in range(lane_num):
+            lane = pg.net.lanes(*road)[li]
+            long = RESPAWN_REGION_LONGITUDE / 2
+            pos = lane.position(long, 0.0)
+            h = wrap_to_pi(lane.heading_theta_at(long))
+            places.append([pos[0], pos[1], math.cos(h), math.sin(h), h, 0.0, 0.0, 0.0])
+            lanes.append(mt.lane_id[(road[0], road[1], li)])
+            for d in dests:
+                nodes, roads_, n, fin = route_arrays(mt, (road[0], road[1], li), d)
+                routes.append([nodes, roads_])
+                meta.append([n, fin])
+    return dict(spawn_place=np.asarray(places, np.float32), spawn_lane=np.asarray(lanes, np.int32),
+                spawn_route=np.asarray(routes, np.int32), spawn_route_meta=np.asarray(meta, np.int32), n_dest=len(dests),
+                dests=dests)
+
+
+def route_arrays(mt, lane_index, dest):
+    """(route_nodes[24], route_roads[24], n_checkpoints, final_lane) of set_route (node_network_navigation.py:94-128)."""
+    pg = mt.pg_map
+    ckpts = pg.bfs_route(lane_index[0], dest)
+    if len(ckpts) <= 2:
+        ckpts = [lane_index[0], lane_index[1]]
+    if len(ckpts) > abi.MD_ROUTE_LEN:
+        raise ValueError("route with {} checkpoints exceeds MD_ROUTE_LEN".format(len(ckpts)))
+    nodes = np.full(abi.MD_ROUTE_LEN, -1, np.int32)
+    roads = np.full(abi.MD_ROUTE_LEN, -1, np.int32)
+    for j, name in enumerate(ckpts):
+        nodes[j] = mt.node_index[name]
+    for j in range(len(ckpts) - 1):
+        roads[j] = mt.road_id[(ckpts[j], ckpts[j + 1])]
+    fr = mt.roads[mt.road_id[(ckpts[-2], ckpts[-1])]]
+    return nodes, roads, len(ckpts), int(fr["first_lane"] + fr["n_lanes"] - 1)
+
+
 class WorldTables:
     """Many maps stacked into the CSR layout of MdWorld."""
     def __init__(self, maps, env_map, beam_cs):

@@ -1,0 +1,88 @@
+"""Multi-agent roundabout: scene construction (host) for MultiAgentRoundaboutEnv.
+
+Restates the reset-time part of envs/marl_envs/marl_inout_roundabout.py + manager/spawn_manager.py:
+one fixed map (FirstPGBlock 60 m, 2 lanes + Roundabout exit 10 / inner 30 / angle 70), 4 spawn roads x 2
+lanes x 6 longitudinal slots = 48 spawn points, `num_agents` (40) of them drawn without replacement, a
++-1 m / +-0.25 m jitter inside the slot (spawn_manager.py:211-218 -- note RESPAWN_REGION_LONGITUDE -
+MAX_VEHICLE_LENGTH = -2, so the reference draws uniform(1, -1)), a random destination among the four
+arms, `static_default` vehicles (fixed engine 800 / brake 150).  The reference seeds none of these
+draws (force_seed_spawn_manager=False); here they come from RandomState(env seed) so that a batch is
+reproducible.  The per-step lifecycle (dying queue, respawn) runs on the device: md_lifecycle.
+"""
+import math
+
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.mapgen.lanes import wrap_to_pi
+from metadrive_ped_amd.mapgen.pg import negate_road
+from metadrive_ped_amd.mapgen.tables import route_arrays
+from metadrive_ped_amd.rng import get_np_random
+from metadrive_ped_amd.scene import vehicle_param_record
+
+ROUNDABOUT_SPAWN_ROADS = [(">>", ">>>"), negate_road("1O0_2_", "1O0_3_"), negate_road("1O1_2_", "1O1_3_"),
+                          negate_road("1O2_2_", "1O2_3_")]
+MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
+REGION_LONG, REGION_LAT = 8.0, 3.0
+
+
+class RoundaboutScene:
+    """Per-env arrays (cap == num_agents slots, all agents) for one env seed."""
+    def __init__(self, seed, mt, cfg):
+        A = cfg["agents_per_env"]
+        cap = cfg["cap"]
+        assert cap >= A
+        self.seed, self.tables = seed, mt
+        self.n_traffic, self.n_props = 0, 0
+        self.shape = np.zeros(cap, dtype=abi.SHAPE_DT)
+        self.shape["aux"] = -1
+        self.dyn = np.zeros(cap, dtype=abi.DYN_DT)
+        self.param = np.zeros(cap, dtype=abi.PARAM_DT)
+        self.nav = np.zeros(cap, dtype=abi.NAV_DT)
+        self.nav["lane"] = -1
+        self.nav["target_lane"] = -1
+        self.pid = np.zeros(cap, dtype=abi.PID_DT)
+        self.pid["target_speed"] = 30.0
+        self.route_nodes = np.full((cap, abi.MD_ROUTE_LEN), -1, dtype=np.int32)
+        self.route_roads = np.full((cap, abi.MD_ROUTE_LEN), -1, dtype=np.int32)
+        self.final_lane = np.zeros(cap, dtype=np.int32)
+        self.idm_rand = np.zeros((cap, abi.MD_IDM_RAND), dtype=np.int32)
+        rng = get_np_random(seed)
+        pg = mt.pg_map
+        lane_num = pg.lane_num
+        exit_length = cfg["exit_length"] - 10   # minus FirstPGBlock.ENTRANCE_LENGTH
+        num_slots = int(math.floor(exit_length / REGION_LONG))
+        spots = [(road, li, j) for road in ROUNDABOUT_SPAWN_ROADS for li in range(lane_num) for j in range(num_slots)]
+        if A > len(spots):
+            raise ValueError("Too many agents! We only accept {} agents, but you have {} agents!".format(len(spots), A))
+        chosen = rng.choice(len(spots), A, replace=False)
+        dests = [negate_road(*r)[1] for r in ROUNDABOUT_SPAWN_ROADS]
+        prm, length, width, vcfg = vehicle_param_record(cfg["agent_vehicle_model"], 0, cfg["physics_world_step_size"])
+        for a, k in enumerate(chosen):
+            road, li, j = spots[int(k)]
+            lane = pg.net.lanes(*road)[li]
+            long = REGION_LONG / 2 + j * REGION_LONG + rng.uniform(-(REGION_LONG - MAX_VEHICLE_LENGTH) / 2,
+                                                                   (REGION_LONG - MAX_VEHICLE_LENGTH) / 2)
+            lat = rng.uniform(-(REGION_LAT - MAX_VEHICLE_WIDTH) / 2, (REGION_LAT - MAX_VEHICLE_WIDTH) / 2)
+            dest = dests[int(rng.randint(len(dests)))]
+            pos = lane.position(long, lat)
+            h = wrap_to_pi(lane.heading_theta_at(long))
+            sh = self.shape[a]
+            sh["cx"], sh["cy"], sh["c"], sh["s"] = pos[0], pos[1], math.cos(h), math.sin(h)
+            sh["hl"], sh["hw"] = length / 2, width / 2
+            sh["flags"] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT
+            d = self.dyn[a]
+            d["heading"], d["last_x"], d["last_y"], d["last_c"], d["last_s"] = h, pos[0], pos[1], sh["c"], sh["s"]
+            self.param[a] = prm
+            nodes, roads, n, fin = route_arrays(mt, (road[0], road[1], li), dest)
+            self.route_nodes[a], self.route_roads[a], self.final_lane[a] = nodes, roads, fin
+            nv = self.nav[a]
+            nv["lane"] = mt.lane_id[(road[0], road[1], li)]
+            nv["ck0"], nv["ck1"] = (0, 1) if n > 2 else (0, 0)
+            nv["route_len"] = n
+        # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
+        self.shape["hl"], self.shape["hw"] = length / 2, width / 2
+        self.param[:] = prm
+
+    def trim(self, cap):
+        pass

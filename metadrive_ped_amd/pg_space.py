@@ -50,10 +50,17 @@ class Parameter:
     radius = "radius"
     angle = "angle"
     dir = "dir"
+    radius_inner = "inner_radius"
+    radius_exit = "exit_radius"
 
 
 class BlockParameterSpace:
     """pg_space.py:275-326 (subset built so far)"""
+    ROUNDABOUT = {
+        "exit_radius": BoxSpace(min=5, max=15),
+        "inner_radius": BoxSpace(min=15, max=45),
+        "angle": ConstantSpace(60),
+    }
     STRAIGHT = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
     CURVE = {
         Parameter.length: BoxSpace(min=40.0, max=80.0),

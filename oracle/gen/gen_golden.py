@@ -370,7 +370,38 @@ def section_objects():
     dump("objects.json", dict(accident_prob=0.8, cases=cases))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects)
+def section_roundabout():
+    """Map of MultiAgentRoundaboutEnv: FirstPGBlock(60 m, 2 lanes) + Roundabout(exit 10,
+    inner 30, angle 70) as MARoundaboutMap._generate builds it (marl_inout_roundabout.py:27-60), the spawn
+    roads, and the shortest checkpoint paths between every spawn road and every destination."""
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.roundabout import Roundabout
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.component.road_network import Road
+    from metadrive.envs.marl_envs.marl_inout_roundabout import MARoundaboutConfig
+    from metadrive.manager.spawn_manager import SpawnManager
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, 2, MagicMock(), MagicMock(), length=60)
+    Roundabout.EXIT_PART_LENGTH = 60
+    rb = Roundabout(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok = rb.construct_block(MagicMock(), MagicMock(), extra_config={"exit_radius": 10, "inner_radius": 30, "angle": 70})
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+    spawn_roads = [[r.start_node, r.end_node] for r in MARoundaboutConfig["spawn_roads"]]
+    routes = []
+    for sr in MARoundaboutConfig["spawn_roads"]:
+        for er in MARoundaboutConfig["spawn_roads"]:
+            dest = (-er).end_node
+            path = net.shortest_path((sr.start_node, sr.end_node, 0), dest)
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest, path=path))
+    dump("roundabout.json", dict(no_cross=bool(ok), roads=roads, spawn_roads=spawn_roads, routes=routes,
+                                 max_capacity=int(SpawnManager.max_capacity(MARoundaboutConfig["spawn_roads"], 60, 2)),
+                                 config={k: float(v) for k, v in dict(rb.get_config()).items()}))
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -325,8 +325,20 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
             s->action[2 * (base + j)] = 0.0f;
             s->action[2 * (base + j) + 1] = 0.0f;
         }
+        if (c->is_multi_agent) {
+            memcpy(&s->route_nodes[(size_t)base * MD_ROUTE_LEN], &s->route_nodes0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
+            memcpy(&s->route_roads[(size_t)base * MD_ROUTE_LEN], &s->route_roads0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
+            memcpy(&s->final_lane[base], &s->final_lane0[base], sizeof(int32_t) * c->cap);
+            s->env_steps[e] = 0;
+            s->next_agent_id[e] = c->agents_per_env;
+            for (int j = 0; j < c->cap; ++j) s->agent_id[base + j] = j;
+        }
         s->need_reset[e] = 0;
         just_reset = 1;
+    }
+    if (c->is_multi_agent && !just_reset) {
+        MdState v = md_env_view(s, c, e);
+        md_lifecycle_env(w, &v, c, w->env_map[e]);
     }
     if (!just_reset) {
         idm_env(w, s, c, e);
@@ -345,6 +357,14 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         if (c->n_beams > 0)
             lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + 19);
     }
+}
+
+EXPORT int ref_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    for (int e = 0; e < c->n_envs; ++e) {
+        MdState v = md_env_view(s, c, e);
+        md_lifecycle_env(w, &v, c, w->env_map[e]);
+    }
+    return MD_OK;
 }
 
 EXPORT int ref_step(const MdWorld* w, const MdState* s, const MdConfig* c) {

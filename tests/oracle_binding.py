@@ -28,7 +28,7 @@ def load():
     lib = C.CDLL(ORACLE_SO)
     W, S, K = C.POINTER(abi.MdWorld), C.POINTER(abi.MdState), C.POINTER(abi.MdConfig)
     for name in ("ref_integrate", "ref_localize", "ref_contacts", "ref_observe", "ref_idm", "ref_traffic_after_step",
-                 "ref_step"):
+                 "ref_lifecycle", "ref_step"):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [W, S, K]
@@ -86,6 +86,7 @@ class OracleWorld:
         self.state = state if state is not None else host.clone_state()
         wa = dict(host.world.arrays)
         wa["lane_off_host"], wa["road_off_host"] = wa["lane_off"], wa["road_off"]
+        wa["n_dest_host"] = host.spawn["n_dest"] if host.spawn is not None else 0
         self.w, self.s, self.k = make_structs(wa, self.state, host.md_config, host.world.n_maps, host.E, _ptr)
 
     def call(self, name, *extra):
