@@ -401,7 +401,99 @@ def section_roundabout():
                                  config={k: float(v) for k, v in dict(rb.get_config()).items()}))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout)
+def section_idm():
+    """IDM longitudinal model, desired gap, PID steering and the front/back object search
+    (SURVEY 8a-10): IDMPolicy.acceleration / desired_gap / steering_control and
+    FrontBackObjects.get_find_front_back_objs of the reference on fake vehicles."""
+    from types import SimpleNamespace
+    from metadrive.policy.idm_policy import IDMPolicy, FrontBackObjects
+    from metadrive.component.vehicle.PID_controller import PIDController
+    from metadrive.component.lane.straight_lane import StraightLane
+    from metadrive.component.lane.circular_lane import CircularLane
+    rng = np.random.RandomState(77)
+    out = {}
+
+    def policy(ego):
+        p = object.__new__(IDMPolicy)
+        p.control_object = ego
+        p.target_speed = IDMPolicy.NORMAL_SPEED
+        p.disable_idm_deceleration = False
+        p.heading_pid = PIDController(1.7, 0.01, 3.5)
+        p.lateral_pid = PIDController(0.3, .002, 0.05)
+        return p
+
+    acc = []
+    for _ in range(120):
+        h = float(rng.uniform(-3.1, 3.1))
+        v = float(rng.uniform(0, 20))
+        fv = float(rng.uniform(0, 20))
+        fh = h + float(rng.uniform(-0.3, 0.3))
+        target = float(rng.choice([30.0, 5.0]))
+        has_front = bool(rng.rand() < 0.7)
+        dist = float(rng.uniform(0.005, 30))
+        ego = SimpleNamespace(speed_km_h=v * 3.6, velocity_km_h=np.array([v * math.cos(h), v * math.sin(h)]) * 3.6,
+                              heading=np.array([math.cos(h), math.sin(h)]))
+        front = SimpleNamespace(velocity_km_h=np.array([fv * math.cos(fh), fv * math.sin(fh)]) * 3.6, speed_km_h=fv * 3.6)
+        p = policy(ego)
+        p.target_speed = target
+        a = IDMPolicy.acceleration(p, front if has_front else None, dist)
+        gap = IDMPolicy.desired_gap(p, ego, front)
+        acc.append(dict(v=v, h=h, fv=fv, fh=fh, target=target, has_front=has_front, dist=dist, acc=float(a), gap=float(gap)))
+    out["acceleration"] = acc
+
+    steer = []
+    lanes = [StraightLane([0, 0], [80, 10], 3.5), CircularLane((5.0, -3.0), 40.0, 0.3, 1.5, True, 3.5),
+             CircularLane((5.0, -3.0), 30.0, -2.0, 1.2, False, 3.5)]
+    for lane in lanes:
+        rec = lane_record(lane)
+        seq = []
+        ego = SimpleNamespace(position=None, heading_theta=0.0)
+        p = policy(ego)
+        for k in range(12):
+            s_ = float(rng.uniform(2, lane.length - 3))
+            lat = float(rng.uniform(-1.5, 1.5))
+            pos = lane.position(s_, lat)
+            ego.position = (float(pos[0]), float(pos[1]))
+            ego.heading_theta = float(lane.heading_theta_at(s_) + rng.uniform(-0.3, 0.3))
+            st = IDMPolicy.steering_control(p, lane)
+            seq.append(dict(pos=list(ego.position), heading=ego.heading_theta, steering=float(st)))
+        rec["sequence"] = seq
+        steer.append(rec)
+    out["steering"] = steer
+
+    # front/back search on a 3-lane straight road followed by a 3-lane straight road
+    def road(x0, x1):
+        ls = []
+        for i in range(3):
+            l = StraightLane([x0, -3.5 * i], [x1, -3.5 * i], 3.5)
+            l.index = ("a%d" % x0, "b%d" % x1, i)
+            ls.append(l)
+        return ls
+    r1, r2 = road(0, 60), road(60, 140)
+    fb = []
+    for _ in range(60):
+        ego_lane = r1[int(rng.randint(3))]
+        es = float(rng.uniform(5, 58))
+        epos = ego_lane.position(es, float(rng.uniform(-0.5, 0.5)))
+        objs = []
+        for j in range(int(rng.randint(1, 9))):
+            lanes_all = r1 + r2
+            ol = lanes_all[int(rng.randint(6))]
+            os_ = float(rng.uniform(1, ol.length - 1))
+            op = ol.position(os_, float(rng.uniform(-0.5, 0.5)))
+            objs.append(SimpleNamespace(lane=ol, position=np.array([float(op[0]), float(op[1])]), slot=j))
+        res = FrontBackObjects.get_find_front_back_objs(objs, ego_lane, (float(epos[0]), float(epos[1])), 30, r1)
+        fb.append(dict(ego_lane=ego_lane.index[2], ego_pos=[float(epos[0]), float(epos[1])],
+                       objs=[dict(road=0 if o.lane in r1 else 1, lane=o.lane.index[2], pos=[float(o.position[0]), float(o.position[1])]) for o in objs],
+                       front=[(o.slot if o is not None else -1) for o in res.front_objs],
+                       back=[(o.slot if o is not None else -1) for o in res.back_objs],
+                       front_dist=[(float(d) if d is not None else None) for d in res.front_dist],
+                       back_dist=[(float(d) if d is not None else None) for d in res.back_dist]))
+    out["front_back"] = fb
+    dump("idm.json", out)
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

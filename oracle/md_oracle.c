@@ -437,6 +437,36 @@ EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, fl
 EXPORT void ref_probe_math(int op, const float* a, const float* b, float* out, int n) {
     for (int i = 0; i < n; ++i) out[i] = md_probe_eval(op, a[i], b[i]);
 }
+EXPORT float ref_idm_gap(float v_kmh, float dv_kmh) { return md_idm_desired_gap(v_kmh, dv_kmh); }
+/* IDMPolicy.steering_control (policy/idm_policy.py:293-301); pid6 = heading p,i,d then lateral p,i,d */
+EXPORT float ref_idm_steer(const MdLane* L, float x, float y, float heading, float* pid6) {
+    float s_, lat;
+    md_lane_local(L, x, y, &s_, &lat);
+    float lane_heading = md_lane_heading_at(L, s_ + 1.0f);
+    float st = md_pid(&pid6[0], &pid6[1], &pid6[2], 1.7f, 0.01f, 3.5f, -md_wrap_to_pi(lane_heading - heading));
+    st += md_pid(&pid6[3], &pid6[4], &pid6[5], 0.3f, 0.002f, 0.05f, -lat);
+    return st;
+}
+/* FrontBackObjects.get_find_front_back_objs on a hand-made scene: out = front[3], back[3]; dist = front_d[3], back_d[3] */
+EXPORT void ref_front_back(const MdLane* lanes, MdShape* shapes, MdNav* navs, int cap, int self_slot, const int* ids3,
+                           float px, float py, int* out6, float* dist6) {
+    MdState s;
+    memset(&s, 0, sizeof s);
+    s.shape = shapes;
+    s.nav = navs;
+    MdConfig c;
+    memset(&c, 0, sizeof c);
+    c.cap = cap;
+    MdIdmPlan p;
+    p.success = 1; p.use_ref = 1; p.fail = 0;
+    p.ids[0] = ids3[0]; p.ids[1] = ids3[1]; p.ids[2] = ids3[2];
+    FrontBack fb;
+    md_find_front_back(&s, &c, lanes, self_slot, &p, px, py, &fb);
+    for (int i = 0; i < 3; ++i) {
+        out6[i] = fb.front[i]; out6[3 + i] = fb.back[i];
+        dist6[i] = fb.front_d[i]; dist6[3 + i] = fb.back_d[i];
+    }
+}
 EXPORT int ref_abi(int32_t* sizes, int n) {
     int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),
                      sizeof(MdRoad), sizeof(MdGrid), sizeof(MdWorld), sizeof(MdState), sizeof(MdConfig)};

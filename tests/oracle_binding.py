@@ -67,6 +67,11 @@ def load():
     lib.ref_obb_quad.restype = C.c_int
     lib.ref_obb_quad.argtypes = [C.c_void_p, C.c_void_p]
     lib.ref_bicycle.argtypes = [C.c_void_p, f, f, C.c_void_p, f, C.c_int]
+    lib.ref_idm_gap.restype = f
+    lib.ref_idm_gap.argtypes = [f, f]
+    lib.ref_idm_steer.restype = f
+    lib.ref_idm_steer.argtypes = [C.c_void_p, f, f, f, C.c_void_p]
+    lib.ref_front_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, f, f, C.c_void_p, C.c_void_p]
     lib.ref_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     abi.check_abi(lib.ref_abi, ORACLE_SO)
     _LIB = lib
