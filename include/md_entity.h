@@ -56,6 +56,12 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     return v;
 }
 
+/* observation layout offsets (obs/state_obs.py:64-151) */
+MD_HD int md_obs_mid(const MdConfig* c) { return c->n_side > 0 ? c->n_side : 2; }              /* heading_diff ... */
+MD_HD int md_obs_ll(const MdConfig* c) { return md_obs_mid(c) + 6; }                             /* lane-line block  */
+MD_HD int md_obs_navi(const MdConfig* c) { return md_obs_ll(c) + (c->n_lane_line > 0 ? c->n_lane_line : 1); }
+MD_HD int md_obs_lidar(const MdConfig* c) { return md_obs_navi(c) + 10; }
+
 MD_HD int md_kind_of(int flags) { return flags & MD_KIND_MASK; }
 MD_HD int md_is_circle_kind(int k) { return k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_PEDESTRIAN; }
 /* present: has a body in the world (seen by lidar, can be hit).  Traffic spawned for a block that
@@ -177,8 +183,9 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     float* info = s->step_info + (size_t)ai * 8;
     MdDyn* d = &s->dyn[n];
     MdNav* nav = &s->nav[n];
+    const int o_mid = md_obs_mid(c), o_ll = md_obs_ll(c), o_navi = md_obs_navi(c);
     if (!k->valid) {
-        for (int i = 0; i < 19; ++i) obs[i] = 0.0f;
+        for (int i = 0; i < md_obs_lidar(c); ++i) obs[i] = 0.0f;
         s->reward[ai] = 0.0f;
         s->cost[ai] = 0.0f;
         for (int i = 0; i < 8; ++i) info[i] = 0.0f;
@@ -198,20 +205,22 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     /* ---- state obs (obs/state_obs.py:64-151) ---- */
     float speed_kmh = md_fabs(d->speed) * 3.6f;
     const MdParam* P = &s->param[n];
-    obs[0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
-    obs[1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
-    obs[2] = r[1][0];
-    obs[3] = md_clip((speed_kmh + 1.0f) / (P->max_speed_kmh + 1.0f), 0.0f, 1.0f);
-    obs[4] = md_clip((d->steering / 60.0f + 1.0f) / 2.0f, 0.0f, 1.0f); /* MAX_STEERING = 60 (base_vehicle.py:80) */
-    obs[5] = md_clip((s->action[2 * n] + 1.0f) / 2.0f, 0.0f, 1.0f);
-    obs[6] = md_clip((s->action[2 * n + 1] + 1.0f) / 2.0f, 0.0f, 1.0f);
-    obs[7] = r[8][0];
+    if (c->n_side <= 0) { /* side detector off: distances to the route's left / right border */
+        obs[0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
+        obs[1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
+    }
+    obs[o_mid + 0] = r[1][0];
+    obs[o_mid + 1] = md_clip((speed_kmh + 1.0f) / (P->max_speed_kmh + 1.0f), 0.0f, 1.0f);
+    obs[o_mid + 2] = md_clip((d->steering / 60.0f + 1.0f) / 2.0f, 0.0f, 1.0f); /* MAX_STEERING = 60 (base_vehicle.py:80) */
+    obs[o_mid + 3] = md_clip((s->action[2 * n] + 1.0f) / 2.0f, 0.0f, 1.0f);
+    obs[o_mid + 4] = md_clip((s->action[2 * n + 1] + 1.0f) / 2.0f, 0.0f, 1.0f);
+    obs[o_mid + 5] = r[8][0];
     float ls = r[2][0], llat = r[2][1];
-    obs[8] = md_clip((llat * 2.0f / c->max_lane_width + 1.0f) / 2.0f, 0.0f, 1.0f);
+    if (c->n_lane_line <= 0) obs[o_ll] = md_clip((llat * 2.0f / c->max_lane_width + 1.0f) / 2.0f, 0.0f, 1.0f);
     /* ---- navi (node_network_navigation.py:160-168, 243-292) ---- */
     for (int i = 0; i < 5; ++i) {
-        obs[9 + i] = r[3][i];
-        obs[14 + i] = r[4][i];
+        obs[o_navi + i] = r[3][i];
+        obs[o_navi + 5 + i] = r[4][i];
     }
 
     /* ---- arrive destination (metadrive_env.py:213-227) ---- */

@@ -258,7 +258,7 @@ typedef struct MdConfig {
     int32_t agents_per_env;
     int32_t cap;               /* mover slots per env                                            */
     int32_t n_beams;           /* lidar num_lasers (0 = lidar off)                               */
-    int32_t obs_dim;           /* 19 + n_beams                                                   */
+    int32_t obs_dim;           /* (n_side or 2) + 6 + (n_lane_line or 1) + 10 + n_beams  (= 19 + n_beams by default) */
     int32_t substeps;          /* decision_repeat (envs/base_env.py:186)  = 5                     */
     int32_t horizon;           /* 0 = None                                                       */
     float dt;                  /* physics_world_step_size (envs/base_env.py:185) = 0.02          */
@@ -285,6 +285,10 @@ typedef struct MdConfig {
     int32_t delay_done;        /* steps a finished vehicle stays in place as a static body (25)  */
     int32_t allow_respawn;
     int32_t crash_done, out_of_road_done;
+    /* observation layout (obs/state_obs.py:64-151): [side cloud n_side | left,right] + 5 + yaw +
+     * [lane-line cloud n_lane_line | lateral] + navi 10 + lidar n_beams */
+    int32_t n_side;            /* side_detector.num_lasers (0 = off: two distance dims instead)   */
+    int32_t n_lane_line;       /* lane_line_detector.num_lasers (0 = off: one lateral dim instead) */
     int32_t pad1;
 } MdConfig;
 

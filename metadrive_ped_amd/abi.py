@@ -107,7 +107,8 @@ class MdConfig(C.Structure):
         ("max_lane_width", C.c_float), ("total_width", C.c_float), ("curve_radius_max", C.c_float),
         ("curve_angle_max", C.c_float),
         ("is_multi_agent", C.c_int32), ("delay_done", C.c_int32), ("allow_respawn", C.c_int32),
-        ("crash_done", C.c_int32), ("out_of_road_done", C.c_int32), ("pad1", C.c_int32),
+        ("crash_done", C.c_int32), ("out_of_road_done", C.c_int32), ("n_side", C.c_int32), ("n_lane_line", C.c_int32),
+        ("pad1", C.c_int32),
     ]
 
 

@@ -1055,8 +1055,8 @@ __attribute__((visibility("default"))) int md_observe(const MdWorld* w, const Md
     if (r != MD_OK) return r;
     NEED(s->dyn); NEED(s->param); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_roads); NEED(s->final_lane);
     NEED(s->flags); NEED(s->obs); NEED(s->reward); NEED(s->cost); NEED(s->step_info); NEED(s->need_reset);
-    if (c->obs_dim < 19) {
-        snprintf(g_err, sizeof g_err, "obs_dim=%d < 19", c->obs_dim);
+    if (c->obs_dim < md_obs_lidar(c)) {
+        snprintf(g_err, sizeof g_err, "obs_dim=%d < %d", c->obs_dim, md_obs_lidar(c));
         return MD_EINVAL;
     }
     return launch<PH_OBSERVE>(w, s, c, nullptr, 0, 0, stream);
@@ -1124,11 +1124,11 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
     NEED(s->shape0); NEED(s->dyn0); NEED(s->nav0); NEED(s->pid0);
     r = check_marl(w, s, c);
     if (r != MD_OK) return r;
-    if (c->obs_dim != 19 + c->n_beams) {
-        snprintf(g_err, sizeof g_err, "obs_dim=%d != 19 + n_beams=%d", c->obs_dim, c->n_beams);
+    if (c->obs_dim != md_obs_lidar(c) + c->n_beams) {
+        snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim, md_obs_lidar(c), c->n_beams);
         return MD_EINVAL;
     }
-    return launch<PH_ALL>(w, s, c, s->obs, c->obs_dim, 19, stream);
+    return launch<PH_ALL>(w, s, c, s->obs, c->obs_dim, md_obs_lidar(c), stream);
 }
 
 }  // extern "C"

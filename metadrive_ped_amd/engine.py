@@ -53,7 +53,11 @@ class HostScene:
         A = cfg["num_agents"]
         self.E, self.cap, self.A = E, cap, A
         self.n_beams = int(cfg["vehicle_config"]["lidar"]["num_lasers"]) if cfg["vehicle_config"]["lidar"]["distance"] > 0 else 0
-        self.obs_dim = 19 + self.n_beams
+        vc = cfg["vehicle_config"]
+        self.n_side = int(vc["side_detector"]["num_lasers"]) if vc["side_detector"]["distance"] > 0 else 0
+        self.n_ll = int(vc["lane_line_detector"]["num_lasers"]) if vc["lane_line_detector"]["distance"] > 0 else 0
+        self.state_dim = (self.n_side or 2) + 6 + (self.n_ll or 1) + 10   # 19 with both detectors off
+        self.obs_dim = self.state_dim + self.n_beams
         mc = cfg["map_config"]
         seeds = [cfg["start_seed"] + ((cfg["env_seed_offset"] + e) % cfg["num_scenarios"]) for e in range(E)]
         self.seeds = seeds
@@ -146,6 +150,11 @@ class HostScene:
             st["next_agent_id"] = np.full(E, A, np.int32)
         self.state = st
         self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
+        self.md_config.n_side, self.md_config.n_lane_line = self.n_side, self.n_ll
+        self.md_config.obs_dim = self.obs_dim
+        # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
+        self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
+        self.ll_beams = beam_table(self.n_ll, np.pi / 2) if self.n_ll else None
 
     def clone_state(self):
         return {k: v.copy() for k, v in self.state.items()}
@@ -229,6 +238,8 @@ class BatchedEngine:
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
         wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else 0
         self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
+        self._side_beams = self._to_dev(h.side_beams) if h.side_beams is not None else None
+        self._ll_beams = self._to_dev(h.ll_beams) if h.ll_beams is not None else None
         sd = self.state_dev
         # typed views for the env API
         self.obs = sd["obs"].view(torch.float32).view(self.E, self.A, self.obs_dim)
@@ -252,8 +263,23 @@ class BatchedEngine:
         self.need_reset.fill_(1)
         self.step_raw()
 
+    SIDE_MASK = (1 << abi.Q_LINE_WHITE_CONT) | (1 << abi.Q_LINE_YELLOW_CONT)      # CollisionGroup.ContinuousLaneLine
+    LANE_LINE_MASK = SIDE_MASK | (1 << abi.Q_LINE_BROKEN)                         # ... | BrokenLaneLine
+
     def step_raw(self):
         self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
+        h = self.host
+        if h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
+            self.line_detector(self._side_beams, h.n_side, float(self.cfg["vehicle_config"]["side_detector"]["distance"]),
+                               self.SIDE_MASK, self.state_dev["obs"], h.obs_dim, 0)
+        if h.n_ll:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
+            self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
+                               self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, (h.n_side or 2) + 6)
+
+    def line_detector(self, beams, n, dist, mask, out, stride, offset):
+        self._check(self.lib.md_line_detector(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(beams.data_ptr()),
+                                              n, C.c_float(dist), C.c_uint32(mask), C.c_void_p(out.data_ptr()), stride, offset,
+                                              self._stream()), "md_line_detector")
 
     def step(self, actions):
         """actions: tensor [E, A, 2] (or [E, 2] when A == 1), float32, on the engine's device."""

@@ -53,7 +53,10 @@ class BatchedMultiAgentRoundaboutEnv:
         self.num_agents = self.config["num_agents"]
         lidar = self.config["vehicle_config"]["lidar"]
         n = lidar["num_lasers"] if lidar["distance"] > 0 else 0
-        self.observation_space = Box(-0.0, 1.0, (19 + n, ), np.float32)
+        vc = self.config["vehicle_config"]
+        n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
+        n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
+        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + 10 + n, ), np.float32)
         self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
         self.engine = None
 

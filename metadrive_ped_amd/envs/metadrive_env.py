@@ -36,7 +36,10 @@ class BatchedMetaDriveEnv:
         self.engine = None
         lidar = self.config["vehicle_config"]["lidar"]
         n = lidar["num_lasers"] if lidar["distance"] > 0 else 0
-        self._obs_dim = 19 + n
+        vc = self.config["vehicle_config"]
+        n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
+        n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
+        self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 10 + n
         self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
         self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
         self.start_seed = self.config["start_seed"]

@@ -355,7 +355,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         MdState v = md_env_view(s, c, e);
         md_observe_agent(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a, just_reset);
         if (c->n_beams > 0)
-            lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + 19);
+            lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + md_obs_lidar(c));
     }
 }
 

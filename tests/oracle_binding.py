@@ -106,10 +106,24 @@ class OracleWorld:
             self.call("ref_step_mt", threads)
         else:
             self.call("ref_step")
+        self._detectors()
+
+    def _detectors(self):
+        from metadrive_ped_amd.engine import BatchedEngine
+        h = self.host
+        vc = h.cfg["vehicle_config"]
+        if h.n_side:
+            self.call("ref_line_detector", C.c_void_p(h.side_beams.ctypes.data), h.n_side, C.c_float(vc["side_detector"]["distance"]),
+                      C.c_uint32(BatchedEngine.SIDE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim, 0)
+        if h.n_ll:
+            self.call("ref_line_detector", C.c_void_p(h.ll_beams.ctypes.data), h.n_ll, C.c_float(vc["lane_line_detector"]["distance"]),
+                      C.c_uint32(BatchedEngine.LANE_LINE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim,
+                      (h.n_side or 2) + 6)
 
     def reset(self):
         self.state["need_reset"][:] = 1
         self.call("ref_step")
+        self._detectors()
 
     def lidar(self):
         out = np.zeros((self.host.E * self.host.A, self.host.n_beams), np.float32)

@@ -99,3 +99,28 @@ def test_safe_env_rollout_parity(cs_dist):
     assert_state_equal(eng.download_state(), orc.state, where="safe final")
     assert hit_obj
     assert (orc.state["step_info"][:, 5] > 0).any()          # total_cost accumulates
+
+
+def test_side_and_lane_line_detectors_in_obs(cs_dist):
+    """side_detector / lane_line_detector on (reference test configs: tests/test_env/test_metadrive_env.py:26-33):
+    the two clouds take the place of the border-distance / lateral dims; md_line_detector vs ref_line_detector."""
+    import torch
+    E = 16
+    eng, orc = _engine_and_oracle(cs_dist, num_envs=E, num_scenarios=E,
+                                  vehicle_config=dict(side_detector=dict(num_lasers=12, distance=50),
+                                                      lane_line_detector=dict(num_lasers=6, distance=20),
+                                                      lidar=dict(num_lasers=120, distance=50)))
+    assert eng.obs_dim == 12 + 6 + 6 + 10 + 120
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="detector reset")
+    for t in range(60):
+        a = scripted_actions(E, 1, t, seed=5)
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+    st = eng.download_state()
+    assert_state_equal(st, orc.state, where="detector final")
+    side = st["obs"][:, :12]
+    assert (side < 1.0).any() and (side >= 0).all()           # the road border is within 50 m of a car on the road
+    ll = st["obs"][:, 18:24]
+    assert (ll < 1.0).any()
