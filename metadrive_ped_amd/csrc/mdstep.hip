@@ -699,6 +699,8 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
     MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + w.max_lanes);
     float* l_scratch = reinterpret_cast<float*>(l_roads + w.max_roads) + wave * 48;  // per-wave observe results
+    MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + w.max_roads) + kWaves * 48);
+    int32_t* l_final = reinterpret_cast<int32_t*>(l_param + cap);
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
     constexpr bool kLidarOnly = (PH == PH_LIDAR);
@@ -726,10 +728,12 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         copy16(l_dyn, gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         copy16(l_nav, gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
         copy16(l_pid, gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
+        copy16(l_param, gv.param, cap * (int)sizeof(MdParam), tid, kBlock);
         for (int j = tid; j < cap; j += kBlock) {
             l_action[2 * j] = gv.action[2 * j];
             l_action[2 * j + 1] = gv.action[2 * j + 1];
             l_flags[j] = gv.flags[j];
+            l_final[j] = gv.final_lane ? gv.final_lane[j] : 0;
         }
     }
     const bool do_reset = reset_flag != 0;  // block-uniform
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
 #endif
             }
             for (int j = tid; j < cap; j += kBlock) {
-                gv.final_lane[j] = gv.final_lane0[j];
+                l_final[j] = gv.final_lane0[j];
                 gv.agent_id[j] = j;
             }
             if (tid == 0) {
@@ -772,6 +776,8 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         s.pid = l_pid;
         s.action = l_action;
         s.flags = l_flags;
+        s.param = l_param;
+        s.final_lane = l_final;
 #ifndef MD_NO_STAGE_MAP
         s.route_roads = l_rroads;
 #endif
@@ -839,6 +845,8 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
 #ifndef MD_NO_STAGE_MAP
         if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent) copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
 #endif
+        if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent)
+            for (int j = tid; j < cap; j += kBlock) gv.final_lane[j] = l_final[j];
         for (int j = tid; j < cap; j += kBlock) {
             if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_LIFECYCLE)) {
                 gv.action[2 * j] = l_action[2 * j];
@@ -896,7 +904,8 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
            void* stream) {
     const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
-                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 4 * 48 * 4 + 16;
+                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 4 * 48 * 4 +
+                       (size_t)c->cap * (sizeof(MdParam) + 4) + 16;
     if (lds > 64 * 1024 || w->max_lanes <= 0 || w->max_roads <= 0) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
