@@ -12,7 +12,8 @@ import os
 from metadrive_ped_amd import abi
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmdstep.so")
+# MD_LIB_PATH: tuning experiments only (A/B of differently compiled builds of the same source)
+LIB_PATH = os.environ.get("MD_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmdstep.so")
 
 
 class MdStepError(RuntimeError):
