@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--cap", type=int, default=0, help="mover slots per env (0 = smallest that fits)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl"],
+                   help="metadrive = BASELINE configs[1] (the headline line); safe = configs[3] per-GPU shard (8192 "
+                        "SafeMetaDriveEnv); marl = configs[2] (1024 x 40-agent roundabout, 240 beams)")
     p.add_argument("--cpu-envs", type=int, default=2048)
     p.add_argument("--cpu-steps", type=int, default=100)
     return p.parse_args()
@@ -66,10 +69,27 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     E = args.envs
-    cfg = make_config(dict(
-        num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0, map=3,
-        block_dist_config=cs_dist(), traffic_density=0.1, mover_capacity=args.cap, auto_reset=True, horizon=1000,
-        device="cuda:%d" % local_rank))
+    common = dict(num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0,
+                  mover_capacity=args.cap, auto_reset=True, device="cuda:%d" % local_rank)
+    if args.workload == "metadrive":
+        cfg = make_config(dict(common, map=3, block_dist_config=cs_dist(), traffic_density=0.1, horizon=1000))
+        label = ("BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (Curve/Straight blocks), 240-beam "
+                 "lidar, traffic_density=0.1, trigger traffic, auto-reset" % E)
+    elif args.workload == "safe":
+        if args.envs == 4096:
+            E = common["num_envs"] = 8192
+            common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
+        from metadrive_ped_amd.envs.metadrive_env import BatchedSafeMetaDriveEnv
+        cfg = make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, block_dist_config=cs_dist(),
+                                                                              horizon=1000)))
+        label = "BASELINE configs[3] shard: %d SafeMetaDriveEnv per GPU (accident_prob 0.8, density 0.05), 240 beams" % E
+    else:
+        if args.envs == 4096:
+            E = common["num_envs"] = 1024
+            common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
+        from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
+        cfg = BatchedMultiAgentRoundaboutEnv(dict(common, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50)))).config
+        label = "BASELINE configs[2]: %d MultiAgentRoundaboutEnv x 40 agents per GPU, 240-beam lidar, respawn on" % E
     # host-side scene generation happens BEFORE the GPU / process group are touched (fork pool inside)
     t0 = time.time()
     from metadrive_ped_amd.engine import HostScene
@@ -84,7 +104,7 @@ def main():
 
     gen = torch.Generator(device="cpu")
     gen.manual_seed(rank)
-    n_act = 64
+    n_act = 64 if E * A <= 8192 else 16
     actions = (torch.rand(n_act, E, A, 2, generator=gen) * 2 - 1)
     actions[..., 1] = actions[..., 1].abs() * 0.9 + 0.1  # mostly forward, so that envs meet traffic and curves
     actions[..., 0] *= 0.25
@@ -115,7 +135,10 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    total_agent_steps = args.steps * E * A * world
+    # multi-agent: only slots holding a live agent count as agent-steps (dying / free slots do not)
+    sf = eng.shape_f.view(torch.int32)[:, :A, 6]
+    active_frac = float((((sf & 0x10) != 0) & ((sf & 0x80) == 0)).float().mean().item()) if A > 1 else 1.0
+    total_agent_steps = args.steps * E * A * world * active_frac
     value = total_agent_steps / elapsed
 
     # ---- per-launch duration of the fused step kernel with HIP events on the launch stream ----
@@ -178,7 +201,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "metadrive":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import numpy as np
         import oracle_binding as ob
@@ -202,12 +225,12 @@ def main():
 
     if rank == 0:
         line = OrderedDict(
-            metric="agent-steps/sec at 4096 envs x 240-beam lidar", value=round(value, 1), unit="agent-steps/s",
+            metric="agent-steps/sec at 4096 envs x 240-beam lidar" if args.workload == "metadrive" else
+            "agent-steps/sec (%s workload)" % args.workload, value=round(value, 1), unit="agent-steps/s",
             n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload="BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (Curve/Straight "
-                                 "blocks), 240-beam lidar, traffic_density=0.1, trigger traffic, auto-reset" % E,
-                        envs_per_gpu=E, agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
+            config=dict(workload=label,
+                        envs_per_gpu=E, active_agent_fraction=round(active_frac, 3), agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
             roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, with_gather=with_gather,
             host_build_s=round(build_s, 1))
         print(json.dumps(line))
