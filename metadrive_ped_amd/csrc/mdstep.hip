@@ -674,11 +674,16 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
     for (int i = tid; i < (nbytes >> 4); i += nthreads) d[i] = s[i];
 }
 
-template <int PH, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
-                                                    int lidar_stride, int lidar_offset) {
-    constexpr int kBlock = BLOCK;
-    constexpr int kWaves = BLOCK / 64;
+// STAGE_MAP: copy the env's lane + road tables into LDS (small maps: <= kStageMaxLanes lanes); big maps
+// (intersections, roundabouts: 100-200 lanes) are read through L1/L2 instead -- staging 30 KB per env per
+// step would cost more HBM traffic and LDS occupancy than it saves in latency.
+constexpr int kStageMaxLanes = 64;
+
+template <int PH, bool STAGE_MAP>
+__global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
+                                                  int lidar_stride, int lidar_offset) {
+    constexpr int kBlock = 256;
+    constexpr int kWaves = kBlock / 64;
     const int e = blockIdx.x;
     if (e >= c.n_envs) return;
     const int tid = threadIdx.x;
@@ -696,10 +701,11 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
     // static tables of this env's map + the movers' routes: read many times by the serial per-vehicle
     // logic, so they sit in LDS too (a dependent chain of HBM/L2 round trips otherwise)
     int32_t* l_rroads = reinterpret_cast<int32_t*>(l_flags + ((cap + 3) & ~3));
+    const int n_stage_lanes = STAGE_MAP ? w.max_lanes : 0, n_stage_roads = STAGE_MAP ? w.max_roads : 0;
     MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
-    MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + w.max_lanes);
-    float* l_scratch = reinterpret_cast<float*>(l_roads + w.max_roads) + wave * 48;  // per-wave observe results
-    MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + w.max_roads) + kWaves * 48);
+    MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + n_stage_lanes);
+    float* l_scratch = reinterpret_cast<float*>(l_roads + n_stage_roads) + wave * 48;  // per-wave observe results
+    MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + n_stage_roads) + kWaves * 48);
     int32_t* l_final = reinterpret_cast<int32_t*>(l_param + cap);
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
@@ -710,21 +716,23 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
 
     MD_STAMP_AT(0);
     copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
-#ifndef MD_NO_STAGE_MAP
-    const MdLane* lanes = l_lanes;
-    const MdRoad* roads = l_roads;
-#else
-    const MdLane* lanes = w.lanes + w.lane_off[w.env_map[e]];
-    const MdRoad* roads = w.roads + w.road_off[w.env_map[e]];
-#endif
+    const MdLane* lanes;
+    const MdRoad* roads;
+    if (STAGE_MAP) {
+        lanes = l_lanes;
+        roads = l_roads;
+    } else {
+        lanes = w.lanes + w.lane_off[w.env_map[e]];
+        roads = w.roads + w.road_off[w.env_map[e]];
+    }
     if (!kLidarOnly) {
-#ifndef MD_NO_STAGE_MAP
-        const int m = w.env_map[e];
-        const int lo = w.lane_off[m], ro = w.road_off[m];
-        copy16(l_lanes, w.lanes + lo, (w.lane_off[m + 1] - lo) * (int)sizeof(MdLane), tid, kBlock);
-        copy16(l_roads, w.roads + ro, (w.road_off[m + 1] - ro) * (int)sizeof(MdRoad), tid, kBlock);
+        if (STAGE_MAP) {
+            const int m = w.env_map[e];
+            const int lo = w.lane_off[m], ro = w.road_off[m];
+            copy16(l_lanes, w.lanes + lo, (w.lane_off[m + 1] - lo) * (int)sizeof(MdLane), tid, kBlock);
+            copy16(l_roads, w.roads + ro, (w.road_off[m + 1] - ro) * (int)sizeof(MdRoad), tid, kBlock);
+        }
         copy16(l_rroads, gv.route_roads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
-#endif
         copy16(l_dyn, gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         copy16(l_nav, gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
         copy16(l_pid, gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
@@ -752,11 +760,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         if (c.is_multi_agent) {  // respawns rewrote the routes: restore them too
             for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
                 gv.route_nodes[i] = gv.route_nodes0[i];
-#ifndef MD_NO_STAGE_MAP
                 l_rroads[i] = gv.route_roads0[i];
-#else
-                gv.route_roads[i] = gv.route_roads0[i];
-#endif
             }
             for (int j = tid; j < cap; j += kBlock) {
                 l_final[j] = gv.final_lane0[j];
@@ -778,9 +782,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         s.flags = l_flags;
         s.param = l_param;
         s.final_lane = l_final;
-#ifndef MD_NO_STAGE_MAP
         s.route_roads = l_rroads;
-#endif
     }
     __syncthreads();
     MD_STAMP_AT(1);
@@ -842,9 +844,7 @@ __global__ __launch_bounds__(BLOCK) void env_kernel(MdWorld w, MdState g, MdConf
         if (PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
         if (PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
-#ifndef MD_NO_STAGE_MAP
         if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent) copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
-#endif
         if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent)
             for (int j = tid; j < cap; j += kBlock) gv.final_lane[j] = l_final[j];
         for (int j = tid; j < cap; j += kBlock) {
@@ -902,28 +902,22 @@ int need(const void* p, const char* name) {
 template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
+    const bool stage = w->max_lanes <= kStageMaxLanes;
     const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
-                       (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) + 4 * 48 * 4 +
-                       (size_t)c->cap * (sizeof(MdParam) + 4) + 16;
+                       (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
+                       4 * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16;
     if (lds > 64 * 1024 || w->max_lanes <= 0 || w->max_roads <= 0) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
         return MD_EINVAL;
     }
-    static const int block = [] {
-        const char* v = getenv("MD_BLOCK");  // tuning knob: threads per env workgroup (64 / 128 / 256)
-        const int b = v ? atoi(v) : 256;
-        return (b == 64 || b == 128 || b == 256) ? b : 256;
-    }();
     const dim3 grid(c->n_envs);
     const hipStream_t st = (hipStream_t)stream;
-    if (block == 64)
-        hipLaunchKernelGGL((env_kernel<PH, 64>), grid, dim3(64), lds, st, *w, *s, *c, lidar_out, stride, offset);
-    else if (block == 128)
-        hipLaunchKernelGGL((env_kernel<PH, 128>), grid, dim3(128), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    if (stage)
+        hipLaunchKernelGGL((env_kernel<PH, true>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
     else
-        hipLaunchKernelGGL((env_kernel<PH, 256>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+        hipLaunchKernelGGL((env_kernel<PH, false>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));

@@ -77,7 +77,8 @@ def is_negative_road(end_node):
 
 
 class RoadNet:
-    """graph[from][to] -> [lanes], insertion-ordered like the reference's dict-of-dicts."""
+    """graph[from][to] -> [lanes], insertion-ordered like the reference's dict-of-dicts
+    (component/road_network/node_road_network.py:68-134)."""
     def __init__(self):
         self.graph = OrderedDict()
 
@@ -87,18 +88,62 @@ class RoadNet:
     def lanes(self, a, b):
         return self.graph[a][b]
 
+    def decoration_lanes(self):
+        return self.graph[DECORATION[0]][DECORATION[1]] if DECORATION[0] in self.graph else []
+
     def merge(self, other):
+        """NodeRoadNetwork.add: dict.update replaces whole `from` entries; decoration lanes are concatenated."""
+        dec = self.decoration_lanes() + other.decoration_lanes()
         for a, tos in other.graph.items():
-            self.graph[a] = tos  # whole `from` entry replaced, as dict.update does (node_road_network.py:100)
+            self.graph[a] = tos
+        if dec:
+            self.graph.pop(DECORATION[0], None)
+            self.graph[DECORATION[0]] = OrderedDict([(DECORATION[1], dec)])
 
     def remove(self, other):
+        """NodeRoadNetwork.__isub__"""
         for a in list(other.graph.keys()):
+            if a in DECORATION:
+                continue
             self.graph.pop(a, None)
+        if DECORATION[0] in other.graph and DECORATION[0] in self.graph:
+            mine = self.graph[DECORATION[0]][DECORATION[1]]
+            for lane in other.decoration_lanes():
+                if lane in mine:
+                    mine.remove(lane)
 
     def roads(self):
         for a, tos in self.graph.items():
             for b, lanes in tos.items():
                 yield a, b, lanes
+
+    def all_paths(self, start, goal):
+        """bfs_paths (node_road_network.py:242-259): every simple path start -> goal."""
+        out = []
+        queue = [(start, [start])]
+        while queue:
+            node, path = queue.pop(0)
+            if node not in self.graph:
+                continue
+            for nxt in self.graph[node].keys():
+                if nxt in path:
+                    continue
+                if nxt == goal:
+                    out.append(path + [nxt])
+                elif nxt in self.graph:
+                    queue.append((nxt, path + [nxt]))
+        return out
+
+    def remove_all_roads(self, start, end):
+        """remove_all_roads (node_road_network.py:172-192)"""
+        removed = []
+        for path in self.all_paths(start, end):
+            for i, node in enumerate(path[:-1]):
+                if node in self.graph and path[i + 1] in self.graph[node]:
+                    removed += self.graph[node].pop(path[i + 1])
+                    if len(self.graph[node]) == 0:
+                        self.graph.pop(node)
+        return removed
 
 
 # ---------------------------------------------------------------------------------------------
@@ -149,34 +194,54 @@ def lane_crosses_network(net, lane, positive, ignore_intersection_checking=False
 # ---------------------------------------------------------------------------------------------
 # road builders (create_pg_block_utils.py:50-281)
 # ---------------------------------------------------------------------------------------------
-def create_road_from(lane, lane_num, road, block_net, global_net, ignore_check=False):
-    """`lane` is the RIGHT-most lane of the new road; build the lane_num-1 lanes to its left."""
+def create_road_from(lane, lane_num, road, block_net, global_net, ignore_check=False, toward_smaller=True,
+                     center_line_type=None, side_lane_line_type=None, inner_lane_line_type=None, center_line_color=None):
+    """CreateRoadFrom (pgblock/create_pg_block_utils.py:50-175).  With toward_smaller (default) `lane` is the
+    RIGHT-most lane and the others are built to its left; otherwise `lane` is the LEFT-most one."""
+    center = center_line_type or LINE_CONTINUOUS
+    side_t = side_lane_line_type or LINE_SIDE
+    inner = inner_lane_line_type or LINE_BROKEN
+    color = center_line_color or COLOR_YELLOW
     a, b = road
     width = lane.width
+    n_extra = lane_num - 1
     made = []
     cur = lane
-    for i in range(lane_num - 1, 0, -1):
+    for i in range(n_extra, 0, -1):
         if isinstance(cur, StraightLane):
-            side = cur.shifted(-width)
+            side = cur.shifted(-width if toward_smaller else width)
         else:
-            side = cur.with_radius(cur.radius + width if cur.clockwise else cur.radius - width)
-        side.line_types = [LINE_CONTINUOUS, LINE_BROKEN] if i == 1 else [LINE_BROKEN, LINE_BROKEN]
+            if not toward_smaller:
+                r2 = cur.radius - width if cur.clockwise else cur.radius + width
+            else:
+                r2 = cur.radius + width if cur.clockwise else cur.radius - width
+            side = cur.with_radius(r2)
+        if i == 1:
+            side.line_types = [center, inner] if toward_smaller else [inner, side_t]
+        else:
+            side.line_types = [inner, inner]
         made.append(side)
         cur = side
-    made.reverse()
-    made.append(lane)
-    lane.line_types = [LINE_BROKEN if len(made) > 1 else LINE_CONTINUOUS, LINE_SIDE]
+    if toward_smaller:
+        made.reverse()
+        made.append(lane)
+        lane.line_types = [inner if len(made) > 1 else center, side_t]
+    else:
+        made.insert(0, lane)
+        if len(made) > 1:
+            lane.line_types = [lane.line_types[0], made[-1].line_types[0]]
     factor = (SIDEWALK_WIDTH + SIDEWALK_LINE_DIST + width / 2.0) * 2.0 / width
     no_cross = not lane_crosses_network(global_net, lane, factor, ignore_check)
     for l in made:
         block_net.add_lane(a, b, l)
-    if lane_num == 1:
-        made[-1].line_types = [LINE_CONTINUOUS, LINE_SIDE]
-    made[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
+    if n_extra == 0:
+        made[-1].line_types = [center, side_t]
+    made[0].line_colors = [color, COLOR_GREY]
     return no_cross
 
 
 def create_adverse_road(road, block_net, global_net, ignore_check=False):
+    """CreateAdverseRoad (create_pg_block_utils.py:202-281)"""
     a, b = road
     lanes = block_net.lanes(a, b)
     ref = lanes[-1]
@@ -248,6 +313,11 @@ class Block:
         if s.index is None:
             s.index = "{}-socket{}".format(self.name, len(self.sockets))
         self.sockets[s.index] = s
+
+    def get_socket(self, index):
+        """Called by the BIG search when the next block plugs into this socket; intersections / roundabouts
+        drop the socket's incoming road from their respawn roads (intersection.py:150-154, roundabout.py:181-185)."""
+        return self.sockets[index]
 
     def construct(self):
         """construct_block: resample parameters, rebuild the topology, merge into the global net."""
@@ -416,11 +486,310 @@ class Roundabout(Block):
                 lane.line_types = [LINE_BROKEN, LINE_BROKEN]
         return exit_road, ok
 
+    def get_socket(self, index):
+        s = self.sockets[index]
+        if s.negative in self.respawn_roads:
+            self.respawn_roads.remove(s.negative)
+        return s
+
     def intermediate_spawn_lanes(self):
         return [self.net.lanes(*r) for r in self.respawn_roads] + self.intermediate_spawn_places
 
 
-BLOCK_CLASSES = {"Straight": Straight, "Curve": Curve, "Roundabout": Roundabout}
+class InterSection(Block):
+    """4-way intersection (pgblock/intersection.py:16-258): for each of the four arms a left-turn arc, the
+    straight-through lanes, a right-turn arc and (for three arms) an exit road with its adverse road."""
+    ID = "X"
+    SPACE = BlockParameterSpace.INTERSECTION
+    EXIT_PART_LENGTH = 35
+    EXTRA_PART = "extra"
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.radius = self.config["radius"]
+
+    def road_node(self, part, idx):
+        return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
+
+    def get_socket(self, index):
+        s = self.sockets[index]
+        if s.negative in self.respawn_roads:
+            self.respawn_roads.remove(s.negative)
+        return s
+
+    def plug(self):
+        from collections import deque
+        p = self.config
+        self.lane_width = self.basic_lane.width
+        dec_inc = -1 if p["decrease_increase"] == 0 else 1
+        if self.lane_num <= 1:
+            dec_inc = 1
+        elif self.lane_num >= 4:
+            dec_inc = -1
+        self.lane_num_intersect = self.lane_num + dec_inc * p["change_lane_num"]
+        ok = True
+        attach_road = self.pre_socket.positive
+        attach_lanes = self.global_net.lanes(*attach_road)
+        nodes = deque([self.road_node(0, 0), self.road_node(1, 0), self.road_node(2, 0), self.pre_socket.negative[0]])
+        for i in range(4):
+            right_lane, success = self._create_part(attach_lanes, attach_road, self.radius, nodes, i)
+            ok = ok and success
+            if i != 3:
+                lane_num = self.lane_num if i == 1 else self.lane_num_intersect
+                exit_road = (self.road_node(i, 0), self.road_node(i, 1))
+                ok = create_road_from(right_lane, lane_num, exit_road, self.net, self.global_net) and ok
+                ok = create_adverse_road(exit_road, self.net, self.global_net) and ok
+                sock = Socket(exit_road, negate_road(*exit_road))
+                self.respawn_roads.append(sock.negative)
+                self.add_socket(sock)
+                attach_road = negate_road(*exit_road)
+                attach_lanes = self.net.lanes(*attach_road)
+        return ok
+
+    def _create_part(self, attach_lanes, attach_road, radius, nodes, part_idx):
+        lane_num = self.lane_num_intersect if part_idx in (0, 2) else self.lane_num
+        ok = True
+        left = attach_lanes[0]
+        self._left_turn(radius, lane_num, left, attach_road, nodes, part_idx)
+        lanes_on_road = list(attach_lanes)
+        straight_len = 2 * radius + (2 * lane_num - 1) * lanes_on_road[0].width
+        for l in lanes_on_road:
+            self.net.add_lane(attach_road[1], nodes[1], l.extended(straight_len, (LINE_NONE, LINE_NONE)))
+        right_turn = lanes_on_road[-1]
+        right_bend, right_straight = bend_then_straight(right_turn, self.EXIT_PART_LENGTH, radius, np.deg2rad(90), True,
+                                                        right_turn.width, (LINE_NONE, LINE_SIDE))
+        ok = (not lane_crosses_network(self.global_net, right_bend, 1)) and ok
+        create_road_from(right_bend, min(self.lane_num, self.lane_num_intersect), (attach_road[1], nodes[0]), self.net,
+                         self.global_net, toward_smaller=True, side_lane_line_type=LINE_SIDE, inner_lane_line_type=LINE_NONE,
+                         center_line_type=LINE_NONE)
+        nodes.rotate(-1)
+        right_straight.line_types = [LINE_BROKEN, LINE_SIDE]
+        return right_straight, ok
+
+    def _left_turn(self, radius, lane_num, left, attach_road, nodes, part_idx):
+        left_radius = radius + lane_num * left.width
+        diff = self.lane_num_intersect - self.lane_num
+        n = min(self.lane_num, self.lane_num_intersect)
+        kw = dict(toward_smaller=False, center_line_type=LINE_NONE, side_lane_line_type=LINE_NONE, inner_lane_line_type=LINE_NONE)
+        if (part_idx in (1, 3) and diff > 0) or (part_idx in (0, 2) and diff < 0):
+            diff = abs(diff)
+            bend, extra = bend_then_straight(left, self.lane_width * diff, left_radius, np.deg2rad(90), False, left.width,
+                                             (LINE_NONE, LINE_NONE))
+            start = nodes[2]
+            pre = start + self.EXTRA_PART
+            create_road_from(bend, n, (attach_road[1], pre), self.net, self.global_net, **kw)
+            create_road_from(extra, n, (pre, start), self.net, self.global_net, **kw)
+        else:
+            bend, _ = bend_then_straight(left, self.EXIT_PART_LENGTH, left_radius, np.deg2rad(90), False, left.width,
+                                         (LINE_NONE, LINE_NONE))
+            create_road_from(bend, n, (attach_road[1], nodes[2]), self.net, self.global_net, **kw)
+
+    def intermediate_spawn_lanes(self):
+        return [self.net.lanes(*r) for r in self.respawn_roads]
+
+
+class TInterSection(InterSection):
+    """3-way intersection: an X intersection with one arm removed (pgblock/t_intersection.py:8-118)."""
+    ID = "T"
+    SPACE = BlockParameterSpace.T_INTERSECTION
+
+    def plug(self):
+        ok = super().plug()
+        self._exclude_lanes()
+        return ok
+
+    def _exclude_lanes(self):
+        t_type = self.config["t_type"]
+        pre = self.pre_socket
+        self.sockets[pre.index] = pre  # add_sockets(self.pre_block_socket)
+        key = "{}-socket{}".format(self.name, t_type)
+        start_node = self.sockets[key].negative[1]
+        end_node = self.sockets[key].positive[0]
+        for i in range(4):
+            if i == t_type:
+                continue
+            idx = "{}-socket{}".format(self.name, i) if i < 3 else pre.index
+            sk = self.sockets[idx]
+            exit_node = sk.positive[0] if i != 3 else sk.negative[0]
+            self.net.remove_all_roads(start_node, exit_node)
+            entry_node = sk.negative[1] if i != 3 else sk.positive[1]
+            self.net.remove_all_roads(entry_node, end_node)
+        self._change_vis(t_type)
+        self.sockets.pop(pre.index)
+        sock = self.sockets.pop(key)
+        self.net.remove_all_roads(*sock.positive)
+        self.net.remove_all_roads(*sock.negative)
+        self.respawn_roads.remove(sock.negative)
+
+    def _change_vis(self, t_type):
+        socks = list(self.sockets.values())
+        nxt = socks[(t_type + 1) % 4]
+        next_pos, next_neg = nxt.positive, nxt.negative
+        last = socks[(t_type + 3) % 4]
+        last_pos, last_neg = last.positive, last.negative
+        if t_type == 2:   # Goal.LEFT
+            next_pos, next_neg = nxt.negative, nxt.positive
+        if t_type == 0:   # Goal.RIGHT
+            last_pos, last_neg = last.negative, last.positive
+        for i, road in enumerate([(last_neg[1], next_pos[0]), (next_neg[1], last_pos[0])]):
+            lanes = self.net.lanes(*road)
+            outside = LINE_SIDE if i == 0 else LINE_NONE
+            for k, lane in enumerate(lanes):
+                lane.line_types = [LINE_NONE, LINE_NONE] if k != len(lanes) - 1 else [LINE_NONE, outside]
+                if k == 0:
+                    lane.line_colors = [COLOR_YELLOW, COLOR_GREY]
+                    if i == 1:
+                        lane.line_types[0] = LINE_NONE
+
+
+class _Ramp(Block):
+    SPACE = BlockParameterSpace.RAMP_PARAMETER
+    RADIUS, ANGLE, CONNECT_PART_LEN, RAMP_LEN = 40, 10, 20, 15
+    LANE_TYPE = (LINE_CONTINUOUS, LINE_CONTINUOUS)
+
+    def _check(self, lane):
+        return not lane_crosses_network(self.global_net, lane, 0.95)
+
+    def set_part(self, x):
+        self._part, self._road = x, 0
+
+    def road_node(self, part, idx):
+        return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
+
+
+class InRampOnStraight(_Ramp):
+    """Merging ramp (pgblock/ramp.py:38-224)."""
+    ID = "r"
+    EXTRA_PART, SOCKET_LEN = 10, 20
+
+    def plug(self):
+        acc_len = self.config["length"]
+        self.lane_width = w = self.basic_lane.width
+        n = self.lane_num
+        ok = True
+        self.set_part(0)
+        sin_a, cos_a = math.sin(np.deg2rad(self.ANGLE)), math.cos(np.deg2rad(self.ANGLE))
+        longitude_len = sin_a * self.RADIUS * 2 + cos_a * self.CONNECT_PART_LEN + self.RAMP_LEN
+        extend_lane = self.basic_lane.extended(longitude_len + self.EXTRA_PART, [LINE_BROKEN, LINE_CONTINUOUS])
+        extend_road = (self.pre_socket.positive[1], self.node())
+        ok = create_road_from(extend_lane, n, extend_road, self.net, self.global_net, side_lane_line_type=LINE_CONTINUOUS) and ok
+        self.net.lanes(*extend_road)[-1].line_types = [LINE_BROKEN if n != 1 else LINE_CONTINUOUS, LINE_CONTINUOUS]
+        ok = create_adverse_road(extend_road, self.net, self.global_net) and ok
+        self.net.lanes(*negate_road(*extend_road))[-1].line_types = [LINE_NONE if n == 1 else LINE_BROKEN, LINE_SIDE]
+        acc_side = extend_lane.extended(acc_len + w, [extend_lane.line_types[0], LINE_SIDE])
+        acc_road = (extend_road[1], self.node())
+        ok = create_road_from(acc_side, n, acc_road, self.net, self.global_net, side_lane_line_type=LINE_CONTINUOUS) and ok
+        ok = create_adverse_road(acc_road, self.net, self.global_net) and ok
+        self.net.lanes(*acc_road)[-1].line_types = [LINE_CONTINUOUS if n == 1 else LINE_BROKEN, LINE_BROKEN]
+        socket_side = acc_side.extended(self.SOCKET_LEN, acc_side.line_types)
+        socket_road = (acc_road[1], self.node())
+        ok = create_road_from(socket_side, n, socket_road, self.net, self.global_net, side_lane_line_type=LINE_CONTINUOUS) and ok
+        ok = create_adverse_road(socket_road, self.net, self.global_net) and ok
+        self.add_socket(Socket(socket_road, negate_road(*socket_road)))
+        # ramp part
+        self.set_part(1)
+        lateral = (1 - cos_a) * self.RADIUS * 2 + sin_a * self.CONNECT_PART_LEN
+        end_pt = extend_lane.position(self.EXTRA_PART + self.RAMP_LEN, lateral + w)
+        start_pt = extend_lane.position(self.EXTRA_PART, lateral + w)
+        straight = StraightLane(start_pt, end_pt, w, self.LANE_TYPE)
+        straight_road = (self.node(), self.node())
+        self.net.add_lane(straight_road[0], straight_road[1], straight)
+        ok = self._check(straight) and ok
+        self.respawn_roads.append(straight_road)
+        bend_1, connect = bend_then_straight(straight, self.CONNECT_PART_LEN, self.RADIUS, np.deg2rad(self.ANGLE), False, w,
+                                             self.LANE_TYPE)
+        bend_1_road = (straight_road[1], self.node())
+        connect_road = (bend_1_road[1], self.node())
+        self.net.add_lane(bend_1_road[0], bend_1_road[1], bend_1)
+        self.net.add_lane(connect_road[0], connect_road[1], connect)
+        ok = self._check(bend_1) and ok
+        ok = self._check(connect) and ok
+        bend_2, acc_lane = bend_then_straight(connect, acc_len, self.RADIUS, np.deg2rad(self.ANGLE), True, w, self.LANE_TYPE)
+        acc_lane.line_types = [LINE_BROKEN, LINE_CONTINUOUS]
+        bend_2_road = (connect_road[1], self.road_node(0, 0))
+        self.net.add_lane(bend_2_road[0], bend_2_road[1], bend_2)
+        self.net.add_lane(acc_road[0], acc_road[1], acc_lane)
+        ok = self._check(bend_2) and ok
+        ok = self._check(acc_lane) and ok
+        merge, _ = bend_then_straight(acc_lane, 10, w / 2, np.pi / 2, False, w, (LINE_BROKEN, LINE_CONTINUOUS))
+        self.net.add_lane(DECORATION[0], DECORATION[1], merge)
+        return ok
+
+    def intermediate_spawn_lanes(self):
+        spawn = super().intermediate_spawn_lanes()
+        on_socket = self.net.lanes(*list(self.sockets.values())[0].positive)[0]
+        return [lanes for lanes in spawn if on_socket not in lanes]
+
+
+class OutRampOnStraight(_Ramp):
+    """Diverging ramp (pgblock/ramp.py:227-385)."""
+    ID = "R"
+    EXTRA_LEN = 15
+
+    def plug(self):
+        self.lane_width = w = self.basic_lane.width
+        n = self.lane_num
+        ok = True
+        sin_a, cos_a = math.sin(np.deg2rad(self.ANGLE)), math.cos(np.deg2rad(self.ANGLE))
+        longitude_len = sin_a * self.RADIUS * 2 + cos_a * self.CONNECT_PART_LEN + self.RAMP_LEN + self.EXTRA_LEN
+        self.set_part(0)
+        dec_len = self.config["length"]
+        dec_lane = self.basic_lane.extended(dec_len + w, [self.basic_lane.line_types[0], LINE_SIDE])
+        dec_road = (self.pre_socket.positive[1], self.node())
+        ok = create_road_from(dec_lane, n, dec_road, self.net, self.global_net, side_lane_line_type=LINE_CONTINUOUS) and ok
+        ok = create_adverse_road(dec_road, self.net, self.global_net) and ok
+        dec_right = self.net.lanes(*dec_road)[-1]
+        dec_right.line_types = [LINE_CONTINUOUS if n == 1 else LINE_BROKEN, LINE_BROKEN]
+        extend_lane = dec_right.extended(longitude_len, [dec_right.line_types[0], LINE_CONTINUOUS])
+        extend_road = (dec_road[1], self.node())
+        ok = create_road_from(extend_lane, n, extend_road, self.net, self.global_net, side_lane_line_type=LINE_CONTINUOUS) and ok
+        ok = create_adverse_road(extend_road, self.net, self.global_net) and ok
+        self.net.lanes(*negate_road(*extend_road))[-1].line_types = [LINE_NONE if n == 1 else LINE_BROKEN, LINE_SIDE]
+        self.add_socket(Socket(extend_road, negate_road(*extend_road)))
+        self.set_part(1)
+        dec_side = StraightLane(dec_right.position(w, w), dec_right.position(dec_right.length, w), w,
+                                (LINE_BROKEN, LINE_CONTINUOUS))
+        self.net.add_lane(dec_road[0], dec_road[1], dec_side)
+        ok = self._check(dec_side) and ok
+        bend_1, connect = bend_then_straight(dec_side, self.CONNECT_PART_LEN, self.RADIUS, np.deg2rad(self.ANGLE), True, w,
+                                             self.LANE_TYPE)
+        bend_1_road = (dec_road[1], self.node())
+        connect_road = (bend_1_road[1], self.node())
+        self.net.add_lane(bend_1_road[0], bend_1_road[1], bend_1)
+        self.net.add_lane(connect_road[0], connect_road[1], connect)
+        ok = self._check(bend_1) and ok
+        ok = self._check(connect) and ok
+        bend_2, straight = bend_then_straight(connect, self.RAMP_LEN, self.RADIUS, np.deg2rad(self.ANGLE), False, w,
+                                              self.LANE_TYPE)
+        bend_2_road = (connect_road[1], self.node())
+        straight_road = (bend_2_road[1], self.node())
+        self.net.add_lane(bend_2_road[0], bend_2_road[1], bend_2)
+        self.net.add_lane(straight_road[0], straight_road[1], straight)
+        ok = self._check(bend_2) and ok
+        ok = self._check(straight) and ok
+        tool = StraightLane(dec_side.end, dec_side.start, dec_side.width)
+        merge, _ = bend_then_straight(tool, 10, w / 2, np.pi / 2, True, w, (LINE_CONTINUOUS, LINE_BROKEN))
+        self.net.add_lane(DECORATION[0], DECORATION[1], merge)
+        return ok
+
+
+class StdInterSection(InterSection):
+    """pgblock/std_intersection.py: the lane count never changes across the intersection"""
+    def plug(self):
+        self.config["change_lane_num"] = 0
+        return super().plug()
+
+
+class StdTInterSection(TInterSection):
+    """pgblock/std_t_intersection.py"""
+    def plug(self):
+        self.config["change_lane_num"] = 0
+        return super().plug()
+
+
+BLOCK_CLASSES = {"Straight": Straight, "Curve": Curve, "Roundabout": Roundabout, "StdInterSection": StdInterSection,
+                 "StdTInterSection": StdTInterSection, "InRampOnStraight": InRampOnStraight,
+                 "OutRampOnStraight": OutRampOnStraight}
 
 
 class MARoundaboutMap:
@@ -484,7 +853,7 @@ class PGMap:
                 "PG block type '{}' (id '{}') is not built yet in metadrive_ped_amd.mapgen; restrict "
                 "`block_dist_config` or pass a block sequence made of {}".format(
                     name, BLOCK_ID.get(name), sorted(BLOCK_ID[k] for k in BLOCK_CLASSES)))
-        return BLOCK_CLASSES[name](len(self.blocks), last.sockets[socket_id], self.net, seed)
+        return BLOCK_CLASSES[name](len(self.blocks), last.get_socket(socket_id), self.net, seed)
 
     def _construct(self, block):
         ok = block.construct()

@@ -136,8 +136,8 @@ class MapTables:
             for a, b, _ in blk.net.roads():
                 block_of_road[(a, b)] = bi
         for a, b, lanes in net.roads():
-            if (a, b) == DECORATION:
-                continue
+            # decoration lanes (ramp merge tapers) are real lane bodies in the reference too
+            # (pgblock/pg_block.py:248-257 walks the whole graph), they just never appear on a route
             rid = len(roads)
             self.road_id[(a, b)] = rid
             roads.append((len(lanes_flat), len(lanes), node_id(a), node_id(b), int(is_negative_road(b)),
@@ -202,8 +202,6 @@ class MapTables:
         # --- static quads (pgblock/pg_block.py:248-257: left+right on lane 0 of positive roads, else right only) ---
         quads, kinds = [], []
         for a, b, lanes in net.roads():
-            if (a, b) == DECORATION:
-                continue
             pos = not is_negative_road(b)
             for i, l in enumerate(lanes):
                 q, kd = lane_line_quads(l, (True, True) if (i == 0 and pos) else (False, True))

@@ -56,6 +56,18 @@ class Parameter:
 
 class BlockParameterSpace:
     """pg_space.py:275-326 (subset built so far)"""
+    INTERSECTION = {
+        "radius": ConstantSpace(10),
+        "change_lane_num": DiscreteSpace(min=0, max=1),
+        "decrease_increase": DiscreteSpace(min=0, max=1),
+    }
+    T_INTERSECTION = {
+        "radius": ConstantSpace(10),
+        "t_type": DiscreteSpace(min=0, max=2),
+        "change_lane_num": DiscreteSpace(min=0, max=1),
+        "decrease_increase": DiscreteSpace(min=0, max=1),
+    }
+    RAMP_PARAMETER = {"length": BoxSpace(min=20, max=40)}
     ROUNDABOUT = {
         "exit_radius": BoxSpace(min=5, max=15),
         "inner_radius": BoxSpace(min=15, max=45),

@@ -31,6 +31,12 @@ import seaborn  # noqa: E402  (placeholder)
 # the value is cosmetic and drawn from an UNSEEDED RandomState, it never touches a seeded stream.
 seaborn.color_palette = lambda *a, **k: [(i / 10., i / 10., i / 10.) for i in range(10)]
 
+# BIG backtracking destroys blocks; their destroy() walks Panda3D scene-graph nodes (placeholders here) and
+# raises on anything that is not a real NodePath.  It is pure scene-graph cleanup: make it a no-op.
+import metadrive.base_class.base_object as _bo  # noqa: E402
+
+_bo.clear_node_list = lambda node_path_list: node_path_list.clear() if hasattr(node_path_list, "clear") else None
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -493,7 +499,39 @@ def section_idm():
     dump("idm.json", out)
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm)
+def section_pg_maps_v2():
+    """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
+    straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
+    from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
+    cases = []
+    specs = [(seed, 3, 3.5, 50, "block_num", 3) for seed in range(0, 24)]
+    specs += [(200 + seed, 2, 3.0, 50, "block_num", 5) for seed in range(0, 4)]
+    specs += [(300, 3, 3.5, 50, "block_sequence", "XTO"), (301, 3, 3.5, 50, "block_sequence", "rRX"),
+              (302, 2, 3.5, 50, "block_sequence", "TXT")]
+    for seed, lane_num, lane_width, exit_length, method, parameter in specs:
+        big, net = build_reference_map(seed, lane_num, lane_width, exit_length, method, parameter, PGBlockDistConfig)
+        for f, td in net.graph.items():
+            for t, lanes in td.items():
+                for i, l in enumerate(lanes):
+                    l.index = (f, t, i)
+        roads = []
+        for f, td in net.graph.items():
+            for t, lanes in td.items():
+                roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+        blocks = [dict(name=b.name, config={k: float(v) for k, v in dict(b.get_config()).items()},
+                       trials=int(b.number_of_sample_trial),
+                       sockets=[[s.positive_road.start_node, s.positive_road.end_node] for s in b.get_socket_list()],
+                       respawn_roads=[[r.start_node, r.end_node] for r in b.get_respawn_roads()])
+                  for b in big.blocks]
+        spawn = []
+        for b in big.blocks[1:]:
+            spawn.append([[list(l.index) for l in lanes] for lanes in b.get_intermediate_spawn_lanes()])
+        cases.append(dict(seed=seed, lane_num=lane_num, lane_width=lane_width, exit_length=exit_length,
+                          method=method, parameter=parameter, blocks=blocks, roads=roads, spawn_lanes=spawn))
+    dump("pg_maps_v2.json", dict(cases=cases))
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

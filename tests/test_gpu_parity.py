@@ -124,3 +124,28 @@ def test_side_and_lane_line_detectors_in_obs(cs_dist):
     assert (side < 1.0).any() and (side >= 0).all()           # the road border is within 50 m of a car on the road
     ll = st["obs"][:, 18:24]
     assert (ll < 1.0).any()
+
+
+def test_default_distribution_maps_rollout_parity():
+    """The reference's default config (map=3, BLOCK_TYPE_DISTRIBUTION_V2: ramps, intersections, roundabouts):
+    big lane tables take the non-staged kernel variant."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    E = 64
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, horizon=250))
+    eng = BatchedEngine(cfg)
+    assert eng.w.max_lanes > 64
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="v2 reset")
+    for t in range(300):
+        a = scripted_actions(E, 1, t, seed=21)
+        a[:, :, 0] *= 0.4
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="v2 step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="v2 final")

@@ -24,10 +24,16 @@ def test_config_contract(cs_dist):
 
 
 def test_unbuilt_block_type_fails_loudly():
-    from metadrive_ped_amd.mapgen.pg import PGMap
+    """Every block type of the default distribution is built; the zero-probability ones (forks, merge/split,
+    parking lot, toll gate, bidirection) are not and say so instead of silently changing the map."""
+    from collections import OrderedDict
+    from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2, BlockDist, PGMap
+    for seed in range(10):
+        PGMap(seed)
+    d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
+    d["Merge"] = 1.0
     with pytest.raises(NotImplementedError, match="not built yet"):
-        for seed in range(20):  # default V2 distribution samples ramps/intersections/roundabout
-            PGMap(seed)
+        PGMap(0, block_dist=BlockDist(d))
 
 
 def test_spaces_and_env_surface():
