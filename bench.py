@@ -6,8 +6,8 @@
 A "step" is one env.step() of the whole batch: ONE md_step launch that advances every env by 0.1 s
 of simulated time (IDM traffic -> kinematic integration -> lane localisation -> contacts -> obs /
 reward / done -> 240-beam lidar), with auto-reset of finished envs inside the same launch.
-Workload at N=1 is BASELINE.json configs[1]: 4096 batched MetaDriveEnv, 3-block PG map (block types
-built so far: Curve / Straight), 240-beam lidar, traffic_density 0.1, one env per scenario seed.
+Workload at N=1 is BASELINE.json configs[1]: 4096 batched MetaDriveEnv, 3-block PG map drawn from the
+reference's default block distribution, 240-beam lidar, traffic_density 0.1, one env per scenario seed.
 For N>1 every rank owns 4096 envs of the global batch (weak scaling, no data-path collective: envs
 are independent worlds); rank 0 prints ONE JSON line.  Inputs (state, maps, actions) are resident in
 HBM when the timed region starts.
@@ -72,16 +72,16 @@ def main():
     common = dict(num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0,
                   mover_capacity=args.cap, auto_reset=True, device="cuda:%d" % local_rank)
     if args.workload == "metadrive":
-        cfg = make_config(dict(common, map=3, block_dist_config=cs_dist(), traffic_density=0.1, horizon=1000))
-        label = ("BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (Curve/Straight blocks), 240-beam "
-                 "lidar, traffic_density=0.1, trigger traffic, auto-reset" % E)
+        cfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=1000))
+        label = ("BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (reference default block "
+                 "distribution: curves, straights, ramps, X/T intersections, roundabouts), 240-beam lidar, "
+                 "traffic_density=0.1, trigger traffic, auto-reset" % E)
     elif args.workload == "safe":
         if args.envs == 4096:
             E = common["num_envs"] = 8192
             common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
         from metadrive_ped_amd.envs.metadrive_env import BatchedSafeMetaDriveEnv
-        cfg = make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, block_dist_config=cs_dist(),
-                                                                              horizon=1000)))
+        cfg = make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, horizon=1000)))
         label = "BASELINE configs[3] shard: %d SafeMetaDriveEnv per GPU (accident_prob 0.8, density 0.05), 240 beams" % E
     else:
         if args.envs == 4096:
@@ -160,8 +160,18 @@ def main():
     # whole step per agent ~ 2.6 KB + 136 B * T/A  (state R/W, action, navi/route, obs, flags)
     bytes_step = (2600.0 + 136.0 * T / A) * E * A
     achieved = bytes_step / (step_ms_avg * 1e-3) / 1e9
-    roofline = dict(bound="hbm", kernel="env_kernel<255> (fused md_step)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+    # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh; counters cannot be read
+    # from inside this process), same workload only
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("workload") == args.workload and E == 4096:
+            traffic, traffic_src = pmc["bytes_per_launch"].get("env_kernel<511>"), "profiles/" + pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+    roofline = dict(bound="hbm", kernel="env_kernel<511> (fused md_step)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     bytes_per_launch=int(bytes_step), avg_launch_us=round(step_ms_avg * 1e3, 2),
                     movers_per_env=round(M, 2))
 

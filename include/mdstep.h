@@ -43,7 +43,7 @@ extern "C" {
 /* ---- limits ------------------------------------------------------------------------------ */
 #define MD_MAX_CAP 128        /* mover slots per env the kernels are built for                  */
 #define MD_MAX_BEAMS 1024     /* lidar beams per agent                                          */
-#define MD_ROUTE_LEN 24       /* checkpoints (road nodes) per route                             */
+#define MD_ROUTE_LEN 48       /* checkpoints (road nodes) per route                             */
 #define MD_IDM_RAND 8         /* pre-drawn lane-change timer values per traffic vehicle         */
 
 /* ---- mover kinds (MdShape.flags bits 0..3) ------------------------------------------------ */

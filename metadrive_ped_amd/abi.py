@@ -13,7 +13,7 @@ MD_ABI_VERSION = 1
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
-MD_ROUTE_LEN = 24
+MD_ROUTE_LEN = 48
 MD_IDM_RAND = 8
 
 # mover kinds / flags

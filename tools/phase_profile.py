@@ -24,7 +24,7 @@ def main():
     d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
     d["Curve"], d["Straight"] = 0.6, 0.4
     E = args.envs
-    cfg = make_config(dict(num_envs=E, num_scenarios=min(E, 512), block_dist_config=d, mover_capacity=args.cap,
+    cfg = make_config(dict(num_envs=E, num_scenarios=min(E, 512), mover_capacity=args.cap,
                            auto_reset=True, horizon=1000))
     host = HostScene(cfg)
     eng = BatchedEngine(cfg, host=host)

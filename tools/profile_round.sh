@@ -11,5 +11,5 @@ cat $OUT/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-python tools/summarize_profile.py $OUT > $OUT/summary.txt
+python tools/summarize_profile.py $OUT $OUT/pmc_traffic.json > $OUT/summary.txt
 cat $OUT/summary.txt
