@@ -667,6 +667,77 @@ MD_HD uint32_t md_rng_next(uint32_t* st) {
     return x;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Traffic modes "respawn" / "hybrid": PGTrafficManager.after_step (manager/traffic_manager.py:94-122).
+ * A traffic vehicle that left every lane is removed and, in these two modes, a NEW vehicle of the same
+ * type starts on a random respawn lane at longitude U[0, length/2) with a fresh IDMPolicy
+ * (policy/idm_policy.py:225-233: overtake_timer = randint(0, LANE_CHANGE_FREQ), PIDs zeroed) and a
+ * fresh route (navigation.reset).  The slot is reused.  Serial per env, ascending slot order (the
+ * reference walks its _traffic_vehicles list).  Draws come from the env's xorshift32 stream; the
+ * reference draws from the manager's RandomState whose position depends on Bullet-placed spawns, so
+ * the stream is unpinned either way.
+ * The respawn lanes and their routes are MdWorld.spawn_* with n_dest == 1 (spawn_place unused).
+ * -----------------------------------------------------------------------------------------*/
+MD_HD int md_traffic_wants_respawn(int flags) {
+    return md_kind_of(flags) == MD_KIND_VEHICLE && !(flags & (MD_F_ALIVE | MD_F_PENDING | MD_F_AGENT | MD_F_STATIC));
+}
+
+MD_HD void md_traffic_respawn_env(const MdWorld* w, const MdLane* lanes, const MdState* s, const MdConfig* c, int m) {
+    if (c->traffic_mode == 0 || !w->spawn_off) return;
+    const int p0 = w->spawn_off[m], np_ = w->spawn_off[m + 1] - p0;
+    if (np_ <= 0) return;
+    for (int slot = c->agents_per_env; slot < c->cap; ++slot) {
+        MdShape* sh = &s->shape[slot];
+        if (!md_traffic_wants_respawn(sh->flags)) continue;
+        const int p = p0 + (int)(md_rng_next(s->rng) % (uint32_t)np_);
+        const MdLane* L = &lanes[w->spawn_lane[p]];
+        const float u = (float)(md_rng_next(s->rng) >> 8) * (1.0f / 16777216.0f);
+        const float lng = u * L->length * 0.5f;
+        float x, y;
+        md_lane_position(L, lng, &x, &y);
+        const float h = md_wrap_to_pi(md_lane_heading_at(L, lng));
+        sh->cx = x;
+        sh->cy = y;
+        md_sincos(h, &sh->s, &sh->c);
+        sh->flags = MD_KIND_VEHICLE | MD_F_ALIVE;
+        sh->aux = -1;
+        MdDyn* d = &s->dyn[slot];
+        d->heading = h;
+        d->speed = 0.0f;
+        d->steering = 0.0f;
+        d->throttle = 0.0f;
+        d->last_x = x;
+        d->last_y = y;
+        d->last_c = sh->c;
+        d->last_s = sh->s;
+        MdNav* nav = &s->nav[slot];
+        nav->lane = w->spawn_lane[p];
+        nav->route_len = w->spawn_route_meta[2 * (size_t)p];
+        nav->ck0 = 0;
+        nav->ck1 = (nav->route_len <= 2) ? 0 : 1;
+        nav->target_lane = -1;
+        nav->timer = (int)(md_rng_next(s->rng) % (uint32_t)IDM_LANE_CHANGE_FREQ);
+        nav->trigger_road = -1;
+        nav->trigger_order = 0;
+        nav->steps = 0;
+        nav->done = 0;
+        s->final_lane[slot] = w->spawn_route_meta[2 * (size_t)p + 1];
+        const int32_t* rt = w->spawn_route + (size_t)p * 2 * MD_ROUTE_LEN;
+        for (int k = 0; k < MD_ROUTE_LEN; ++k) {
+            s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];
+            s->route_roads[(size_t)slot * MD_ROUTE_LEN + k] = rt[MD_ROUTE_LEN + k];
+        }
+        MdPid* pid = &s->pid[slot];
+        pid->hp = pid->hi = pid->hd = 0.0f;
+        pid->lp = pid->li = pid->ld = 0.0f;
+        pid->target_speed = IDM_NORMAL_SPEED;
+        pid->energy = 0.0f;
+        s->flags[slot] = 0;
+        s->action[2 * slot] = 0.0f;
+        s->action[2 * slot + 1] = 0.0f;
+    }
+}
+
 #define MD_RESPAWN_HALF_LEN 4.0f  /* RESPAWN_REGION_LONGITUDE / 2 (spawn_manager.py:28) */
 #define MD_RESPAWN_HALF_WID 1.5f  /* RESPAWN_REGION_LATERAL / 2 */
 

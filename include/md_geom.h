@@ -231,6 +231,21 @@ MD_HD float md_lane_heading_at(const MdLane* L, float s) {
     return phi + MD_HALF_PI_F * L->dirsign;
 }
 
+/* centre-line point at longitudinal s: StraightLane.position (straight_lane.py:57-58) /
+ * CircularLane.position (circular_lane.py:55-58) with lateral = 0 */
+MD_HD void md_lane_position(const MdLane* L, float s, float* x, float* y) {
+    if (L->type == 0) {
+        *x = L->ax + s * L->bx;
+        *y = L->ay + s * L->by;
+        return;
+    }
+    float phi = L->dirsign * s / L->bx + L->by;
+    float sn, cs;
+    md_sincos(phi, &sn, &cs);
+    *x = L->ax + L->bx * cs;
+    *y = L->ay + L->bx * sn;
+}
+
 MD_HD float md_lane_distance(const MdLane* L, float s, float lat) {
     float a = s - L->length;
     float b = 0.0f - s;

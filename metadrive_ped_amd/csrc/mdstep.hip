@@ -679,7 +679,9 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
 // step would cost more HBM traffic and LDS occupancy than it saves in latency.
 constexpr int kStageMaxLanes = 64;
 
-template <int PH, bool STAGE_MAP>
+// RESPAWN: traffic_mode respawn / hybrid (compiled apart: its slot-rewriting code costs the common trigger-mode
+// kernel 8 VGPRs and one wave of occupancy when it is merely branched around).
+template <int PH, bool STAGE_MAP, bool RESPAWN = false>
 __global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                                                   int lidar_stride, int lidar_offset) {
     constexpr int kBlock = 256;
@@ -757,15 +759,15 @@ __global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig
             l_action[2 * j + 1] = 0.0f;
             l_flags[j] = 0u;
         }
-        if (c.is_multi_agent) {  // respawns rewrote the routes: restore them too
+        if (c.is_multi_agent || RESPAWN) {  // respawns rewrote the routes: restore them too
             for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
                 gv.route_nodes[i] = gv.route_nodes0[i];
                 l_rroads[i] = gv.route_roads0[i];
             }
-            for (int j = tid; j < cap; j += kBlock) {
-                l_final[j] = gv.final_lane0[j];
-                gv.agent_id[j] = j;
-            }
+            for (int j = tid; j < cap; j += kBlock) l_final[j] = gv.final_lane0[j];
+        }
+        if (c.is_multi_agent) {
+            for (int j = tid; j < cap; j += kBlock) gv.agent_id[j] = j;
             if (tid == 0) {
                 gv.env_steps[0] = 0;
                 gv.next_agent_id[0] = c.agents_per_env;
@@ -824,6 +826,10 @@ __global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig
             if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) s.shape[j].flags = f & ~MD_F_ALIVE;
         }
         __syncthreads();
+        if (RESPAWN) {  // respawn / hybrid: the removed vehicle re-enters on a respawn lane (rare; serial)
+            if (tid == 0) md_traffic_respawn_env(&w, lanes, &s, &c, w.env_map[e]);
+            __syncthreads();
+        }
     }
     MD_STAMP_AT(7);
     if (PH & PH_OBSERVE) {
@@ -841,18 +847,20 @@ __global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig
         __syncthreads();
         MD_STAMP_AT(10);
         if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
-        if (PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
-        if (PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
-        if (PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
-        if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent) copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
-        if ((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent)
+        constexpr bool respawns = (PH & PH_TRAFFIC) && RESPAWN;  // traffic respawn rewrites a whole slot
+        if ((PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) || respawns) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+        if ((PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
+        if ((PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
+        if (((PH & (PH_RESET | PH_LIFECYCLE)) && c.is_multi_agent) || ((PH & (PH_RESET | PH_TRAFFIC)) && RESPAWN)) {
+            copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
             for (int j = tid; j < cap; j += kBlock) gv.final_lane[j] = l_final[j];
+        }
         for (int j = tid; j < cap; j += kBlock) {
-            if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_LIFECYCLE)) {
+            if ((PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_LIFECYCLE)) || respawns) {
                 gv.action[2 * j] = l_action[2 * j];
                 gv.action[2 * j + 1] = l_action[2 * j + 1];
             }
-            if (PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE | PH_LIFECYCLE)) gv.flags[j] = l_flags[j];
+            if ((PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE | PH_LIFECYCLE)) || respawns) gv.flags[j] = l_flags[j];
         }
         if (do_reset && tid == 0) gv.need_reset[0] = 0;
     }
@@ -914,7 +922,13 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     }
     const dim3 grid(c->n_envs);
     const hipStream_t st = (hipStream_t)stream;
-    if (stage)
+    constexpr bool kCanRespawn = (PH & (PH_TRAFFIC | PH_RESET)) != 0;
+    if (kCanRespawn && c->traffic_mode != 0) {
+        if (stage)
+            hipLaunchKernelGGL((env_kernel<PH, true, kCanRespawn>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+        else
+            hipLaunchKernelGGL((env_kernel<PH, false, kCanRespawn>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    } else if (stage)
         hipLaunchKernelGGL((env_kernel<PH, true>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
     else
         hipLaunchKernelGGL((env_kernel<PH, false>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
@@ -1077,6 +1091,21 @@ __attribute__((visibility("default"))) int md_idm(const MdWorld* w, const MdStat
     return launch<PH_IDM>(w, s, c, nullptr, 0, 0, stream);
 }
 
+// traffic_mode respawn / hybrid: the respawn-lane tables, the env RNG and the route snapshot must be there
+int check_traffic_mode(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    if (c->traffic_mode == 0) return MD_OK;
+    if (c->traffic_mode < 0 || c->traffic_mode > 2 || c->is_multi_agent) {
+        snprintf(g_err, sizeof g_err, "traffic_mode=%d is not valid here (0 trigger, 1 respawn, 2 hybrid; single-agent envs)",
+                 c->traffic_mode);
+        return MD_EINVAL;
+    }
+    int r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->rng); NEED(s->route_nodes0); NEED(s->route_roads0); NEED(s->final_lane0); NEED(s->final_lane);
+    NEED(w->spawn_off); NEED(w->spawn_lane); NEED(w->spawn_route); NEED(w->spawn_route_meta);
+    return MD_OK;
+}
+
 __attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c,
                                                                 void* stream) {
     int r = check_common(w, s, c);
@@ -1084,6 +1113,8 @@ __attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* 
     r = check_state(s);
     if (r != MD_OK) return r;
     NEED(s->flags);
+    r = check_traffic_mode(w, s, c);
+    if (r != MD_OK) return r;
     return launch<PH_TRAFFIC>(w, s, c, nullptr, 0, 0, stream);
 }
 
@@ -1126,6 +1157,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
     if (c->n_beams > 0) NEED(w->beam_cs);
     NEED(s->shape0); NEED(s->dyn0); NEED(s->nav0); NEED(s->pid0);
     r = check_marl(w, s, c);
+    if (r != MD_OK) return r;
+    r = check_traffic_mode(w, s, c);
     if (r != MD_OK) return r;
     if (c->obs_dim != md_obs_lidar(c) + c->n_beams) {
         snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim, md_obs_lidar(c), c->n_beams);

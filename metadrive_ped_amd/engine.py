@@ -40,6 +40,9 @@ def _build_one(job):
     pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
     mt = MapTables(pg)
+    if scene_cfg["traffic_mode"] != "trigger" and abs(scene_cfg["traffic_density"]) >= 1e-2:
+        from metadrive_ped_amd.mapgen.tables import respawn_tables
+        mt.respawn = respawn_tables(mt, s)
     return mt, EnvScene(s, mt, scene_cfg)
 
 
@@ -139,12 +142,15 @@ class HostScene:
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
         st["need_reset"] = np.ones(E, np.int32)
-        if cfg["is_multi_agent"]:
+        self.traffic_respawns = "spawn_off" in self.world.arrays and not cfg["is_multi_agent"]
+        if cfg["is_multi_agent"] or self.traffic_respawns:
+            # respawns (agents in MARL, traffic in the respawn / hybrid modes) rewrite routes and draw random numbers
             st["route_nodes0"] = st["route_nodes"].copy()
             st["route_roads0"] = st["route_roads"].copy()
             st["final_lane0"] = st["final_lane"].copy()
             # xorshift32 needs a non-zero state; derive it from the env's scenario seed
             st["rng"] = np.asarray([((s * 2654435761) ^ 0x9E3779B9) & 0xFFFFFFFF or 1 for s in seeds], np.uint32)
+        if cfg["is_multi_agent"]:
             st["env_steps"] = np.zeros(E, np.int32)
             st["agent_id"] = np.tile(np.arange(cap, dtype=np.int32), E)
             st["next_agent_id"] = np.full(E, A, np.int32)
@@ -176,7 +182,8 @@ def make_md_config(cfg, E, A, cap, n_beams):
                  "crash_object_done", "crash_human_done", "truncate_as_terminate", "enable_idm_lane_change",
                  "auto_reset"):
         setattr(k, name, int(bool(cfg[name])))
-    k.traffic_mode = {"trigger": 0, "respawn": 1, "hybrid": 2}[cfg["traffic_mode"]]
+    # density ~ 0: PGTrafficManager.reset returns before any mode-specific set-up (traffic_manager.py:62-63)
+    k.traffic_mode = {"trigger": 0, "respawn": 1, "hybrid": 2}[cfg["traffic_mode"]] if abs(cfg["traffic_density"]) >= 1e-2 else 0
     k.max_lane_width = 4.5      # BaseMap.MAX_LANE_WIDTH (component/map/base_map.py:38)
     k.total_width = (3 + 1) * 4.5  # (MAX_LANE_NUM + 1) * MAX_LANE_WIDTH (obs/state_obs.py:92)
     k.curve_radius_max = 60.0   # BlockParameterSpace.CURVE radius max
@@ -236,7 +243,7 @@ class BatchedEngine:
         ptr = lambda t: t.data_ptr()
         wd = dict(self.world_dev)
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
-        wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else 0
+        wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else (1 if h.traffic_respawns else 0)
         self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         self._side_beams = self._to_dev(h.side_beams) if h.side_beams is not None else None
         self._ll_beams = self._to_dev(h.ll_beams) if h.ll_beams is not None else None

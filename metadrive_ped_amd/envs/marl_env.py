@@ -57,7 +57,8 @@ class BatchedMultiAgentRoundaboutEnv:
         n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
         self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + 10 + n, ), np.float32)
-        self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        from metadrive_ped_amd.envs.metadrive_env import make_action_space
+        self.action_space = make_action_space(self.config)
         self.engine = None
 
     def reset(self, seed=None):
@@ -77,7 +78,11 @@ class BatchedMultiAgentRoundaboutEnv:
         if self.engine is None:
             raise RuntimeError("call reset() before step()")
         torch = self.engine.torch
-        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
+        if self.config["discrete_action"]:
+            from metadrive_ped_amd.envs.metadrive_env import discrete_to_continuous
+            a = discrete_to_continuous(torch, self.config, actions, (self.num_envs, self.num_agents), self.engine.device)
+        else:
+            a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
         if tuple(a.shape) != (self.num_envs, self.num_agents, 2):
             raise ValueError("actions must have shape [{}, {}, 2], got {}".format(self.num_envs, self.num_agents, tuple(a.shape)))
         self.engine.step(a)

@@ -18,7 +18,45 @@ import numpy as np
 
 from metadrive_ped_amd import abi
 from metadrive_ped_amd.config import make_config
-from metadrive_ped_amd.envs.spaces import Box
+from metadrive_ped_amd.envs.spaces import Box, Discrete, MultiDiscrete
+
+
+def make_action_space(cfg):
+    """EnvInputPolicy.get_input_space (policy/env_input_policy.py:50-69)."""
+    if not cfg["discrete_action"]:
+        return Box(-1.0, 1.0, (2, ), np.float32)
+    if cfg["use_multi_discrete"]:
+        return MultiDiscrete([cfg["discrete_steering_dim"], cfg["discrete_throttle_dim"]])
+    return Discrete(cfg["discrete_steering_dim"] * cfg["discrete_throttle_dim"])
+
+
+def discrete_to_continuous(torch, cfg, actions, lead_shape, device):
+    """EnvInputPolicy.convert_to_continuous_action (policy/env_input_policy.py:40-48) for a batch: Discrete
+    index -> (index % steering_dim, index // steering_dim), MultiDiscrete -> (a[0], a[1]); each grid index i
+    maps to i * 2/(dim-1) - 1.  Returns float32 [*lead_shape, 2] on `device`."""
+    sd, td = int(cfg["discrete_steering_dim"]), int(cfg["discrete_throttle_dim"])
+    a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions))
+    if a.is_floating_point():
+        raise TypeError("discrete_action=True expects integer actions, got dtype {}".format(a.dtype))
+    a = a.to(device)
+    if cfg["use_multi_discrete"]:
+        if tuple(a.shape) == (2, ):
+            a = a.expand(*lead_shape, 2)
+        if tuple(a.shape) != tuple(lead_shape) + (2, ):
+            raise ValueError("actions must have shape {}, got {}".format(tuple(lead_shape) + (2, ), tuple(a.shape)))
+        si, ti = a[..., 0], a[..., 1]
+    else:
+        if a.dim() == 0:
+            a = a.expand(*lead_shape)
+        if tuple(a.shape) != tuple(lead_shape):
+            raise ValueError("actions must have shape {}, got {}".format(tuple(lead_shape), tuple(a.shape)))
+        si, ti = a % sd, torch.div(a, sd, rounding_mode="floor")
+    if cfg["action_check"]:
+        ok = (si >= 0) & (si < sd) & (ti >= 0) & (ti < td)
+        assert bool(ok.all()), "Input is not compatible with action space {}!".format(make_action_space(cfg))
+    steering = si.to(torch.float32) * (2.0 / (sd - 1)) - 1.0
+    throttle = ti.to(torch.float32) * (2.0 / (td - 1)) - 1.0
+    return torch.stack([steering, throttle], dim=-1)
 
 
 class BatchedMetaDriveEnv:
@@ -41,7 +79,7 @@ class BatchedMetaDriveEnv:
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
         self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 10 + n
         self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
-        self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        self.action_space = make_action_space(self.config)
         self.start_seed = self.config["start_seed"]
         self.episode_rewards = None
 
@@ -72,10 +110,13 @@ class BatchedMetaDriveEnv:
             raise RuntimeError("call reset() before step()")
         torch = self.engine.torch
         a = actions
-        if not torch.is_tensor(a):
-            a = torch.as_tensor(np.asarray(a, dtype=np.float32))
-        if a.dim() == 1:
-            a = a.unsqueeze(0).expand(self.num_envs, 2)
+        if self.config["discrete_action"]:
+            a = discrete_to_continuous(torch, self.config, a, (self.num_envs, ), self.engine.device)
+        else:
+            if not torch.is_tensor(a):
+                a = torch.as_tensor(np.asarray(a, dtype=np.float32))
+            if a.dim() == 1:
+                a = a.unsqueeze(0).expand(self.num_envs, 2)
         if tuple(a.shape) != (self.num_envs, 2):
             raise ValueError("actions must have shape [{}, 2], got {}".format(self.num_envs, tuple(a.shape)))
         self.engine.step(a)

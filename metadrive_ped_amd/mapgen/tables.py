@@ -119,6 +119,7 @@ class MapTables:
     """numpy tables of ONE map (all offsets map-local)."""
     def __init__(self, pg_map):
         self.pg_map = pg_map
+        self.respawn = None    # respawn-lane tables (traffic modes 'respawn' / 'hybrid'), see respawn_tables
         net = pg_map.net
         nodes = {}
         roads, lanes_flat = [], []
@@ -277,6 +278,49 @@ def spawn_tables(mt, spawn_roads, lane_num):
                 dests=dests)
 
 
+def destination_for(pg_map, seed, lane_index):
+    """NodeNetworkNavigation.reset (navigation_module/node_network_navigation.py:43-71): a vehicle on a
+    negative road drives to the first block's socket, any other to a socket of the last block."""
+    from metadrive_ped_amd.rng import get_np_random
+    negative = lane_index[1].find("-") != -1
+    block = pg_map.blocks[0] if negative else pg_map.blocks[-1]
+    sockets = list(block.sockets.values())
+    socket = sockets[0] if len(sockets) == 1 else sockets[int(get_np_random(seed).choice(len(sockets)))]
+    return socket.negative[1] if negative else socket.positive[1]
+
+
+def respawn_lanes(pg_map):
+    """PGTrafficManager._get_available_respawn_lanes (manager/traffic_manager.py:279-296): a road named by
+    two blocks is an inner road and drops out."""
+    roads = []
+    for block in pg_map.blocks:
+        for road in block.respawn_roads:
+            if road in roads:
+                roads.remove(road)
+            else:
+                roads.append(road)
+    out = []
+    for road in roads:
+        out += pg_map.net.lanes(*road)
+    return out
+
+
+def respawn_tables(mt, seed):
+    """MdWorld.spawn_* for the traffic modes 'respawn' / 'hybrid': one entry per respawn lane with the
+    route a vehicle starting there follows (n_dest = 1; spawn_place is not used on this path)."""
+    pg = mt.pg_map
+    lanes, routes, meta = [], [], []
+    for lane in respawn_lanes(pg):
+        idx = tuple(lane.index)
+        nodes, roads_, n, fin = route_arrays(mt, idx, destination_for(pg, seed, idx))
+        lanes.append(mt.lane_id[idx])
+        routes.append([nodes, roads_])
+        meta.append([n, fin])
+    return dict(spawn_place=np.zeros((len(lanes), 8), np.float32), spawn_lane=np.asarray(lanes, np.int32),
+                spawn_route=np.asarray(routes, np.int32).reshape(-1, 2, abi.MD_ROUTE_LEN),
+                spawn_route_meta=np.asarray(meta, np.int32).reshape(-1, 2), n_dest=1)
+
+
 def route_arrays(mt, lane_index, dest):
     """(route_nodes[24], route_roads[24], n_checkpoints, final_lane) of set_route (node_network_navigation.py:94-128)."""
     pg = mt.pg_map
@@ -346,6 +390,14 @@ class WorldTables:
         a["beam_cs"] = np.asarray(beam_cs, dtype=np.float32).reshape(-1, 2)
         self.n_maps = n
         self.n_envs = len(env_map)
+        if n and all(getattr(m, "respawn", None) is not None for m in maps):
+            off = [0]
+            for m in maps:
+                off.append(off[-1] + len(m.respawn["spawn_lane"]))
+            a["spawn_off"] = np.asarray(off, np.int32)
+            for k in ("spawn_place", "spawn_lane", "spawn_route", "spawn_route_meta"):
+                a[k] = np.ascontiguousarray(np.concatenate([m.respawn[k] for m in maps]))
+            self.n_dest = 1
         # guard: padding arrays that may legitimately be empty
         for k in ("quads", "quad_kind", "cell_items", "node_adj", "hull_xy"):
             if a[k].size == 0:

@@ -26,6 +26,7 @@ import numpy as np
 from metadrive_ped_amd import abi
 from metadrive_ped_amd.mapgen.lanes import wrap_to_pi
 from metadrive_ped_amd.mapgen.pg import FirstBlock
+from metadrive_ped_amd.mapgen.tables import destination_for, respawn_lanes
 from metadrive_ped_amd.pg_space import VEHICLE_TYPES, sample_parameters
 from metadrive_ped_amd.rng import Randomizable, get_np_random
 
@@ -107,9 +108,27 @@ class EnvScene:
         density = cfg["traffic_density"]
         slot = A
         if abs(density) >= 1e-2:
-            if cfg["traffic_mode"] != "trigger":
-                raise NotImplementedError("traffic_mode '{}' is not built yet (only 'trigger')".format(cfg["traffic_mode"]))
-            for bi, block in enumerate(pg_map.blocks[1:], start=1):
+            if cfg["traffic_mode"] not in ("trigger", "respawn", "hybrid"):
+                raise ValueError("No such mode named {}".format(cfg["traffic_mode"]))  # traffic_manager.py:71
+            if cfg["traffic_mode"] == "respawn":
+                # _create_respawn_vehicles (traffic_manager.py:213-228): every vehicle drives from step 0
+                for lane in respawn_lanes(pg_map):
+                    total_num = int(lane.length / VEHICLE_GAP)
+                    longs = [i * VEHICLE_GAP for i in range(total_num)]
+                    traffic_mgr.np_random.shuffle(longs)
+                    for long in longs[:int(np.ceil(density * len(longs)))]:
+                        vtype = str(traffic_mgr.np_random.choice(TRAFFIC_TYPE_KEYS, p=TRAFFIC_TYPE_P))
+                        vseed = engine.generate_seed()
+                        policy_seed = traffic_mgr.generate_seed()
+                        if slot > self._next_prop_slot:
+                            raise ValueError("env seed {}: more than cap={} movers; raise `mover_capacity`".format(seed, cap))
+                        self._place_vehicle(slot, vtype, vseed, tuple(lane.index), float(long), 0.0, dt, abi.F_ALIVE)
+                        self.nav[slot]["trigger_road"] = -1
+                        prng = get_np_random(policy_seed)
+                        self.nav[slot]["timer"] = int(prng.randint(0, 50))
+                        self.idm_rand[slot] = [int(prng.randint(0, 25)) for _ in range(abi.MD_IDM_RAND)]
+                        slot += 1
+            for bi, block in enumerate(pg_map.blocks[1:] if cfg["traffic_mode"] != "respawn" else [], start=1):
                 trigger_lanes = block.intermediate_spawn_lanes()
                 potential = []
                 for lanes in trigger_lanes:
@@ -284,11 +303,7 @@ class EnvScene:
         # navigation.reset + set_route (node_network_navigation.py:43-128)
         lane_id = t.lane_id[tuple(lane_index)]
         start_node = lane_index[0]
-        negative = lane_index[1].find("-") != -1
-        block = pg_map.blocks[0] if negative else pg_map.blocks[-1]
-        sockets = list(block.sockets.values())
-        socket = sockets[0] if len(sockets) == 1 else sockets[int(get_np_random(self.seed).choice(len(sockets)))]
-        dest = socket.negative[1] if negative else socket.positive[1]
+        dest = destination_for(pg_map, self.seed, lane_index)
         ckpts = pg_map.bfs_route(start_node, dest)
         ck0, ck1 = 0, 1
         if len(ckpts) <= 2:

@@ -230,12 +230,16 @@ EXPORT int ref_contacts(const MdWorld* w, const MdState* s, const MdConfig* c) {
 /* PGTrafficManager.after_step (manager/traffic_manager.py:94-122), trigger mode: traffic that left
  * every lane hull is removed. */
 EXPORT int ref_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c) {
-    (void)w;
     for (int n = 0; n < c->n_envs * c->cap; ++n) {
         MdShape* sh = &s->shape[n];
         if (!drives(sh->flags) || (sh->flags & MD_F_AGENT)) continue;
         if (!(s->flags[n] & MD_FL_ON_LANE)) sh->flags &= ~MD_F_ALIVE;
     }
+    if (c->traffic_mode != 0)
+        for (int e = 0; e < c->n_envs; ++e) {
+            MdState v = md_env_view(s, c, e);
+            md_traffic_respawn_env(w, w->lanes + w->lane_off[w->env_map[e]], &v, c, w->env_map[e]);
+        }
     return MD_OK;
 }
 
@@ -325,10 +329,12 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
             s->action[2 * (base + j)] = 0.0f;
             s->action[2 * (base + j) + 1] = 0.0f;
         }
-        if (c->is_multi_agent) {
+        if (c->is_multi_agent || c->traffic_mode != 0) { /* routes are rewritten by respawns */
             memcpy(&s->route_nodes[(size_t)base * MD_ROUTE_LEN], &s->route_nodes0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
             memcpy(&s->route_roads[(size_t)base * MD_ROUTE_LEN], &s->route_roads0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
             memcpy(&s->final_lane[base], &s->final_lane0[base], sizeof(int32_t) * c->cap);
+        }
+        if (c->is_multi_agent) {
             s->env_steps[e] = 0;
             s->next_agent_id[e] = c->agents_per_env;
             for (int j = 0; j < c->cap; ++j) s->agent_id[base + j] = j;
@@ -350,6 +356,10 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         MdShape* sh = &s->shape[base + j];
         if (!drives(sh->flags) || (sh->flags & MD_F_AGENT)) continue;
         if (!(s->flags[base + j] & MD_FL_ON_LANE)) sh->flags &= ~MD_F_ALIVE;
+    }
+    if (c->traffic_mode != 0) {
+        MdState v = md_env_view(s, c, e);
+        md_traffic_respawn_env(w, w->lanes + w->lane_off[w->env_map[e]], &v, c, w->env_map[e]);
     }
     for (int a = 0; a < c->agents_per_env; ++a) {
         MdState v = md_env_view(s, c, e);

@@ -91,7 +91,7 @@ class OracleWorld:
         self.state = state if state is not None else host.clone_state()
         wa = dict(host.world.arrays)
         wa["lane_off_host"], wa["road_off_host"] = wa["lane_off"], wa["road_off"]
-        wa["n_dest_host"] = host.spawn["n_dest"] if host.spawn is not None else 0
+        wa["n_dest_host"] = host.spawn["n_dest"] if host.spawn is not None else (1 if host.traffic_respawns else 0)
         self.w, self.s, self.k = make_structs(wa, self.state, host.md_config, host.world.n_maps, host.E, _ptr)
 
     def call(self, name, *extra):

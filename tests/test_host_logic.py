@@ -47,6 +47,35 @@ def test_spaces_and_env_surface():
         env.step(np.zeros((3, 2), np.float32))      # step before reset
 
 
+def test_discrete_action_tables():
+    """The reference's known answers for the action grids (tests/test_functionality/test_discrete_action.py:
+    48-56,78-87): Discrete(15) with steering_dim 3 / throttle_dim 5, and MultiDiscrete([3, 5])."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.envs.metadrive_env import discrete_to_continuous, make_action_space
+    from metadrive_ped_amd.envs.spaces import Discrete, MultiDiscrete
+    cfg = make_config(dict(discrete_action=True, use_multi_discrete=False, discrete_steering_dim=3,
+                           discrete_throttle_dim=5, action_check=True))
+    sp = make_action_space(cfg)
+    assert isinstance(sp, Discrete) and sp.n == 15 and sp.contains(sp.sample())
+    got = discrete_to_continuous(torch, cfg, torch.tensor([0, 1, 2, 7, 14]), (5, ), "cpu")
+    assert got.tolist() == [[-1, -1], [0, -1], [1, -1], [0, 0], [1, 1]]
+    with pytest.raises(AssertionError):
+        discrete_to_continuous(torch, cfg, torch.tensor([15]), (1, ), "cpu")
+    with pytest.raises(TypeError):
+        discrete_to_continuous(torch, cfg, torch.tensor([0.5]), (1, ), "cpu")
+    cfg = make_config(dict(discrete_action=True, use_multi_discrete=True, discrete_steering_dim=3,
+                           discrete_throttle_dim=5, action_check=True))
+    sp = make_action_space(cfg)
+    assert isinstance(sp, MultiDiscrete) and sp.shape == (2, ) and all(sp.nvec == (3, 5)) and sp.contains(sp.sample())
+    got = discrete_to_continuous(torch, cfg, torch.tensor([[0, 0], [1, 0], [2, 0], [1, 2], [2, 4]]), (5, ), "cpu")
+    assert got.tolist() == [[-1, -1], [0, -1], [1, -1], [0, 0], [1, 1]]
+    # default grid 5 x 5 (base_env.py:74-77)
+    cfg = make_config(dict(discrete_action=True))
+    assert make_action_space(cfg).n == 25
+    assert discrete_to_continuous(torch, cfg, torch.tensor([12]), (1, ), "cpu").tolist() == [[0.0, 0.0]]
+
+
 def test_scene_routes_and_traffic(cs_dist):
     from metadrive_ped_amd.engine import HostScene
     h = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6))

@@ -219,3 +219,54 @@ def test_obb_overlap_symmetry_and_containment():
             assert ab == 1
         if dist > math.hypot(float(a["hl"][0]), float(a["hw"][0])) + math.hypot(float(b["hl"][0]), float(b["hw"][0])):
             assert ab == 0
+
+
+@pytest.mark.parametrize("mode", ["respawn", "hybrid"])
+def test_traffic_respawn_modes(mode):
+    """PGTrafficManager in respawn / hybrid mode (manager/traffic_manager.py:51-72,94-122,213-228): respawn mode
+    starts ceil(density * slots) driving vehicles per respawn lane; a vehicle that leaves the lanes comes back
+    on a respawn lane in the first half of it, at rest, with a route; the count of vehicles is conserved."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.mapgen.tables import respawn_lanes
+    E = 6
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, traffic_mode=mode, traffic_density=0.2, horizon=5000))
+    host = HostScene(cfg)
+    fl0 = host.state["shape0"]["flags"].reshape(E, -1)
+    is_traffic = ((fl0 & abi.KIND_MASK) == abi.KIND_VEHICLE) & ((fl0 & abi.F_AGENT) == 0)
+    if mode == "respawn":
+        assert not (fl0 & abi.F_PENDING).any()
+        for e, seed in enumerate(host.seeds):
+            lanes = respawn_lanes(host.scenes[seed].tables.pg_map)
+            want = sum(int(np.ceil(0.2 * int(l.length / 10))) for l in lanes)
+            assert is_traffic[e].sum() == want
+    else:
+        assert ((fl0 & abi.F_PENDING) != 0)[is_traffic].all()          # hybrid starts like trigger mode
+    o = ob.OracleWorld(host)
+    o.reset()
+    st = o.state
+    n0 = is_traffic.sum(1)
+    last = st["rng"].copy()
+    seen = 0
+    for t in range(900):
+        o.step(np.tile(np.array([0.0, 0.25 if mode == "hybrid" else 0.0], np.float32), (E, 1, 1)))
+        changed = np.nonzero(st["rng"] != last)[0]
+        last = st["rng"].copy()
+        fl = st["shape"]["flags"].reshape(E, -1)
+        for e in changed:
+            seen += 1
+            m = host.world.arrays
+            p0, p1 = m["spawn_off"][e], m["spawn_off"][e + 1]
+            ok = False
+            nav = st["nav"].reshape(E, -1)
+            dyn = st["dyn"].reshape(E, -1)
+            for j in range(1, host.cap):
+                if dyn["speed"][e, j] == 0.0 and nav["steps"][e, j] == 0 and (fl[e, j] & abi.F_ALIVE) and \
+                        nav["lane"][e, j] in m["spawn_lane"][p0:p1] and nav["route_len"][e, j] >= 2:
+                    ok = True
+            assert ok, "env %d: a respawned vehicle must sit at rest on a respawn lane" % e
+        alive = ((fl & abi.F_ALIVE) != 0) & ((fl & abi.KIND_MASK) == abi.KIND_VEHICLE) & ((fl & abi.F_AGENT) == 0) & \
+            ((fl & abi.F_STATIC) == 0)
+        if not st["need_reset"].any():
+            assert (alive.sum(1) == n0).all(), "traffic count is conserved in %s mode" % mode
+    assert seen > 0
