@@ -30,6 +30,7 @@ from collections import OrderedDict
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP32_PEAK_TFLOPS = 157.3   # vector FP32, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 
 
@@ -190,6 +191,28 @@ def main():
                  frac=round(bytes_lidar / (lid_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=int(bytes_lidar),
                  flops_per_launch=int(30.0 * B * (M - 1) * E * A))
 
+    # ---- attainable HBM bandwidth on this box: HIP stream-copy kernel through the same library ----
+    import ctypes as C
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for _ in range(3):
+        eng._check(eng.lib.md_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, st), "copy")
+    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ca.record()
+    for _ in range(10):
+        eng._check(eng.lib.md_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), nbytes, st), "copy")
+    cb.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2.0 * nbytes * 10 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+    del src, dst
+    roofline["peak_attainable"] = round(copy_gbs, 1)            # measured stream copy (read + write), GB/s
+    roofline["frac_attainable"] = round(achieved / copy_gbs, 5)
+    lidar["fp32_tflops"] = round(lidar["flops_per_launch"] / (lid_ms * 1e-3) / 1e12, 2)
+    lidar["fp32_peak_tflops"] = FP32_PEAK_TFLOPS
+    lidar["fp32_frac"] = round(lidar["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
+
     # ---- optional gather (N>1): obs + reward + flags to every rank over RCCL ----
     with_gather = None
     if world > 1:
@@ -229,9 +252,27 @@ def main():
         for i in range(args.cpu_steps):
             orc.step(acts[i % n_act], threads=cores)
         dt = time.perf_counter() - t0
+        # single thread, on a slice of the same envs (SURVEY 8d asks for both figures)
+        n1 = max(1, n_cpu // 16)
+        ccfg1 = dict(cfg)
+        ccfg1["num_envs"] = n1
+        orc1 = ob.OracleWorld(HostScene(ccfg1))
+        orc1.reset()
+        t1 = time.perf_counter()
+        for i in range(args.cpu_steps):
+            orc1.step(acts[i % n_act][:n1], threads=1)
+        dt1 = time.perf_counter() - t1
+        try:
+            with open("/proc/cpuinfo") as fh:
+                cpu_model = [l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")][0]
+        except (OSError, IndexError):
+            cpu_model = "unknown"
         cpu_baseline = dict(value=round(n_cpu * A * args.cpu_steps / dt, 1), unit="agent-steps/s", cores=cores, kind="port",
                             sample="%d envs x %d steps of the same workload, oracle/md_oracle.c ref_step_mt on %d threads"
-                                   % (n_cpu, args.cpu_steps, cores))
+                                   % (n_cpu, args.cpu_steps, cores),
+                            single_thread_value=round(n1 * A * args.cpu_steps / dt1, 1),
+                            single_thread_sample="%d envs x %d steps, 1 thread" % (n1, args.cpu_steps),
+                            cpu_model=cpu_model, nproc=os.cpu_count())
 
     if rank == 0:
         line = OrderedDict(

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 1
+#define MD_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -289,7 +289,8 @@ typedef struct MdConfig {
      * [lane-line cloud n_lane_line | lateral] + navi 10 + lidar n_beams */
     int32_t n_side;            /* side_detector.num_lasers (0 = off: two distance dims instead)   */
     int32_t n_lane_line;       /* lane_line_detector.num_lasers (0 = off: one lateral dim instead) */
-    int32_t pad1;
+    int32_t num_others;        /* vehicle_config.lidar.num_others: nearest detected vehicles in the obs (0 = none) */
+    int32_t add_others_navi;   /* vehicle_config.lidar.add_others_navi                            */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */
@@ -305,6 +306,11 @@ const char* md_last_error(void);
  * km/h, b = distance m).  The parity tests compare it bit for bit with the host build of the same
  * formulas: this is what makes "bit-exact booleans" a checkable claim. */
 int md_probe_math(int op, const float* a, const float* b, float* out, int n, void* stream);
+
+/* Measurement hook ("measure the attainable number on the box with a HIP stream-copy
+ * kernel"): dst[i] = src[i] over nbytes (a multiple of 16, both 16-byte aligned) with 16-byte
+ * accesses, grid-stride; moves 2 * nbytes of HBM traffic.  No reference counterpart. */
+int md_probe_stream_copy(void* dst, const void* src, size_t nbytes, void* stream);
 
 /* Lidar: Lidar.perceive / perceive()  component/sensors/lidar.py:49-73,
  * component/sensors/distance_detector.py:27-85, utils/math.py:76-81.

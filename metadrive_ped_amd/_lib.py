@@ -45,6 +45,8 @@ def load():
                                      C.c_void_p]
     lib.md_probe_math.restype = C.c_int
     lib.md_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.md_probe_stream_copy.restype = C.c_int
+    lib.md_probe_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     abi.check_abi(lib.md_abi, LIB_PATH)
     _LIB = lib
     return lib

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 1
+MD_ABI_VERSION = 2
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -108,7 +108,8 @@ class MdConfig(C.Structure):
         ("curve_angle_max", C.c_float),
         ("is_multi_agent", C.c_int32), ("delay_done", C.c_int32), ("allow_respawn", C.c_int32),
         ("crash_done", C.c_int32), ("out_of_road_done", C.c_int32), ("n_side", C.c_int32), ("n_lane_line", C.c_int32),
-        ("pad1", C.c_int32),
+        ("num_others", C.c_int32),
+        ("add_others_navi", C.c_int32),
     ]
 
 
@@ -122,7 +123,7 @@ WORLD_FIELDS = [f for f, t in MdWorld._fields_ if t is P]
 STATE_FIELDS = [f for f, t in MdState._fields_ if t is P]
 
 # symbols include/mdstep.h declares; tests check every one is exported
-ENTRY_POINTS = ["md_abi", "md_last_error", "md_probe_math", "md_lidar", "md_line_detector", "md_integrate", "md_localize",
+ENTRY_POINTS = ["md_abi", "md_last_error", "md_probe_math", "md_probe_stream_copy", "md_lidar", "md_line_detector", "md_integrate", "md_localize",
                 "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_lifecycle", "md_step"]
 
 

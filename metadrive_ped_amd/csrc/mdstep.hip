@@ -177,6 +177,7 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
     if (valid) out_row[beam] = best;
 }
 
+// (Keeping the sectors off the wave that runs the agent's observe chain was tried: 154 vs 145 us, worse.)
 __device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
                             float* out, int out_stride, int out_offset) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
@@ -681,10 +682,14 @@ constexpr int kStageMaxLanes = 64;
 
 // RESPAWN: traffic_mode respawn / hybrid (compiled apart: its slot-rewriting code costs the common trigger-mode
 // kernel 8 VGPRs and one wave of occupancy when it is merely branched around).
+// Threads per env workgroup.  256 = 4 waves: measured best (tools/run_blocks.sh rebuilds with -DMD_ENV_BLOCK=128/64).
+#ifndef MD_ENV_BLOCK
+#define MD_ENV_BLOCK 256
+#endif
 template <int PH, bool STAGE_MAP, bool RESPAWN = false>
-__global__ __launch_bounds__(256) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
+__global__ __launch_bounds__(MD_ENV_BLOCK) void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                                                   int lidar_stride, int lidar_offset) {
-    constexpr int kBlock = 256;
+    constexpr int kBlock = MD_ENV_BLOCK;
     constexpr int kWaves = kBlock / 64;
     const int e = blockIdx.x;
     if (e >= c.n_envs) return;
@@ -911,11 +916,13 @@ template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
     const bool stage = w->max_lanes <= kStageMaxLanes;
-    const size_t lds = (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
+    // the lidar-only kernel stages nothing but the shapes: asking for the full image would cost it occupancy
+    const size_t lds = (PH == PH_LIDAR) ? (size_t)c->cap * sizeof(MdShape) + 16 :
+                       (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
                        4 * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16;
-    if (lds > 64 * 1024 || w->max_lanes <= 0 || w->max_roads <= 0) {
+    if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
         return MD_EINVAL;
@@ -925,13 +932,13 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     constexpr bool kCanRespawn = (PH & (PH_TRAFFIC | PH_RESET)) != 0;
     if (kCanRespawn && c->traffic_mode != 0) {
         if (stage)
-            hipLaunchKernelGGL((env_kernel<PH, true, kCanRespawn>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+            hipLaunchKernelGGL((env_kernel<PH, true, kCanRespawn>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset);
         else
-            hipLaunchKernelGGL((env_kernel<PH, false, kCanRespawn>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+            hipLaunchKernelGGL((env_kernel<PH, false, kCanRespawn>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset);
     } else if (stage)
-        hipLaunchKernelGGL((env_kernel<PH, true>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+        hipLaunchKernelGGL((env_kernel<PH, true>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset);
     else
-        hipLaunchKernelGGL((env_kernel<PH, false>), grid, dim3(256), lds, st, *w, *s, *c, lidar_out, stride, offset);
+        hipLaunchKernelGGL((env_kernel<PH, false>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
@@ -978,6 +985,44 @@ __attribute__((visibility("default"))) int md_debug_set_stamp_buffer(void* dev_p
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? MD_OK : MD_ELAUNCH;
 }
 #endif
+
+// 4 x 16 B per thread in flight (loads issued before the stores), non-temporal both ways, 2048 workgroups
+// striding over 16 KB tiles: the usual shape of a bandwidth probe on this part.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(u32x4* __restrict__ dst, const u32x4* __restrict__ src, size_t n16) {
+    constexpr int U = 4;
+    const size_t tile = (size_t)256 * U;
+    const size_t n_tiles = n16 / tile;
+    for (size_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const size_t base = t * tile + threadIdx.x;
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&src[base + (size_t)u * 256]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], &dst[base + (size_t)u * 256]);
+    }
+    // tail (< one tile): first workgroup
+    if (blockIdx.x == 0)
+        for (size_t i = n_tiles * tile + threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+}
+
+__attribute__((visibility("default"))) int md_probe_stream_copy(void* dst, const void* src, size_t nbytes, void* stream) {
+    if (!dst || !src || nbytes == 0 || (nbytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {
+        snprintf(g_err, sizeof g_err, "md_probe_stream_copy: null / unaligned pointer or size not a multiple of 16");
+        return MD_EINVAL;
+    }
+    const size_t n16 = nbytes >> 4;
+    size_t blocks = (n16 + 1023) / 1024;
+    if (blocks > 2048u) blocks = 2048u;  // 8 workgroups per CU, tile-stride beyond
+    hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst,
+                       (const u32x4*)src, n16);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
 
 __attribute__((visibility("default"))) int md_probe_math(int op, const float* a, const float* b, float* out, int n,
                                                         void* stream) {

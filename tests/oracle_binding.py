@@ -133,3 +133,23 @@ class OracleWorld:
     @property
     def obs(self):
         return self.state["obs"]
+
+
+def lidar_raw(shape, beam_cs, E, cap, n_beams, lidar_range):
+    """ref_lidar on a bare shape table (one agent per env in slot 0): the lidar micro-bench's checker."""
+    lib = load()
+    shape = np.ascontiguousarray(shape)
+    beam_cs = np.ascontiguousarray(beam_cs, np.float32)
+    w = abi.MdWorld()
+    w.n_maps, w.n_envs, w.max_lanes, w.max_roads = 1, E, 1, 1
+    w.beam_cs = beam_cs.ctypes.data
+    s = abi.MdState()
+    s.shape = shape.ctypes.data
+    k = abi.MdConfig()
+    k.struct_size = C.sizeof(abi.MdConfig)
+    k.n_envs, k.agents_per_env, k.cap, k.n_beams, k.obs_dim = E, 1, cap, n_beams, n_beams
+    k.lidar_range = lidar_range
+    out = np.zeros((E, n_beams), np.float32)
+    rc = lib.ref_lidar(C.byref(w), C.byref(s), C.byref(k), C.c_void_p(out.ctypes.data), n_beams, 0)
+    assert rc == 0
+    return out

@@ -42,3 +42,19 @@ def test_probe_math_bit_exact(op):
     bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
     assert len(bad) == 0, "{}: {} of {} differ, e.g. a={} b={} gpu={} cpu={}".format(
         OPS[op], len(bad), n, a[bad[:3]], b[bad[:3]], got[bad[:3]], want[bad[:3]])
+
+
+def test_stream_copy_probe_copies():
+    """md_probe_stream_copy (the attainable-bandwidth probe of bench.py) is a faithful copy, tail included."""
+    import ctypes as C
+    import torch
+    from metadrive_ped_amd import _lib
+    lib = _lib.load()
+    n = 16 * (1024 * 37 + 123)
+    src = torch.randint(0, 255, (n, ), dtype=torch.uint8, device="cuda")
+    dst = torch.zeros_like(src)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.md_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, st), "copy")
+    torch.cuda.synchronize()
+    assert torch.equal(src, dst)
+    assert lib.md_probe_stream_copy(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), 24, st) != 0

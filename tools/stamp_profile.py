@@ -30,7 +30,7 @@ def main():
     d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
     d["Curve"], d["Straight"] = 0.6, 0.4
     E = int(os.environ.get("ENVS", "4096"))
-    cfg = make_config(dict(num_envs=E, num_scenarios=min(E, 512), mover_capacity=0, horizon=1000))
+    cfg = make_config(dict(num_envs=E, num_scenarios=min(E, int(os.environ.get("SCEN", "512"))), mover_capacity=0, horizon=1000))
     eng = BatchedEngine(cfg, host=HostScene(cfg))
     eng.reset()
     g = torch.Generator().manual_seed(0)
