@@ -53,6 +53,7 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.env_steps = g->env_steps ? g->env_steps + e : 0;
     v.agent_id = g->agent_id ? g->agent_id + b : 0;
     v.next_agent_id = g->next_agent_id ? g->next_agent_id + e : 0;
+    v.detected = g->detected ? g->detected + (size_t)e * c->agents_per_env * 2 : 0;
     return v;
 }
 
@@ -60,7 +61,10 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
 MD_HD int md_obs_mid(const MdConfig* c) { return c->n_side > 0 ? c->n_side : 2; }              /* heading_diff ... */
 MD_HD int md_obs_ll(const MdConfig* c) { return md_obs_mid(c) + 6; }                             /* lane-line block  */
 MD_HD int md_obs_navi(const MdConfig* c) { return md_obs_ll(c) + (c->n_lane_line > 0 ? c->n_lane_line : 1); }
-MD_HD int md_obs_lidar(const MdConfig* c) { return md_obs_navi(c) + 10; }
+/* "others" block: num_others nearest detected vehicles x 4 dims (+4 with add_others_navi), between navi and cloud */
+MD_HD int md_obs_others(const MdConfig* c) { return md_obs_navi(c) + 10; }
+MD_HD int md_others_width(const MdConfig* c) { return c->add_others_navi ? 8 : 4; }
+MD_HD int md_obs_lidar(const MdConfig* c) { return md_obs_others(c) + (c->num_others > 0 ? c->num_others * md_others_width(c) : 0); }
 
 MD_HD int md_kind_of(int flags) { return flags & MD_KIND_MASK; }
 MD_HD int md_is_circle_kind(int k) { return k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_PEDESTRIAN; }
@@ -665,6 +669,97 @@ MD_HD uint32_t md_rng_next(uint32_t* st) {
     x ^= x << 5;
     *st = x;
     return x;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * "Others" block of LidarStateObservation: Lidar.get_surrounding_vehicles_info
+ * (component/sensors/lidar.py:93-138).  det_lo/det_hi = bit set of the slots some lidar beam of agent `a`
+ * hit first (detected_objects); vehicles among them (broken-down ones included, they are BaseVehicles;
+ * cones / tripods / barriers are not) are ranked by centre distance -- ties to the lowest slot, the reference
+ * sorts a Python set -- and the nearest num_others are described in the ego frame:
+ *   [ (fwd/R+1)/2, (left/R+1)/2, (dv_fwd/vmax+1)/2, (dv_left/vmax+1)/2 ]   R = lidar distance, speeds in km/h,
+ *   vmax = the ego's max_speed_km_h; with add_others_navi also the two checkpoints of that vehicle
+ *   (BaseNavigation.get_checkpoints, base_navigation.py:145-152), clipped to R, same projection.
+ * Missing vehicles are zero-filled.  Frame: (forward, left), the convert_to_local_coordinates derivation of
+ * SURVEY 8a-5 (a Panda3D transform: unpinned).  Velocity = speed along the heading (the kinematic model's
+ * slip angle is ignored here).
+ * -----------------------------------------------------------------------------------------*/
+MD_HD void md_others_project(float dx, float dy, float hc, float hs, float scale, float* o0, float* o1) {
+    float fwd = dx * hc + dy * hs;
+    float left = -dx * hs + dy * hc;
+    *o0 = md_clip((fwd / scale + 1.0f) / 2.0f, 0.0f, 1.0f);
+    *o1 = md_clip((left / scale + 1.0f) / 2.0f, 0.0f, 1.0f);
+}
+
+MD_HD void md_others_ckpt(const MdLane* lanes, const MdRoad* roads, const MdState* s, int j, float* c1x, float* c1y,
+                          float* c2x, float* c2y) {
+    const MdNav* nav = &s->nav[j];
+    const int32_t* rroads = s->route_roads + (size_t)j * MD_ROUTE_LEN;
+    const MdRoad* r1 = &roads[rroads[nav->ck0]];
+    const MdRoad* r2 = (nav->ck1 != nav->ck0) ? &roads[rroads[nav->ck1]] : r1;
+    /* later_middle uses the CURRENT lane's width and the current road's lane count (base_navigation.py:147) */
+    float wdt = (nav->lane >= 0) ? lanes[nav->lane].width : lanes[r1->first_lane].width;
+    float lm = ((float)r1->n_lanes / 2.0f - 0.5f) * wdt;
+    const MdLane* L1 = &lanes[r1->first_lane];
+    const MdLane* L2 = &lanes[r2->first_lane];
+    *c1x = L1->ex + lm * L1->elx;
+    *c1y = L1->ey + lm * L1->ely;
+    *c2x = L2->ex + lm * L2->elx;
+    *c2y = L2->ey + lm * L2->ely;
+}
+
+MD_HD void md_others_block(const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c, int a,
+                           unsigned long long det_lo, unsigned long long det_hi, float* out) {
+    const int wd = md_others_width(c);
+    const MdShape* me = &s->shape[a];
+    const float R = c->lidar_range;
+    const float vmax = s->param[a].max_speed_kmh;
+    const float ego_v = s->dyn[a].speed * 3.6f;
+    /* keep vehicles only */
+    for (int j = 0; j < c->cap && j < 128; ++j) {
+        if (md_kind_of(s->shape[j].flags) == MD_KIND_VEHICLE) continue;
+        if (j < 64) det_lo &= ~(1ull << j);
+        else det_hi &= ~(1ull << (j - 64));
+    }
+    for (int k = 0; k < c->num_others; ++k) {
+        float* o = out + k * wd;
+        int best = -1;
+        float bd = 3.0e38f;
+        for (int j = 0; j < c->cap && j < 128; ++j) {
+            unsigned long long m = (j < 64) ? det_lo : det_hi;
+            if (!((m >> (j & 63)) & 1ull)) continue;
+            float d = md_norm(me->cx - s->shape[j].cx, me->cy - s->shape[j].cy);
+            if (d < bd) {
+                bd = d;
+                best = j;
+            }
+        }
+        if (best < 0 || !md_present(me->flags)) {
+            for (int i = 0; i < wd; ++i) o[i] = 0.0f;
+            continue;
+        }
+        if (best < 64) det_lo &= ~(1ull << best);
+        else det_hi &= ~(1ull << (best - 64));
+        const MdShape* v = &s->shape[best];
+        md_others_project(v->cx - me->cx, v->cy - me->cy, me->c, me->s, R, &o[0], &o[1]);
+        float ov = s->dyn[best].speed * 3.6f;
+        md_others_project(ov * v->c - ego_v * me->c, ov * v->s - ego_v * me->s, me->c, me->s, vmax, &o[2], &o[3]);
+        if (c->add_others_navi) {
+            float c1x = me->cx, c1y = me->cy, c2x = me->cx, c2y = me->cy;
+            if (s->nav[best].route_len >= 2 && s->route_roads[(size_t)best * MD_ROUTE_LEN + s->nav[best].ck0] >= 0)
+                md_others_ckpt(lanes, roads, s, best, &c1x, &c1y, &c2x, &c2y);
+            float pts[4] = {c1x, c1y, c2x, c2y};
+            for (int q = 0; q < 2; ++q) {
+                float dx = pts[2 * q] - me->cx, dy = pts[2 * q + 1] - me->cy;
+                float nd = md_norm(dx, dy);
+                if (nd > R) { /* _project_to_vehicle_system, lidar.py:85-91 */
+                    dx = dx / nd * R;
+                    dy = dy / nd * R;
+                }
+                md_others_project(dx, dy, me->c, me->s, R, &o[4 + 2 * q], &o[5 + 2 * q]);
+            }
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -250,6 +250,10 @@ typedef struct MdState {
     int32_t* env_steps;        /* [n_envs] engine.episode_step                                   */
     int32_t* agent_id;         /* [N] running agent number held by the slot ("agent{k}")          */
     int32_t* next_agent_id;    /* [n_envs] VehicleAgentManager.next_agent_count                   */
+    /* optional (NULL = not wanted; required when MdConfig.num_others > 0) */
+    uint64_t* detected;        /* [n_envs * agents_per_env][2] bit j of the 128-bit set: some beam of the agent's lidar
+                                  hit the mover in slot j first -- the `detected_objects` half of Lidar.perceive's
+                                  return value (component/sensors/lidar.py:49-73); written by md_step           */
 } MdState;
 
 typedef struct MdConfig {

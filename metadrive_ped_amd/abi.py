@@ -89,6 +89,7 @@ class MdState(C.Structure):
         ("step_info", P), ("need_reset", P), ("shape0", P), ("dyn0", P), ("nav0", P), ("pid0", P),
         ("route_nodes0", P), ("route_roads0", P), ("final_lane0", P), ("rng", P), ("env_steps", P), ("agent_id", P),
         ("next_agent_id", P),
+        ("detected", P),
     ]
 
 

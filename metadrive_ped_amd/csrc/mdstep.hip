@@ -86,8 +86,9 @@ __device__ __forceinline__ int wave_min_i(int v, bool valid, int none) {
 // ------------------------------------------------------------------------------------------------
 // Lidar for one (agent, sector) work item, executed by one wave.
 // ------------------------------------------------------------------------------------------------
+// det: LDS words [2] of agent a's detected set (nullptr = not tracked)
 __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int a, int sec, int lane,
-                           float* __restrict__ out_row) {
+                           float* __restrict__ out_row, unsigned long long* det) {
     const MdShape me = s.shape[a];  // wave-uniform (s is the env-local, LDS-staged view)
     const int beam = sec * 64 + lane;
     const bool valid = beam < c.n_beams;
@@ -138,6 +139,7 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
     const float way = ay * me.c + ax * me.s;
 
     float best = 1.0f;
+    int best_j = -1;  // slot of the body this beam hits first (tracked only when det != nullptr)
     for (int j0 = 0; j0 < c.cap; j0 += 64) {
         const int j = j0 + lane;
         MdShape o;
@@ -171,22 +173,41 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
             const float ohl = bcast_f(o.hl, k), ohw = bcast_f(o.hw, k);
             const int ofl = bcast_i(o.flags, k);
             const float t = md_ray_shape(me.cx, me.cy, dirx, diry, ocx, ocy, oc, os, ohl, ohw, md_kind_of(ofl));
-            if (t < best) best = t;
+            if (t < best) {
+                best = t;
+                best_j = j0 + k;  // candidates come in ascending slot order: equal fractions keep the lowest slot
+            }
         }
     }
     if (valid) out_row[beam] = best;
+    if (det) {
+        // union of the 64 beams' first hits: peel one distinct slot per iteration (<= a handful)
+        unsigned long long todo = __ballot(valid && best_j >= 0);
+        unsigned long long lo = 0ull, hi = 0ull;
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            const int jj = bcast_i(best_j, k);
+            todo &= ~__ballot(best_j == jj);
+            if (jj < 64) lo |= 1ull << jj;
+            else hi |= 1ull << (jj - 64);
+        }
+        if (lane == 0) {
+            if (lo) atomicOr(&det[0], lo);
+            if (hi) atomicOr(&det[1], hi);
+        }
+    }
 }
 
 // (Keeping the sectors off the wave that runs the agent's observe chain was tried: 154 vs 145 us, worse.)
 __device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
-                            float* out, int out_stride, int out_offset) {  // `out` is the GLOBAL output base
+                            float* out, int out_stride, int out_offset, unsigned long long* l_det) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
     const int nsec = (c.n_beams + 63) >> 6;
     const int items = c.agents_per_env * nsec;
     for (int it = wave; it < items; it += kWaves) {
         const int a = it / nsec, sec = it - a * nsec;
         float* row = out + (size_t)(e * c.agents_per_env + a) * out_stride + out_offset;
-        lidar_item(w, s, c, a, sec, lane, row);
+        lidar_item(w, s, c, a, sec, lane, row, l_det ? l_det + 2 * a : nullptr);
     }
 }
 
@@ -714,6 +735,8 @@ __global__ __launch_bounds__(MD_ENV_BLOCK) void env_kernel(MdWorld w, MdState g,
     float* l_scratch = reinterpret_cast<float*>(l_roads + n_stage_roads) + wave * 48;  // per-wave observe results
     MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + n_stage_roads) + kWaves * 48);
     int32_t* l_final = reinterpret_cast<int32_t*>(l_param + cap);
+    unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
+    const bool track_det = (PH == PH_ALL) && g.detected != nullptr;
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
     constexpr bool kLidarOnly = (PH == PH_LIDAR);
@@ -750,6 +773,8 @@ __global__ __launch_bounds__(MD_ENV_BLOCK) void env_kernel(MdWorld w, MdState g,
             l_flags[j] = gv.flags[j];
             l_final[j] = gv.final_lane ? gv.final_lane[j] : 0;
         }
+        if (track_det)
+            for (int j = tid; j < 2 * c.agents_per_env; j += kBlock) l_det[j] = 0ull;
     }
     const bool do_reset = reset_flag != 0;  // block-uniform
     const int just_reset = do_reset ? 1 : 0;
@@ -843,7 +868,7 @@ __global__ __launch_bounds__(MD_ENV_BLOCK) void env_kernel(MdWorld w, MdState g,
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
     if (PH & PH_LIDAR) {
-        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset);
+        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr);
     }
 
     MD_STAMP_AT(9);
@@ -867,9 +892,23 @@ __global__ __launch_bounds__(MD_ENV_BLOCK) void env_kernel(MdWorld w, MdState g,
             }
             if ((PH & (PH_RESET | PH_LOCALIZE | PH_CONTACTS | PH_OBSERVE | PH_LIFECYCLE)) || respawns) gv.flags[j] = l_flags[j];
         }
+        if (track_det)
+            for (int j = tid; j < 2 * c.agents_per_env; j += kBlock) gv.detected[j] = l_det[j];
         if (do_reset && tid == 0) gv.need_reset[0] = 0;
     }
     MD_STAMP_AT(11);
+}
+
+// "Others" block of the observation (Lidar.get_surrounding_vehicles_info): one thread per agent, after the
+// step kernel has written the detected sets and the new state back.  Off in the headline configs.
+__global__ __launch_bounds__(64) void others_kernel(MdWorld w, MdState g, MdConfig c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_envs * c.agents_per_env) return;
+    const int e = i / c.agents_per_env, a = i - e * c.agents_per_env;
+    const MdState s = md_env_view(&g, &c, e);
+    const int m = w.env_map[e];
+    md_others_block(w.lanes + w.lane_off[m], w.roads + w.road_off[m], &s, &c, a, s.detected[2 * a], s.detected[2 * a + 1],
+                    s.obs + (size_t)a * c.obs_dim + md_obs_others(&c));
 }
 
 __global__ void probe_kernel(int op, const float* a, const float* b, float* out, int n) {
@@ -921,7 +960,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
-                       4 * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16;
+                       4 * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8;
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
@@ -1209,7 +1248,21 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
         snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim, md_obs_lidar(c), c->n_beams);
         return MD_EINVAL;
     }
-    return launch<PH_ALL>(w, s, c, s->obs, c->obs_dim, md_obs_lidar(c), stream);
+    if (c->num_others < 0 || c->num_others > 16 || (c->num_others > 0 && c->n_beams <= 0)) {
+        snprintf(g_err, sizeof g_err, "num_others=%d needs 0..16 and the lidar on", c->num_others);
+        return MD_EINVAL;
+    }
+    if (c->num_others > 0) NEED(s->detected);
+    r = launch<PH_ALL>(w, s, c, s->obs, c->obs_dim, md_obs_lidar(c), stream);
+    if (r != MD_OK || c->num_others <= 0) return r;
+    const int n = c->n_envs * c->agents_per_env;
+    hipLaunchKernelGGL(others_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, *w, *s, *c);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
 }
 
 }  // extern "C"

@@ -60,7 +60,11 @@ class HostScene:
         self.n_side = int(vc["side_detector"]["num_lasers"]) if vc["side_detector"]["distance"] > 0 else 0
         self.n_ll = int(vc["lane_line_detector"]["num_lasers"]) if vc["lane_line_detector"]["distance"] > 0 else 0
         self.state_dim = (self.n_side or 2) + 6 + (self.n_ll or 1) + 10   # 19 with both detectors off
-        self.obs_dim = self.state_dim + self.n_beams
+        # "others" block only exists with the lidar on (obs/state_obs.py:172-183)
+        self.num_others = int(vc["lidar"]["num_others"]) if self.n_beams > 0 else 0
+        self.add_others_navi = bool(vc["lidar"]["add_others_navi"]) and self.num_others > 0
+        self.others_dim = self.num_others * (8 if self.add_others_navi else 4)
+        self.obs_dim = self.state_dim + self.others_dim + self.n_beams
         mc = cfg["map_config"]
         seeds = [cfg["start_seed"] + ((cfg["env_seed_offset"] + e) % cfg["num_scenarios"]) for e in range(E)]
         self.seeds = seeds
@@ -154,9 +158,12 @@ class HostScene:
             st["env_steps"] = np.zeros(E, np.int32)
             st["agent_id"] = np.tile(np.arange(cap, dtype=np.int32), E)
             st["next_agent_id"] = np.full(E, A, np.int32)
+        if self.num_others > 0:
+            st["detected"] = np.zeros((E * A, 2), np.uint64)
         self.state = st
         self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
         self.md_config.n_side, self.md_config.n_lane_line = self.n_side, self.n_ll
+        self.md_config.num_others, self.md_config.add_others_navi = self.num_others, int(self.add_others_navi)
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
@@ -223,6 +230,7 @@ class BatchedEngine:
             raise _lib.MdStepError("BatchedEngine needs a ROCm device (config['device']={!r}); there is no CPU "
                                    "fallback".format(cfg["device"]))
         self.host = host
+        self._noise_gen = None
         self.build()
 
     # -- upload helpers ---------------------------------------------------------------------------
@@ -282,6 +290,29 @@ class BatchedEngine:
         if h.n_ll:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
             self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
                                self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, (h.n_side or 2) + 6)
+        self._lidar_noise()
+
+    def _lidar_noise(self):
+        """LidarStateObservation._add_noise_to_cloud_points (obs/state_obs.py:234-244): gaussian noise (clipped to
+        [0,1]) then dropout to 0 on the lidar cloud of the observation.  The reference draws from the global,
+        unseeded numpy stream, so no stream can be 'the' stream; this one is a device generator seeded with
+        start_seed + env_seed_offset (reproducible, shard-dependent)."""
+        lc = self.cfg["vehicle_config"]["lidar"]
+        g, p = float(lc["gaussian_noise"]), float(lc["dropout_prob"])
+        if (g <= 0.0 and p <= 0.0) or self.n_beams <= 0:
+            return
+        torch = self.torch
+        if self._noise_gen is None:
+            self._noise_gen = torch.Generator(device=self.device)
+            self._noise_gen.manual_seed(int(self.cfg["start_seed"]) + int(self.cfg["env_seed_offset"]))
+        cloud = self.obs[..., self.obs_dim - self.n_beams:]
+        if g > 0.0:
+            noise = torch.empty_like(cloud).normal_(0.0, g, generator=self._noise_gen)
+            cloud.copy_((cloud + noise).clamp_(0.0, 1.0))
+        if p > 0.0:
+            assert p <= 1.0
+            drop = torch.empty_like(cloud).uniform_(0.0, 1.0, generator=self._noise_gen) < p
+            cloud.masked_fill_(drop, 0.0)
 
     def line_detector(self, beams, n, dist, mask, out, stride, offset):
         self._check(self.lib.md_line_detector(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(beams.data_ptr()),

@@ -56,7 +56,8 @@ class BatchedMultiAgentRoundaboutEnv:
         vc = self.config["vehicle_config"]
         n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
-        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + 10 + n, ), np.float32)
+        n_o = lidar["num_others"] * (8 if lidar["add_others_navi"] else 4) if n > 0 else 0
+        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + 10 + n_o + n, ), np.float32)
         from metadrive_ped_amd.envs.metadrive_env import make_action_space
         self.action_space = make_action_space(self.config)
         self.engine = None

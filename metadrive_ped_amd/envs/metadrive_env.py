@@ -77,7 +77,8 @@ class BatchedMetaDriveEnv:
         vc = self.config["vehicle_config"]
         n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
-        self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 10 + n
+        n_o = lidar["num_others"] * (8 if lidar["add_others_navi"] else 4) if n > 0 else 0
+        self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 10 + n_o + n
         self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
         self.action_space = make_action_space(self.config)
         self.start_seed = self.config["start_seed"]
@@ -127,6 +128,32 @@ class BatchedMetaDriveEnv:
 
     def close(self):
         self.engine = None
+
+    # -- state checkpoint (the role of BaseEngine/BaseManager get_state / set_state, manager/base_manager.py:116-135,
+    #    and of BaseVehicle.get_state / set_state, component/vehicle/base_vehicle.py:808-846: everything that
+    #    evolves is already a flat array here, so a checkpoint is a dict of numpy arrays) -----------------------
+    def get_state(self):
+        """Every evolving array of the batch (poses, dynamics, navigation, PID, flags, obs, RNG ...) as host numpy
+        arrays, plus the scenario assignment.  set_state() of the result resumes bit-identically."""
+        if self.engine is None:
+            raise RuntimeError("call reset() before get_state()")
+        st = self.engine.download_state()
+        st["__seeds__"] = np.asarray(self.engine.host.seeds, dtype=np.int64)
+        return st
+
+    def set_state(self, state):
+        if self.engine is None:
+            raise RuntimeError("call reset() before set_state()")
+        seeds = np.asarray(state["__seeds__"])
+        if seeds.tolist() != list(self.engine.host.seeds):
+            raise ValueError("the checkpoint was taken with another scenario assignment (start_seed / num_scenarios / "
+                             "env_seed_offset differ): maps and routes would not match")
+        arrays = {k: v for k, v in state.items() if k != "__seeds__"}
+        ref = self.engine.host.state
+        for k, v in arrays.items():
+            if k not in ref or np.asarray(v).nbytes != ref[k].nbytes:
+                raise ValueError("checkpoint array {!r} does not fit this batch".format(k))
+        self.engine.upload_state(arrays)
 
     # -- helpers --------------------------------------------------------------------------------
     def _obs(self):

@@ -44,10 +44,12 @@
  * (constants.py:242-244); beam i direction = heading + 2*pi*i/B (utils/math.py:76-81,
  * distance_detector.py:177-180); own chassis excluded (distance_detector.py:129,60-71).
  * -----------------------------------------------------------------------------------------*/
-static void lidar_agent(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, float* out) {
+static void lidar_agent_det(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, float* out,
+                            unsigned long long det[2]) {
     int base = e * c->cap;
     const MdShape* me = &s->shape[base + a];
     for (int i = 0; i < c->n_beams; ++i) out[i] = 1.0f;
+    det[0] = det[1] = 0ull;
     if (!present(me->flags)) return;
     for (int i = 0; i < c->n_beams; ++i) {
         float bc = w->beam_cs[2 * i], bs = w->beam_cs[2 * i + 1];
@@ -55,15 +57,25 @@ static void lidar_agent(const MdWorld* w, const MdState* s, const MdConfig* c, i
         float dirx = (bc * me->c - bs * me->s) * c->lidar_range;
         float diry = (bs * me->c + bc * me->s) * c->lidar_range;
         float best = 1.0f;
+        int best_j = -1; /* the body the beam hits first (detected_objects; equal fractions -> lowest slot) */
         for (int j = 0; j < c->cap; ++j) {
             if (j == a) continue;
             const MdShape* o = &s->shape[base + j];
             if (!present(o->flags)) continue;
             float t = md_ray_shape(me->cx, me->cy, dirx, diry, o->cx, o->cy, o->c, o->s, o->hl, o->hw, kind_of(o->flags));
-            if (t < best) best = t;
+            if (t < best) {
+                best = t;
+                best_j = j;
+            }
         }
         out[i] = best;
+        if (best_j >= 0 && best_j < 128) det[best_j >> 6] |= 1ull << (best_j & 63);
     }
+}
+
+static void lidar_agent(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, float* out) {
+    unsigned long long det[2];
+    lidar_agent_det(w, s, c, e, a, out, det);
 }
 
 EXPORT int ref_lidar(const MdWorld* w, const MdState* s, const MdConfig* c, float* out, int out_stride, int out_offset) {
@@ -364,8 +376,18 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
     for (int a = 0; a < c->agents_per_env; ++a) {
         MdState v = md_env_view(s, c, e);
         md_observe_agent(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a, just_reset);
-        if (c->n_beams > 0)
-            lidar_agent(w, s, c, e, a, s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim + md_obs_lidar(c));
+        if (c->n_beams > 0) {
+            float* row = s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim;
+            unsigned long long det[2];
+            lidar_agent_det(w, s, c, e, a, row + md_obs_lidar(c), det);
+            if (s->detected) {
+                s->detected[2 * (size_t)(e * c->agents_per_env + a)] = det[0];
+                s->detected[2 * (size_t)(e * c->agents_per_env + a) + 1] = det[1];
+            }
+            if (c->num_others > 0)
+                md_others_block(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a,
+                                det[0], det[1], row + md_obs_others(c));
+        }
     }
 }
 

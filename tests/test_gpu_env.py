@@ -70,3 +70,59 @@ def test_full_size_properties(cs_dist):
         a = finals[0][k].reshape(E, -1)[:sub]
         b = o.state[k].reshape(sub, -1)
         assert a.tobytes() == b.tobytes(), k
+
+
+def test_state_checkpoint_resumes_bit_identically():
+    """get_state / set_state: a checkpoint taken mid-episode and restored later replays the same future
+    (the contract of the reference's record / replay and set_state: same state + same actions -> same result)."""
+    import torch
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    E = 24
+    env = BatchedMetaDriveEnv(dict(num_envs=E, num_scenarios=E, horizon=200, traffic_mode="hybrid", traffic_density=0.15))
+    env.reset()
+    acts = [torch.from_numpy(scripted_actions(E, 1, t, seed=9)[:, 0]).cuda() for t in range(120)]
+    for t in range(40):
+        env.step(acts[t])
+    ck = env.get_state()
+    first = []
+    for t in range(40, 120):
+        obs, r, term, trunc, _ = env.step(acts[t])
+        first.append((obs.cpu().numpy().copy(), r.cpu().numpy().copy(), term.cpu().numpy().copy()))
+    env.set_state(ck)
+    for i, t in enumerate(range(40, 120)):
+        obs, r, term, trunc, _ = env.step(acts[t])
+        assert obs.cpu().numpy().tobytes() == first[i][0].tobytes(), "obs diverged at step %d" % t
+        assert r.cpu().numpy().tobytes() == first[i][1].tobytes()
+        assert (term.cpu().numpy() == first[i][2]).all()
+    bad = dict(ck)
+    bad["__seeds__"] = ck["__seeds__"] + 1
+    with pytest.raises(ValueError):
+        env.set_state(bad)
+
+
+def test_discrete_actions_and_lidar_noise():
+    """Discrete action grid drives the same path as the continuous action it maps to; lidar noise / dropout touch
+    only the cloud dims of the observation (obs/state_obs.py:225-244)."""
+    import torch
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    E = 8
+    base = dict(num_envs=E, num_scenarios=E, horizon=100)
+    a = BatchedMetaDriveEnv(dict(base, discrete_action=True, discrete_steering_dim=3, discrete_throttle_dim=5))
+    b = BatchedMetaDriveEnv(dict(base))
+    a.reset()
+    b.reset()
+    idx = torch.tensor([13] * E)                     # 13 -> steering 13 % 3 = 1 -> 0.0 ; throttle 13 // 3 = 4 -> 1.0
+    for t in range(30):
+        oa, ra, *_ = a.step(idx)
+        ob_, rb, *_ = b.step(torch.tensor([[0.0, 1.0]] * E))
+    assert oa.cpu().numpy().tobytes() == ob_.cpu().numpy().tobytes()
+    n = BatchedMetaDriveEnv(dict(base, vehicle_config=dict(lidar=dict(gaussian_noise=0.05, dropout_prob=0.1))))
+    n.reset()
+    for t in range(30):
+        on, *_ = n.step(torch.tensor([[0.0, 1.0]] * E))
+    on, ob_ = on.cpu().numpy(), ob_.cpu().numpy()
+    assert np.array_equal(on[:, :19], ob_[:, :19])                       # state + navi dims untouched
+    cloud = on[:, 19:]
+    assert (cloud >= 0).all() and (cloud <= 1).all()
+    assert 0.05 < (cloud == 0.0).mean() < 0.2                            # ~10 % dropped
+    assert not np.array_equal(cloud, ob_[:, 19:])

@@ -270,3 +270,41 @@ def test_traffic_respawn_modes(mode):
         if not st["need_reset"].any():
             assert (alive.sum(1) == n0).all(), "traffic count is conserved in %s mode" % mode
     assert seen > 0
+
+
+def test_others_block_of_the_observation(cs_dist):
+    """lidar num_others (Lidar.get_surrounding_vehicles_info, component/sensors/lidar.py:93-138): the nearest
+    DETECTED vehicles, nearest first, described in the ego frame; absent entries are zeros; the cloud follows."""
+    from metadrive_ped_amd.engine import HostScene
+    E, K = 6, 4
+    cfg = make_cfg(cs_dist, num_envs=E, num_scenarios=E, traffic_density=0.3,
+                   vehicle_config=dict(lidar=dict(num_lasers=240, distance=50, num_others=K, add_others_navi=True)))
+    host = HostScene(cfg)
+    assert host.obs_dim == 19 + 8 * K + 240
+    o = ob.OracleWorld(host)
+    o.reset()
+    seen = 0
+    for t in range(150):
+        o.step(np.tile(np.array([0.0, 0.6], np.float32), (E, 1, 1)))
+        obs = o.obs
+        assert (obs >= 0).all() and (obs <= 1).all()
+        others = obs[:, 19:19 + 8 * K].reshape(E, K, 8)
+        det = o.state["detected"].reshape(E, 2)
+        sh = o.state["shape"].reshape(E, -1)
+        for e in range(E):
+            ids = [j for j in range(host.cap) if (int(det[e, j >> 6]) >> (j & 63)) & 1]
+            assert 0 not in ids                                           # the ego's own chassis is filtered out
+            veh = [j for j in ids if (sh["flags"][e, j] & abi.KIND_MASK) == abi.KIND_VEHICLE]
+            d = sorted(math.hypot(sh["cx"][e, j] - sh["cx"][e, 0], sh["cy"][e, j] - sh["cy"][e, 0]) for j in veh)
+            n = min(K, len(veh))
+            assert (others[e, n:] == 0).all()
+            for k in range(n):
+                seen += 1
+                fwd = (others[e, k, 0] * 2 - 1) * 50.0
+                left = (others[e, k, 1] * 2 - 1) * 50.0
+                assert abs(math.hypot(fwd, left) - min(d[k], 50 * math.sqrt(2))) < 1e-2 or d[k] > 50.0
+            # every detected body really is within lidar reach
+            for j in ids:
+                r = math.hypot(sh["hl"][e, j], sh["hw"][e, j])
+                assert math.hypot(sh["cx"][e, j] - sh["cx"][e, 0], sh["cy"][e, j] - sh["cy"][e, 0]) <= 50.0 + r + 1e-3
+    assert seen > 50
