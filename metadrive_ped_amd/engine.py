@@ -22,16 +22,20 @@ STATE_ARRAY_SPECS = None  # filled below
 
 
 def _build_marl(cfg, scene_cfg, uniq):
-    """Multi-agent roundabout: one shared map, one scene per env seed."""
-    from metadrive_ped_amd.mapgen.pg import MARoundaboutMap
-    from metadrive_ped_amd.marl import ROUNDABOUT_SPAWN_ROADS, RoundaboutScene
+    """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
+    from metadrive_ped_amd.mapgen.pg import MAIntersectionMap, MARoundaboutMap
+    from metadrive_ped_amd.marl import SPAWN_ROADS, RoundaboutScene
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     mc = cfg["map_config"]
-    pg = MARoundaboutMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
+    kind = cfg["marl_map"]
+    if kind not in SPAWN_ROADS:
+        raise NotImplementedError("multi-agent map {!r} is not built (built: {})".format(kind, sorted(SPAWN_ROADS)))
+    cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]
+    pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
     mt = MapTables(pg)
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
-    scenes = {s: RoundaboutScene(s, mt, sc_cfg) for s in uniq}
-    return mt, scenes, spawn_tables(mt, ROUNDABOUT_SPAWN_ROADS, mc["lane_num"])
+    scenes = {s: RoundaboutScene(s, mt, sc_cfg, SPAWN_ROADS[kind]) for s in uniq}
+    return mt, scenes, spawn_tables(mt, SPAWN_ROADS[kind], mc["lane_num"])
 
 
 def _build_one(job):

@@ -129,3 +129,19 @@ class BatchedMultiAgentRoundaboutEnv:
 
     def close(self):
         self.engine = None
+
+
+class BatchedMultiAgentIntersectionEnv(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentIntersectionEnv (envs/marl_envs/marl_intersection.py:11-110): 30 agents on a 4-way intersection
+    with U-turns, spawn roads = the four arms, destination = a random arm (its own included)."""
+    MAP_DEFAULTS = dict(marl_map="intersection", num_agents=30, map_config=dict(exit_length=60, lane_num=2))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)

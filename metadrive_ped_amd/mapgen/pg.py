@@ -504,9 +504,21 @@ class InterSection(Block):
     EXIT_PART_LENGTH = 35
     EXTRA_PART = "extra"
 
+    u_turn = False   # enable_u_turn (intersection.py:249-250): the multi-agent intersection map switches it on
+
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self.radius = self.config["radius"]
+
+    def _u_turn(self, attach_lanes, attach_road):
+        """_create_u_turn (intersection.py:223-247): a half circle of radius lane_width / 2 from the left-most
+        incoming lane onto the road running the other way."""
+        left = attach_lanes[0]
+        bend, _ = bend_then_straight(left, 0.1, self.lane_width / 2, np.deg2rad(180), False, left.width,
+                                     (LINE_NONE, LINE_NONE))
+        create_road_from(bend, len(attach_lanes), (attach_road[1], negate_road(*attach_road)[0]), self.net, self.global_net,
+                         toward_smaller=False, center_line_type=LINE_NONE, side_lane_line_type=LINE_NONE,
+                         inner_lane_line_type=LINE_NONE)
 
     def road_node(self, part, idx):
         return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
@@ -551,6 +563,8 @@ class InterSection(Block):
         ok = True
         left = attach_lanes[0]
         self._left_turn(radius, lane_num, left, attach_road, nodes, part_idx)
+        if self.u_turn:
+            self._u_turn(attach_lanes, attach_road)
         lanes_on_road = list(attach_lanes)
         straight_len = 2 * radius + (2 * lane_num - 1) * lanes_on_road[0].width
         for l in lanes_on_road:
@@ -811,6 +825,29 @@ class MARoundaboutMap:
     bfs_route = None  # bound below
 
 
+class MAIntersectionMap:
+    """FirstPGBlock + one InterSection (seed 1, U-turns on): the map of MultiAgentIntersectionEnv
+    (envs/marl_envs/marl_intersection.py:27-70)."""
+    def __init__(self, lane_num=2, lane_width=3.5, exit_length=60):
+        if lane_num < 2:
+            raise NotImplementedError("the one-lane multi-agent intersection (U-turns off, spawn road excluded from the "
+                                      "destinations) is not built")
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        x = InterSection(1, list(first.sockets.values())[0], self.net, 1)
+        x.EXIT_PART_LENGTH = exit_length
+        x.u_turn = True
+        x.construct()
+        self.blocks = [first, x]
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
 class PGMap:
     """The BIG search (component/algorithm/BIG.py:27-165) driven to completion."""
     MAX_TRIAL = 5
@@ -917,3 +954,4 @@ def bfs_route(net, start_node, goal):
 
 
 MARoundaboutMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+MAIntersectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

@@ -1,4 +1,4 @@
-"""Multi-agent roundabout: scene construction (host) for MultiAgentRoundaboutEnv.
+"""Multi-agent maps: scene construction (host) for MultiAgentRoundaboutEnv / MultiAgentIntersectionEnv.
 
 Restates the reset-time part of envs/marl_envs/marl_inout_roundabout.py + manager/spawn_manager.py:
 one fixed map (FirstPGBlock 60 m, 2 lanes + Roundabout exit 10 / inner 30 / angle 70), 4 spawn roads x 2
@@ -22,13 +22,19 @@ from metadrive_ped_amd.scene import vehicle_param_record
 
 ROUNDABOUT_SPAWN_ROADS = [(">>", ">>>"), negate_road("1O0_2_", "1O0_3_"), negate_road("1O1_2_", "1O1_3_"),
                           negate_road("1O2_2_", "1O2_3_")]
+# MAIntersectionConfig.spawn_roads (envs/marl_envs/marl_intersection.py:13-18)
+INTERSECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("1X0_0_", "1X0_1_"), negate_road("1X1_0_", "1X1_1_"),
+                            negate_road("1X2_0_", "1X2_1_")]
+SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 
 
 class RoundaboutScene:
-    """Per-env arrays (cap == num_agents slots, all agents) for one env seed."""
-    def __init__(self, seed, mt, cfg):
+    """Per-env arrays (cap == num_agents slots, all agents) for one env seed.  `spawn_roads` selects the map
+    family (the roundabout's by default); everything else is SpawnManager's and shared."""
+    def __init__(self, seed, mt, cfg, spawn_roads=None):
+        ROUNDABOUT_SPAWN_ROADS = spawn_roads if spawn_roads is not None else globals()["ROUNDABOUT_SPAWN_ROADS"]
         A = cfg["agents_per_env"]
         cap = cfg["cap"]
         assert cap >= A

@@ -407,6 +407,38 @@ def section_roundabout():
                                  config={k: float(v) for k, v in dict(rb.get_config()).items()}))
 
 
+def section_ma_intersection():
+    """Map of MultiAgentIntersectionEnv: FirstPGBlock(60 m, 2 lanes) + InterSection with
+    U-turns enabled as MAIntersectionMap._generate builds it (marl_intersection.py:27-70), spawn roads, routes."""
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.intersection import InterSection
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_intersection import MAIntersectionConfig
+    from metadrive.manager.spawn_manager import SpawnManager
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, 2, MagicMock(), MagicMock(), length=60)
+    InterSection.EXIT_PART_LENGTH = 60
+    blk = InterSection(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    blk.enable_u_turn(True)
+    ok = blk.construct_block(MagicMock(), MagicMock())
+    InterSection.EXIT_PART_LENGTH = 35
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+    spawn_roads = [[r.start_node, r.end_node] for r in MAIntersectionConfig["spawn_roads"]]
+    routes = []
+    for sr in MAIntersectionConfig["spawn_roads"]:
+        for er in MAIntersectionConfig["spawn_roads"]:
+            dest = (-er).end_node
+            path = net.shortest_path((sr.start_node, sr.end_node, 0), dest)
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest, path=path))
+    dump("ma_intersection.json", dict(no_cross=bool(ok), roads=roads, spawn_roads=spawn_roads, routes=routes,
+                                      max_capacity=int(SpawnManager.max_capacity(MAIntersectionConfig["spawn_roads"], 60, 2)),
+                                      num_agents=int(MAIntersectionConfig["num_agents"]),
+                                      config={k: float(v) for k, v in dict(blk.get_config()).items()}))
+
+
 def section_idm():
     """IDM longitudinal model, desired gap, PID steering and the front/back object search
     (SURVEY 8a-10): IDMPolicy.acceleration / desired_gap / steering_control and
@@ -531,7 +563,7 @@ def section_pg_maps_v2():
     dump("pg_maps_v2.json", dict(cases=cases))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2)
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

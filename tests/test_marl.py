@@ -148,3 +148,82 @@ def test_marl_env_api_gpu():
     o, rr, tmd, tcd = env.to_dicts(0, obs, r, tm, tc, info)
     assert set(o.keys()) == set(rr.keys()) == (set(tmd.keys()) - {"__all__"})   # key-set consistency (test_ma_roundabout_env)
     assert all(k.startswith("agent") for k in o)
+
+
+# ---- multi-agent intersection (envs/marl_envs/marl_intersection.py) -------------------------
+def _inter_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentIntersectionEnv
+    base = dict(num_envs=3, num_scenarios=3)
+    base.update(kw)
+    return BatchedMultiAgentIntersectionEnv(base).config
+
+
+def test_intersection_map_equals_reference():
+    from metadrive_ped_amd.mapgen.pg import MAIntersectionMap
+    from metadrive_ped_amd.marl import INTERSECTION_SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_intersection.json")) as f:
+        g = json.load(f)
+    m = MAIntersectionMap()
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]      # incl. the 4 U-turn roads
+    for (a, b, lanes), ref in zip(roads, g["roads"]):
+        assert len(lanes) == len(ref["lanes"])
+        for l, rl in zip(lanes, ref["lanes"]):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+            np.testing.assert_allclose([l.length, *l.start, *l.end], [rl["length"], *rl["start"], *rl["end"]], atol=1e-9)
+    assert [list(r) for r in INTERSECTION_SPAWN_ROADS] == g["spawn_roads"]
+    for r in g["routes"]:
+        assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    assert g["max_capacity"] == 48 and g["num_agents"] == 30
+    assert m.blocks[1].config["radius"] == g["config"]["radius"]
+    with pytest.raises(NotImplementedError):
+        MAIntersectionMap(lane_num=1)
+
+
+def test_intersection_lifecycle_on_oracle():
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 2, 30
+    cfg = _inter_cfg(num_envs=E, num_scenarios=E)
+    assert cfg["num_agents"] == A and cfg["marl_map"] == "intersection"
+    host = HostScene(cfg)
+    assert host.cap == A and host.obs_dim == 19 + 72
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert (_counts(o.state, E)[0] == A).all()
+    rng = np.random.RandomState(5)
+    arrived = 0
+    for t in range(400):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.6
+        a[..., 0] = rng.uniform(-0.2, 0.2, (E, A))
+        o.step(a)
+        act, dy = _counts(o.state, E)
+        assert ((act + dy) <= A).all()
+        arrived += int(((o.state["flags"].reshape(E, -1)[:, :A] & abi.FL_ARRIVE_DEST) != 0).sum())
+        obs = o.obs.reshape(E, A, -1)
+        assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+    assert (o.state["next_agent_id"] > A).all()                        # respawns happened
+
+
+@pytest.mark.gpu
+def test_intersection_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 6, 30
+    eng = BatchedEngine(_inter_cfg(num_envs=E, num_scenarios=E))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="intersection reset")
+    rng = np.random.RandomState(8)
+    for t in range(250):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.7
+        a[..., 0] = rng.uniform(-0.3, 0.3, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="intersection step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="intersection final")
+    assert (orc.state["next_agent_id"] > A).all()
