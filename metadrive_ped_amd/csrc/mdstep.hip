@@ -104,37 +104,18 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
     const float dirx = (bc * me.c - bs * me.s) * c.lidar_range;
     const float diry = (bs * me.c + bc * me.s) * c.lidar_range;
 
-    // sector cone: axis = direction of the middle of the sector, half-span h (conservative cull only)
+    // Sector cone for culling: axis = middle of the sector's beam fan, half-span h.  The cull is only ever
+    // CONSERVATIVE (2e-3 slack on the cosine, 1 cm on the radii), so it runs on the hardware's approximate
+    // rcp / rsq / sqrt / sin / cos (1 ulp, v_sin/v_cos take revolutions); the cast below stays exact.
     const int nb = min(64, c.n_beams - sec * 64);
-    const int first = sec * 64, last = first + nb - 1;
-    // axis from the sum of the first and last beam directions (exact bisector), ego frame -> world
-    float ax = w.beam_cs[2 * first] + w.beam_cs[2 * last];
-    float ay = w.beam_cs[2 * first + 1] + w.beam_cs[2 * last + 1];
-    float cos_h;  // cos of half-span
-    {
-        float dotfl = w.beam_cs[2 * first] * w.beam_cs[2 * last] + w.beam_cs[2 * first + 1] * w.beam_cs[2 * last + 1];
-        // span = angle(first,last) could exceed pi: count beams instead
-        float span = MD_TWO_PI_F * (float)(nb - 1) / (float)c.n_beams;
-        float sh_, ch_;
-        md_sincos(0.5f * span, &sh_, &ch_);
-        cos_h = ch_;
-        if (span > MD_PI_F) {  // bisector of first/last points the wrong way
-            ax = -ax;
-            ay = -ay;
-        }
-        (void)dotfl;
-        float an = md_norm(ax, ay);
-        if (an < 1e-6f) {  // span == pi exactly: use the middle beam
-            int mid = (first + last) / 2;
-            ax = w.beam_cs[2 * mid];
-            ay = w.beam_cs[2 * mid + 1];
-            an = 1.0f;
-        }
-        ax /= an;
-        ay /= an;
-    }
-    const float sin_h = md_sqrt(md_max(0.0f, 1.0f - cos_h * cos_h));
-    const float half_span = MD_TWO_PI_F * (float)(nb - 1) / (float)c.n_beams * 0.5f;
+    const float inv_n = __builtin_amdgcn_rcpf((float)c.n_beams);
+    const float mid_rev = ((float)(sec * 64) + 0.5f * (float)(nb - 1)) * inv_n;   // axis angle, in revolutions, ego frame
+    const float half_rev = 0.5f * (float)(nb - 1) * inv_n;
+    const float ax = __builtin_amdgcn_cosf(mid_rev), ay = __builtin_amdgcn_sinf(mid_rev);
+    const float cos_h = __builtin_amdgcn_cosf(half_rev), sin_h = __builtin_amdgcn_sinf(half_rev);
+    const float half_span = MD_TWO_PI_F * half_rev;
+    // cone test is meaningful only while h + asin(rb/dist) < pi; asin <= pi/2, so narrow sectors never need the check
+    const bool narrow = half_span < MD_HALF_PI_F - 0.02f;
     const float wax = ax * me.c - ay * me.s;  // axis in world frame
     const float way = ay * me.c + ax * me.s;
 
@@ -148,18 +129,19 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
         bool keep = (j < c.cap) && (j != a) && md_present(o.flags);
         if (keep) {
             const float ddx = o.cx - me.cx, ddy = o.cy - me.cy;
-            const float dist = md_norm(ddx, ddy);
+            const float d2 = ddx * ddx + ddy * ddy;
             const int k = md_kind_of(o.flags);
-            const float rb = (md_is_circle_kind(k) ? o.hl : md_norm(o.hl, o.hw)) + 0.01f;
-            if (dist > c.lidar_range + rb) keep = false;
-            else if (dist > rb) {
-                // cone test: angle(d, axis) <= half_span + asin(rb/dist)
-                const float sin_a = rb / dist;
-                const float cos_a = md_sqrt(md_max(0.0f, 1.0f - sin_a * sin_a));
-                const float asin_a = md_asin(sin_a);
-                if (half_span + asin_a < MD_PI_F - 0.01f) {
+            const float rb = (md_is_circle_kind(k) ? o.hl : __builtin_amdgcn_sqrtf(o.hl * o.hl + o.hw * o.hw)) + 0.01f;
+            const float reach = c.lidar_range + rb;
+            if (d2 > reach * reach * 1.0001f) keep = false;
+            else if (d2 > rb * rb) {
+                // cone test: angle(d, axis) <= h + alpha, sin(alpha) = rb / dist
+                const float inv = __builtin_amdgcn_rsqf(d2);
+                const float sin_a = rb * inv;
+                const float cos_a = __builtin_amdgcn_sqrtf(md_max(0.0f, 1.0f - sin_a * sin_a));
+                if (narrow || half_span + md_asin(md_min(sin_a, 1.0f)) < MD_PI_F - 0.01f) {
                     const float cos_lim = cos_h * cos_a - sin_h * sin_a;  // cos(h + alpha)
-                    const float cos_t = (ddx * wax + ddy * way) / dist;
+                    const float cos_t = (ddx * wax + ddy * way) * inv;
                     if (cos_t < cos_lim - 2e-3f) keep = false;
                 }
             }
