@@ -96,8 +96,14 @@ class HostScene:
             # reset-time host work only; fork BEFORE this process has touched the GPU (HostScene is built
             # ahead of the first device allocation in BatchedEngine.build)
             import multiprocessing as mp
-            with mp.get_context("fork").Pool(workers) as pool:
+            # close + join, not the context manager's terminate(): under rocprofv3 --pmc the profiler's signal
+            # handler rides along into the forked workers and a SIGTERM there can hang the whole run
+            pool = mp.get_context("fork").Pool(workers)
+            try:
                 built = pool.map(_build_one, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
+            finally:
+                pool.close()
+                pool.join()
         else:
             built = [_build_one(j) for j in jobs]
         for s, (mt, sc) in zip(uniq, built):
