@@ -358,8 +358,13 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         MdState v = md_env_view(s, c, e);
         md_lifecycle_env(w, &v, c, w->env_map[e]);
     }
+    /* Single-agent envs plan the traffic one step ahead: IDMPolicy.act of step t+1 sees exactly the state the
+     * end of step t leaves (traffic_manager.before_step runs before anything moves), so taking the decision at
+     * the end of step t gives the same trajectories; the HIP kernel uses that to overlap it with the agent's
+     * observation.  Multi-agent envs keep the reference order (respawns at the start of a step come first). */
+    const int plan_ahead = !c->is_multi_agent;
     if (!just_reset) {
-        idm_env(w, s, c, e);
+        if (!plan_ahead) idm_env(w, s, c, e);
         for (int j = 0; j < c->cap; ++j) md_integrate_mover(s, c, base + j);
     }
     for (int j = 0; j < c->cap; ++j) localize_mover(w, s, c, e, base + j);
@@ -373,6 +378,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         MdState v = md_env_view(s, c, e);
         md_traffic_respawn_env(w, w->lanes + w->lane_off[w->env_map[e]], &v, c, w->env_map[e]);
     }
+    if (plan_ahead) idm_env(w, s, c, e);
     for (int a = 0; a < c->agents_per_env; ++a) {
         MdState v = md_env_view(s, c, e);
         md_observe_agent(w->lanes + w->lane_off[w->env_map[e]], w->roads + w->road_off[w->env_map[e]], &v, c, a, just_reset);
