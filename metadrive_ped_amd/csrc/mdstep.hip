@@ -737,7 +737,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     const int reset_flag = (PH & PH_RESET) ? gv.need_reset[0] : 0;
 
     MD_STAMP_AT(0);
-    copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
     const MdLane* lanes;
     const MdRoad* roads;
     if (STAGE_MAP) {
@@ -747,7 +746,65 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         lanes = w.lanes + w.lane_off[w.env_map[e]];
         roads = w.roads + w.road_off[w.env_map[e]];
     }
-    if (!kLidarOnly) {
+    if (kLidarOnly) {
+        copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
+    } else if (kBlock == 256) {
+        // Fast path: ALL global loads of the stage-in are issued before the first LDS store, so the whole image
+        // arrives in one memory round trip (a chain of copy loops waits for each loop's loads in turn: 7 trips,
+        // ~9 k cycles per env).  16-B units per array at cap <= 128: shape/dyn/pid/param <= 256 (one per thread),
+        // nav <= 512, routes <= 1536: the first 256 / 512 units go through registers, the rest (cap > 64 / > 42) in tail loops.
+        const int n32 = cap * 2, n64 = cap * 4, nrr = cap * (MD_ROUTE_LEN / 4);
+        const uint4* g_shape = reinterpret_cast<const uint4*>(gv.shape);
+        const uint4* g_dyn = reinterpret_cast<const uint4*>(gv.dyn);
+        const uint4* g_pid = reinterpret_cast<const uint4*>(gv.pid);
+        const uint4* g_param = reinterpret_cast<const uint4*>(gv.param);
+        const uint4* g_nav = reinterpret_cast<const uint4*>(gv.nav);
+        const uint4* g_rr = reinterpret_cast<const uint4*>(gv.route_roads);
+        uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_rr0, r_rr1;
+        float2 r_act;
+        uint32_t r_fl;
+        int r_fin;
+        const bool p32 = tid < n32, pc = tid < cap;
+        if (p32) {
+            r_shape = g_shape[tid];
+            r_dyn = g_dyn[tid];
+            r_pid = g_pid[tid];
+            r_param = g_param[tid];
+        }
+        if (tid < n64) r_nav0 = g_nav[tid];
+        if (tid < nrr) r_rr0 = g_rr[tid];
+        if (tid + 256 < nrr) r_rr1 = g_rr[tid + 256];
+        if (pc) {
+            r_act = reinterpret_cast<const float2*>(gv.action)[tid];
+            r_fl = gv.flags[tid];
+            r_fin = gv.final_lane ? gv.final_lane[tid] : 0;
+        }
+        if (STAGE_MAP) {
+            const int m = w.env_map[e];
+            const int lo = w.lane_off[m], ro = w.road_off[m];
+            copy16(l_lanes, w.lanes + lo, (w.lane_off[m + 1] - lo) * (int)sizeof(MdLane), tid, kBlock);
+            copy16(l_roads, w.roads + ro, (w.road_off[m + 1] - ro) * (int)sizeof(MdRoad), tid, kBlock);
+        }
+        if (p32) {
+            reinterpret_cast<uint4*>(l_shape)[tid] = r_shape;
+            reinterpret_cast<uint4*>(l_dyn)[tid] = r_dyn;
+            reinterpret_cast<uint4*>(l_pid)[tid] = r_pid;
+            reinterpret_cast<uint4*>(l_param)[tid] = r_param;
+        }
+        if (tid < n64) reinterpret_cast<uint4*>(l_nav)[tid] = r_nav0;
+        if (tid < nrr) reinterpret_cast<uint4*>(l_rroads)[tid] = r_rr0;
+        if (tid + 256 < nrr) reinterpret_cast<uint4*>(l_rroads)[tid + 256] = r_rr1;
+        for (int i = tid + 256; i < n64; i += 256) reinterpret_cast<uint4*>(l_nav)[i] = g_nav[i];
+        for (int i = tid + 512; i < nrr; i += 256) reinterpret_cast<uint4*>(l_rroads)[i] = g_rr[i];
+        if (pc) {
+            reinterpret_cast<float2*>(l_action)[tid] = r_act;
+            l_flags[tid] = r_fl;
+            l_final[tid] = r_fin;
+        }
+        if (track_det)
+            for (int j = tid; j < 2 * c.agents_per_env; j += kBlock) l_det[j] = 0ull;
+    } else {
+        copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
         if (STAGE_MAP) {
             const int m = w.env_map[e];
             const int lo = w.lane_off[m], ro = w.road_off[m];
@@ -974,7 +1031,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
-                       4 * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8;
+                       (MD_ENV_BLOCK / 64) * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8;
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
