@@ -228,8 +228,10 @@ __device__ __forceinline__ int grid_clampi(int v, int lo, int hi) { return v < l
 // ------------------------------------------------------------------------------------------------
 // Localisation, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
+// onlane_out: nullptr = write the ON_LANE bit into s.flags[n] (stand-alone phase); otherwise store the bare
+// decision there and leave s.flags alone (fused step: contacts run concurrently and own the other bits).
 __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
-                                 int n, int lane_id) {
+                                 int n, int lane_id, uint32_t* onlane_out = nullptr) {
     // n = slot inside the env-local view; lanes / roads = this env's map tables (LDS copies)
     const MdShape sh = s.shape[n];
     if (!md_drives(sh.flags)) return;
@@ -333,9 +335,13 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
     else if (!has_next) lane = best_any;
     else if (best_next >= 0) lane = best_next;
     else lane = best_any;
-    uint32_t fl = s.flags[n] & ~(uint32_t)MD_FL_ON_LANE;
-    if (on_lane) fl |= MD_FL_ON_LANE;
-    s.flags[n] = fl;
+    if (onlane_out) {
+        onlane_out[n] = on_lane ? MD_FL_ON_LANE : 0u;
+    } else {
+        uint32_t fl = s.flags[n] & ~(uint32_t)MD_FL_ON_LANE;
+        if (on_lane) fl |= MD_FL_ON_LANE;
+        s.flags[n] = fl;
+    }
     if (lane < 0) lane = nav.lane;
     s.nav[n].lane = lane;
     if (lane < 0) return;
@@ -357,7 +363,8 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
 // ------------------------------------------------------------------------------------------------
 // Contacts, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
-__device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id) {
+__device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id,
+                                 uint32_t* cfl_out = nullptr) {
     const int base = 0;  // env-local view
     const int n = slot;
     const MdShape me = s.shape[n];
@@ -420,7 +427,10 @@ __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdCon
         const uint32_t bit = 1u << b;
         if (__ballot((fl & bit) != 0) != 0ull) all |= bit;
     }
-    if (lane_id == 0) s.flags[n] = (s.flags[n] & MD_FL_ON_LANE) | all;
+    if (lane_id == 0) {
+        if (cfl_out) cfl_out[n] = all;
+        else s.flags[n] = (s.flags[n] & MD_FL_ON_LANE) | all;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -728,6 +738,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + n_stage_roads) + kWaves * 48);
     int32_t* l_final = reinterpret_cast<int32_t*>(l_param + cap);
     unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
+    uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_det + 2 * c.agents_per_env);  // fused step: localize / contacts results,
+    uint32_t* l_cfl = l_onlane + cap;                                                  // merged into flags afterwards
     const bool track_det = (PH == PH_ALL) && g.detected != nullptr;
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
@@ -895,18 +907,52 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         __syncthreads();
     }
     MD_STAMP_AT(4);
-    if (PH & PH_LOCALIZE) {
-        for (int j = wave; j < cap; j += kWaves) localize_vehicle(w, lanes, roads, s, e, j, lane);
+    if (kFused) {
+        // Localisation and contacts of a vehicle are independent of each other (both only read the integrated
+        // poses and the map), so they share ONE stage: work items = [localize of every driving vehicle, then
+        // contacts of every driving vehicle], dealt round-robin to the waves.  With the usual 1-3 driving
+        // vehicles per env everything fits one round instead of two phases behind two barriers.
+        unsigned long long drv_lo = 0ull, drv_hi = 0ull;  // driving slots (wave-uniform)
+        for (int j0 = 0; j0 < cap; j0 += 64) {
+            const int j = j0 + lane;
+            const unsigned long long mk = __ballot(j < cap && md_drives(s.shape[j < cap ? j : 0].flags));
+            if (j0 == 0) drv_lo = mk;
+            else drv_hi = mk;
+        }
+        const int nd = __popcll(drv_lo) + __popcll(drv_hi);
+        for (int item = wave; item < 2 * nd; item += kWaves) {
+            int k = item < nd ? item : item - nd;  // k-th driving slot
+            unsigned long long lo = drv_lo, hi = drv_hi;
+            int slot = -1;
+            while (k >= 0) {
+                if (lo) {
+                    slot = __ffsll((long long)lo) - 1;
+                    lo &= lo - 1;
+                } else {
+                    slot = 64 + __ffsll((long long)hi) - 1;
+                    hi &= hi - 1;
+                }
+                --k;
+            }
+            if (item < nd) localize_vehicle(w, lanes, roads, s, e, slot, lane, l_onlane);
+            else contacts_vehicle(w, s, c, e, slot, lane, l_cfl);
+        }
         __syncthreads();
-    }
-    MD_STAMP_AT(5);
-    if (PH & PH_CONTACTS) {
-        for (int j = wave; j < cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
-        __syncthreads();
+    } else {
+        if (PH & PH_LOCALIZE) {
+            for (int j = wave; j < cap; j += kWaves) localize_vehicle(w, lanes, roads, s, e, j, lane);
+            __syncthreads();
+        }
+        MD_STAMP_AT(5);
+        if (PH & PH_CONTACTS) {
+            for (int j = wave; j < cap; j += kWaves) contacts_vehicle(w, s, c, e, j, lane);
+            __syncthreads();
+        }
     }
     MD_STAMP_AT(6);
     if (PH & PH_TRAFFIC) {
         for (int j = tid; j < cap; j += kBlock) {
+            if (kFused && md_drives(s.shape[j].flags)) s.flags[j] = l_onlane[j] | l_cfl[j];
             const int f = s.shape[j].flags;
             if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) s.shape[j].flags = f & ~MD_F_ALIVE;
         }
@@ -1031,7 +1077,8 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
-                       (MD_ENV_BLOCK / 64) * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8;
+                       (MD_ENV_BLOCK / 64) * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
+                       (size_t)c->cap * 8;
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
