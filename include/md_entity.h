@@ -54,6 +54,7 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.agent_id = g->agent_id ? g->agent_id + b : 0;
     v.next_agent_id = g->next_agent_id ? g->next_agent_id + e : 0;
     v.detected = g->detected ? g->detected + (size_t)e * c->agents_per_env * 2 : 0;
+    v.agent_action = g->agent_action ? g->agent_action + (size_t)e * c->agents_per_env * 2 : 0;
     return v;
 }
 

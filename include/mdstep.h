@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 2
+#define MD_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -250,6 +250,10 @@ typedef struct MdState {
     int32_t* env_steps;        /* [n_envs] engine.episode_step                                   */
     int32_t* agent_id;         /* [N] running agent number held by the slot ("agent{k}")          */
     int32_t* next_agent_id;    /* [n_envs] VehicleAgentManager.next_agent_count                   */
+    /* optional: this step's agent actions straight from the caller's buffer, [n_envs * agents_per_env][2]
+     * (steering, throttle).  NULL = the agents' actions are already in `action` (slots 0..A-1 of each env).
+     * Saves the scatter into the per-slot array; md_step still writes the sanitised values to `action`. */
+    const float* agent_action;
     /* optional (NULL = not wanted; required when MdConfig.num_others > 0) */
     uint64_t* detected;        /* [n_envs * agents_per_env][2] bit j of the 128-bit set: some beam of the agent's lidar
                                   hit the mover in slot j first -- the `detected_objects` half of Lidar.perceive's

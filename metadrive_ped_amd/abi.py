@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 2
+MD_ABI_VERSION = 3
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -89,6 +89,7 @@ class MdState(C.Structure):
         ("step_info", P), ("need_reset", P), ("shape0", P), ("dyn0", P), ("nav0", P), ("pid0", P),
         ("route_nodes0", P), ("route_roads0", P), ("final_lane0", P), ("rng", P), ("env_steps", P), ("agent_id", P),
         ("next_agent_id", P),
+        ("agent_action", P),
         ("detected", P),
     ]
 

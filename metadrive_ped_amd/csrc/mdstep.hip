@@ -749,6 +749,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     const int reset_flag = (PH & PH_RESET) ? gv.need_reset[0] : 0;
 
     MD_STAMP_AT(0);
+    const bool kFusedAct = (PH == PH_ALL) && gv.agent_action != nullptr;  // md_step only: agents' actions from the caller's buffer
     const MdLane* lanes;
     const MdRoad* roads;
     if (STAGE_MAP) {
@@ -787,7 +788,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         if (tid < nrr) r_rr0 = g_rr[tid];
         if (tid + 256 < nrr) r_rr1 = g_rr[tid + 256];
         if (pc) {
-            r_act = reinterpret_cast<const float2*>(gv.action)[tid];
+            r_act = (kFusedAct && tid < c.agents_per_env) ? reinterpret_cast<const float2*>(gv.agent_action)[tid]
+                                                          : reinterpret_cast<const float2*>(gv.action)[tid];
             r_fl = gv.flags[tid];
             r_fin = gv.final_lane ? gv.final_lane[tid] : 0;
         }
@@ -829,8 +831,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         copy16(l_pid, gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
         copy16(l_param, gv.param, cap * (int)sizeof(MdParam), tid, kBlock);
         for (int j = tid; j < cap; j += kBlock) {
-            l_action[2 * j] = gv.action[2 * j];
-            l_action[2 * j + 1] = gv.action[2 * j + 1];
+            const float* src = (kFusedAct && j < c.agents_per_env) ? gv.agent_action : gv.action;
+            l_action[2 * j] = src[2 * j];
+            l_action[2 * j + 1] = src[2 * j + 1];
             l_flags[j] = gv.flags[j];
             l_final[j] = gv.final_lane ? gv.final_lane[j] : 0;
         }

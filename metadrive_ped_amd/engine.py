@@ -334,8 +334,19 @@ class BatchedEngine:
         a = actions
         if a.dim() == 2:
             a = a.unsqueeze(1)
-        self.action[:, :self.A, :] = a.to(self.device, self.torch.float32)
-        self.step_raw()
+        if tuple(a.shape) != (self.E, self.A, 2):
+            raise ValueError("actions must have shape [{}, {}, 2], got {}".format(self.E, self.A, tuple(a.shape)))
+        if a.dtype != self.torch.float32 or a.device != self.device or not a.is_contiguous():
+            a = a.to(self.device, self.torch.float32).contiguous()
+        # zero-copy: the kernel reads the agents' actions from the caller's tensor (MdState.agent_action) and
+        # writes the sanitised values into the per-slot `action` array itself.  The struct is passed by value at
+        # launch, so the pointer is cleared again right away; the tensor is kept alive until the next step.
+        self._held_actions = a
+        self.s.agent_action = a.data_ptr()
+        try:
+            self.step_raw()
+        finally:
+            self.s.agent_action = None
 
     def call(self, name):
         """Single-phase entry points (parity tests): md_integrate, md_localize, ..."""

@@ -331,6 +331,11 @@ EXPORT int ref_idm(const MdWorld* w, const MdState* s, const MdConfig* c) {
 static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int e) {
     int base = e * c->cap;
     int just_reset = 0;
+    if (s->agent_action) /* this step's agent actions come from the caller's own buffer */
+        for (int a = 0; a < c->agents_per_env; ++a) {
+            s->action[2 * (base + a)] = s->agent_action[2 * (e * c->agents_per_env + a)];
+            s->action[2 * (base + a) + 1] = s->agent_action[2 * (e * c->agents_per_env + a) + 1];
+        }
     if (s->need_reset[e]) {
         memcpy(&s->shape[base], &s->shape0[base], sizeof(MdShape) * c->cap);
         memcpy(&s->dyn[base], &s->dyn0[base], sizeof(MdDyn) * c->cap);

@@ -99,13 +99,18 @@ class OracleWorld:
         assert rc == 0, (name, rc)
 
     def step(self, actions=None, threads=1):
+        self._held = None
         if actions is not None:
-            a = self.state["action"].reshape(self.host.E, self.host.cap, 2)
-            a[:, :self.host.A, :] = np.asarray(actions, np.float32).reshape(self.host.E, self.host.A, 2)
-        if threads > 1:
-            self.call("ref_step_mt", threads)
-        else:
-            self.call("ref_step")
+            # like BatchedEngine.step: hand the agents' actions over through MdState.agent_action
+            self._held = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.host.E, self.host.A, 2))
+            self.s.agent_action = self._held.ctypes.data
+        try:
+            if threads > 1:
+                self.call("ref_step_mt", threads)
+            else:
+                self.call("ref_step")
+        finally:
+            self.s.agent_action = None
         self._detectors()
 
     def _detectors(self):
