@@ -692,6 +692,7 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
 // (intersections, roundabouts: 100-200 lanes) are read through L1/L2 instead -- staging 30 KB per env per
 // step would cost more HBM traffic and LDS occupancy than it saves in latency.
 constexpr int kStageMaxLanes = 64;
+constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot removed in this step
 
 // RESPAWN: traffic_mode respawn / hybrid (compiled apart: its slot-rewriting code costs the common trigger-mode
 // kernel 8 VGPRs and one wave of occupancy when it is merely branched around).
@@ -957,7 +958,10 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         for (int j = tid; j < cap; j += kBlock) {
             if (kFused && md_drives(s.shape[j].flags)) s.flags[j] = l_onlane[j] | l_cfl[j];
             const int f = s.shape[j].flags;
-            if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) s.shape[j].flags = f & ~MD_F_ALIVE;
+            if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) {
+                s.shape[j].flags = f & ~MD_F_ALIVE;
+                if (kFused) l_cfl[j] = kRemovedMark;  // the slot's last write-back (see the dirty-slot write-back)
+            }
         }
         // next step's trigger: reads the agents' final lanes and the PENDING slots, which the removal above
         // (driving slots only) does not touch
@@ -996,8 +1000,37 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     if (!kLidarOnly) {
         __syncthreads();
         MD_STAMP_AT(10);
-        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
         constexpr bool respawns = (PH & PH_TRAFFIC) && RESPAWN;  // traffic respawn rewrites a whole slot
+        if (kFused && !MULTI && !do_reset) {
+            // Single-agent fused step: only slots that drive now (agents, traffic incl. the just triggered /
+            // respawned) or were removed this step can differ from what HBM already holds -- props, waiting and
+            // dead traffic are never written by any phase.  Writing just those cuts the store traffic ~4x.
+            auto dirty = [&](int j) { return md_drives(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
+            for (int i = tid; i < cap * 2; i += kBlock)
+                if (dirty(i >> 1)) {
+                    reinterpret_cast<uint4*>(gv.shape)[i] = reinterpret_cast<const uint4*>(l_shape)[i];
+                    reinterpret_cast<uint4*>(gv.dyn)[i] = reinterpret_cast<const uint4*>(l_dyn)[i];
+                    reinterpret_cast<uint4*>(gv.pid)[i] = reinterpret_cast<const uint4*>(l_pid)[i];
+                }
+            for (int i = tid; i < cap * 4; i += kBlock)
+                if (dirty(i >> 2)) reinterpret_cast<uint4*>(gv.nav)[i] = reinterpret_cast<const uint4*>(l_nav)[i];
+            if (RESPAWN) {
+                for (int i = tid; i < cap * (MD_ROUTE_LEN / 4); i += kBlock)
+                    if (md_drives(l_shape[i / (MD_ROUTE_LEN / 4)].flags))
+                        reinterpret_cast<uint4*>(gv.route_roads)[i] = reinterpret_cast<const uint4*>(l_rroads)[i];
+            }
+            for (int j = tid; j < cap; j += kBlock)
+                if (dirty(j)) {
+                    reinterpret_cast<float2*>(gv.action)[j] = reinterpret_cast<const float2*>(l_action)[j];
+                    gv.flags[j] = l_flags[j];
+                    if (RESPAWN) gv.final_lane[j] = l_final[j];
+                }
+            if (track_det)
+                for (int j = tid; j < 2 * c.agents_per_env; j += kBlock) gv.detected[j] = l_det[j];
+            MD_STAMP_AT(11);
+            return;
+        }
+        if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
         if ((PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) || respawns) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         if ((PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
         if ((PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
