@@ -103,9 +103,7 @@ BATCH_DEFAULT_CONFIG = dict(
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
 )
 
-_OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False,
-                 random_lane_width=False, random_lane_num=False,
-                 need_inverse_traffic=False, random_traffic=False)
+_OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False, random_traffic=False)
 
 
 def _merge(dst, src, path=""):

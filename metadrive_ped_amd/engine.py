@@ -41,6 +41,16 @@ def _build_marl(cfg, scene_cfg, uniq):
 def _build_one(job):
     """One scenario seed -> (MapTables, EnvScene).  Module-level so that a fork pool can run it."""
     s, mc, dist, scene_cfg = job
+    if scene_cfg.get("random_lane_width") or scene_cfg.get("random_lane_num"):
+        # PGMapManager.add_random_to_map (manager/pg_map_manager.py:68-74): the map manager's stream, re-seeded with
+        # the scenario index at every reset; width first, then the lane count
+        from metadrive_ped_amd.rng import get_np_random
+        rng = get_np_random(s)
+        mc = dict(mc)
+        if scene_cfg.get("random_lane_width"):
+            mc["lane_width"] = float(rng.rand() * (4.5 - 3.0) + 3.0)     # MAX_LANE_WIDTH / MIN_LANE_WIDTH (base_map.py:38-39)
+        if scene_cfg.get("random_lane_num"):
+            mc["lane_num"] = int(rng.randint(2, 3 + 1))                   # MIN_LANE_NUM .. MAX_LANE_NUM (base_map.py:40-41)
     pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
     mt = MapTables(pg)
@@ -82,7 +92,9 @@ class HostScene:
                          spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
-                         accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"])
+                         accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
+                         need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
+                         random_lane_num=cfg["random_lane_num"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)

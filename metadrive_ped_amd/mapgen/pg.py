@@ -339,6 +339,10 @@ class Block:
     def positive_roads_lanes(self):
         return [lanes for a, b, lanes in self.net.roads() if not is_negative_road(b) and (a, b) != DECORATION]
 
+    def negative_roads_lanes(self):
+        """NodeRoadNetwork.get_negative_lanes (road_network/node_road_network.py:145-155)"""
+        return [lanes for a, b, lanes in self.net.roads() if is_negative_road(b) and (a, b) != DECORATION]
+
     def intermediate_spawn_lanes(self):
         """PGBlock.get_intermediate_spawn_lanes (pgblock/pg_block.py:238-244)"""
         out = self.positive_roads_lanes()

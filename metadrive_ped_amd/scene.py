@@ -130,6 +130,11 @@ class EnvScene:
                         slot += 1
             for bi, block in enumerate(pg_map.blocks[1:] if cfg["traffic_mode"] != "respawn" else [], start=1):
                 trigger_lanes = block.intermediate_spawn_lanes()
+                if cfg.get("need_inverse_traffic", False) and block.ID in ("S", "C", "r", "R"):
+                    # oncoming traffic on the simple blocks (traffic_manager.py:242-245)
+                    neg_lanes = block.negative_roads_lanes()
+                    traffic_mgr.np_random.shuffle(neg_lanes)
+                    trigger_lanes = trigger_lanes + neg_lanes
                 potential = []
                 for lanes in trigger_lanes:
                     for l in lanes:

@@ -209,3 +209,28 @@ def test_others_block_and_detected_sets_parity(navi):
     st = eng.download_state()
     assert_state_equal(st, orc.state, where="others final")
     assert (st["detected"] != 0).any()
+
+
+def test_random_lanes_and_inverse_traffic_rollout_parity():
+    """random_lane_width + random_lane_num + need_inverse_traffic: 2- and 3-lane maps of odd widths with oncoming
+    traffic in one batch (different lane tables, LDS-staged and not, in the same launch)."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    E = 48
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, random_lane_width=True, random_lane_num=True,
+                           need_inverse_traffic=True, traffic_density=0.2, horizon=250))
+    eng = BatchedEngine(cfg)
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="random lanes reset")
+    for t in range(300):
+        a = scripted_actions(E, 1, t, seed=13)
+        a[:, :, 0] *= 0.3
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 30 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="random lanes step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="random lanes final")

@@ -146,3 +146,41 @@ def test_line_quads_follow_reference_geometry(cs_dist):
     np.testing.assert_allclose(np.minimum(w, ln), 0.075, atol=1e-5)   # 2 * LANE_LINE_WIDTH/4
     # STRIPE_LENGTH stripes; the LAST stripe of a line runs to length - 1.5 (pg_block.py:268-269) so it is longer
     assert np.median(np.maximum(w, ln)) == pytest.approx(1.5, abs=1e-4) and np.all(np.maximum(w, ln) < 4.5 + 1e-4)
+
+
+def test_random_lane_width_num_and_inverse_traffic():
+    """random_lane_width / random_lane_num (PGMapManager.add_random_to_map, manager/pg_map_manager.py:68-74: the
+    manager's stream re-seeded with the scenario index: rand() for the width, then randint for the count) and
+    need_inverse_traffic (traffic_manager.py:242-245: oncoming traffic on S / C / r / R blocks)."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.rng import get_np_random
+    E = 12
+    base = dict(num_envs=E, num_scenarios=E, traffic_density=0.3)
+    host = HostScene(make_config(dict(base, random_lane_width=True, random_lane_num=True)))
+    for s in host.seeds:
+        pg = host.scenes[s].tables.pg_map
+        rng = get_np_random(s)
+        assert pg.lane_width == pytest.approx(rng.rand() * 1.5 + 3.0) and 3.0 <= pg.lane_width <= 4.5
+        assert pg.lane_num == int(rng.randint(2, 4)) and pg.lane_num in (2, 3)
+    assert len({host.scenes[s].tables.pg_map.lane_num for s in host.seeds}) == 2
+    only_w = HostScene(make_config(dict(base, random_lane_width=True)))
+    assert all(only_w.scenes[s].tables.pg_map.lane_num == 3 for s in only_w.seeds)
+    # inverse traffic: some traffic vehicles start on negative roads of the simple blocks
+    inv = HostScene(make_config(dict(base, need_inverse_traffic=True)))
+    plain = HostScene(make_config(dict(base)))
+    def oncoming_on_simple_blocks(host):
+        n = 0
+        for s in host.seeds:
+            sc = host.scenes[s]
+            mt = sc.tables
+            for j in range(1, 1 + sc.n_traffic):
+                lane_id = sc.nav["lane"][j]
+                if not mt.roads[mt.lanes[lane_id]["road"]]["negative"]:
+                    continue
+                blk = [b for b in mt.pg_map.blocks if any(l is mt.lane_objs[lane_id] for _, _, ls in b.net.roads() for l in ls)]
+                n += bool(blk and blk[0].ID in ("S", "C", "r", "R"))
+        return n
+
+    assert oncoming_on_simple_blocks(inv) > 0 and oncoming_on_simple_blocks(plain) == 0
+    assert sum(inv.scenes[s].n_traffic for s in inv.seeds) > sum(plain.scenes[s].n_traffic for s in plain.seeds)
