@@ -55,6 +55,8 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.next_agent_id = g->next_agent_id ? g->next_agent_id + e : 0;
     v.detected = g->detected ? g->detected + (size_t)e * c->agents_per_env * 2 : 0;
     v.agent_action = g->agent_action ? g->agent_action + (size_t)e * c->agents_per_env * 2 : 0;
+    v.track_shape = g->track_shape ? g->track_shape + b : 0;   /* + t * n_envs * cap per frame */
+    v.track_dyn = g->track_dyn ? g->track_dyn + 2 * b : 0;
     return v;
 }
 
@@ -85,7 +87,32 @@ MD_HD float md_sanitize(float a) { /* utils/math.py:16-26 safe_clip_for_small_ar
     return md_clip(a, -1.0f, 1.0f);
 }
 
+/* traffic_mode 3: a non-agent slot takes its pose from the recorded track at the episode step that is being
+ * computed (the first agent's step counter + 1).  Vehicles become kinematic bodies (STATIC: seen by lidar and
+ * contacts, never driven, localised or removed). */
+MD_HD void md_replay_mover(const MdState* s, const MdConfig* c, int n) {
+    int t = s->nav[0].steps + 1;
+    if (t >= c->track_len) t = c->track_len - 1;
+    if (t < 0) return;
+    const size_t at = (size_t)t * (size_t)c->n_envs * (size_t)c->cap + (size_t)n;
+    const MdShape r = s->track_shape[at];
+    MdShape* sh = &s->shape[n];
+    MdDyn* d = &s->dyn[n];
+    d->last_x = sh->cx;
+    d->last_y = sh->cy;
+    d->last_c = sh->c;
+    d->last_s = sh->s;
+    *sh = r;
+    if (md_kind_of(r.flags) == MD_KIND_VEHICLE) sh->flags = r.flags | MD_F_STATIC;
+    d->heading = s->track_dyn[2 * at];
+    d->speed = s->track_dyn[2 * at + 1];
+}
+
 MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
+    if (c->traffic_mode == 3 && n >= c->agents_per_env) {
+        md_replay_mover(s, c, n);
+        return;
+    }
     MdShape* sh = &s->shape[n];
     if (!md_drives(sh->flags) || (sh->flags & MD_F_SPAWNED)) return;
     MdDyn* d = &s->dyn[n];
@@ -779,7 +806,7 @@ MD_HD int md_traffic_wants_respawn(int flags) {
 }
 
 MD_HD void md_traffic_respawn_env(const MdWorld* w, const MdLane* lanes, const MdState* s, const MdConfig* c, int m) {
-    if (c->traffic_mode == 0 || !w->spawn_off) return;
+    if ((c->traffic_mode != 1 && c->traffic_mode != 2) || !w->spawn_off) return;
     const int p0 = w->spawn_off[m], np_ = w->spawn_off[m + 1] - p0;
     if (np_ <= 0) return;
     for (int slot = c->agents_per_env; slot < c->cap; ++slot) {

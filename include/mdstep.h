@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 3
+#define MD_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -254,6 +254,13 @@ typedef struct MdState {
      * (steering, throttle).  NULL = the agents' actions are already in `action` (slots 0..A-1 of each env).
      * Saves the scatter into the per-slot array; md_step still writes the sanitised values to `action`. */
     const float* agent_action;
+    /* traffic_mode 3 (replay): recorded poses of every non-agent slot, frame-major:
+     * track_shape[t * n_envs * cap + n], track_dyn[2 * (t * n_envs * cap + n)] = (heading, speed);
+     * frame t is the state at the END of the t-th step of the episode (frame 0 = reset state).  The role of
+     * ReplayTrafficParticipantPolicy.act (policy/replay_policy.py:43-67): position / heading / velocity set
+     * from the track at the current episode step, no reaction to the agents. */
+    const MdShape* track_shape;
+    const float* track_dyn;
     /* optional (NULL = not wanted; required when MdConfig.num_others > 0) */
     uint64_t* detected;        /* [n_envs * agents_per_env][2] bit j of the 128-bit set: some beam of the agent's lidar
                                   hit the mover in slot j first -- the `detected_objects` half of Lidar.perceive's
@@ -281,7 +288,7 @@ typedef struct MdConfig {
     int32_t out_of_route_done, on_continuous_line_done;
     int32_t crash_vehicle_done, crash_object_done, crash_human_done;
     int32_t truncate_as_terminate;
-    int32_t traffic_mode;      /* 0 trigger, 1 respawn, 2 hybrid (manager/traffic_manager.py:20-29) */
+    int32_t traffic_mode;      /* 0 trigger, 1 respawn, 2 hybrid (manager/traffic_manager.py:20-29), 3 replay of recorded tracks */
     int32_t enable_idm_lane_change;
     int32_t auto_reset;        /* 1: md_step restores envs whose need_reset flag is set          */
     float max_lane_width;      /* BaseMap.MAX_LANE_WIDTH 4.5                                     */
@@ -299,6 +306,8 @@ typedef struct MdConfig {
     int32_t n_lane_line;       /* lane_line_detector.num_lasers (0 = off: one lateral dim instead) */
     int32_t num_others;        /* vehicle_config.lidar.num_others: nearest detected vehicles in the obs (0 = none) */
     int32_t add_others_navi;   /* vehicle_config.lidar.add_others_navi                            */
+    int32_t track_len;         /* frames in MdState.track_* (traffic_mode 3); later steps hold the last frame */
+    int32_t pad2;
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

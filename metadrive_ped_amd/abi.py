@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 3
+MD_ABI_VERSION = 4
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -90,6 +90,8 @@ class MdState(C.Structure):
         ("route_nodes0", P), ("route_roads0", P), ("final_lane0", P), ("rng", P), ("env_steps", P), ("agent_id", P),
         ("next_agent_id", P),
         ("agent_action", P),
+        ("track_shape", P),
+        ("track_dyn", P),
         ("detected", P),
     ]
 
@@ -112,6 +114,8 @@ class MdConfig(C.Structure):
         ("crash_done", C.c_int32), ("out_of_road_done", C.c_int32), ("n_side", C.c_int32), ("n_lane_line", C.c_int32),
         ("num_others", C.c_int32),
         ("add_others_navi", C.c_int32),
+        ("track_len", C.c_int32),
+        ("pad2", C.c_int32),
     ]
 
 

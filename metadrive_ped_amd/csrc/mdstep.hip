@@ -1005,7 +1005,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             // Single-agent fused step: only slots that drive now (agents, traffic incl. the just triggered /
             // respawned) or were removed this step can differ from what HBM already holds -- props, waiting and
             // dead traffic are never written by any phase.  Writing just those cuts the store traffic ~4x.
-            auto dirty = [&](int j) { return md_drives(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
+            const bool replay = c.traffic_mode == 3;  // replayed slots move without "driving"
+            auto dirty = [&](int j) { return replay || md_drives(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
             for (int i = tid; i < cap * 2; i += kBlock)
                 if (dirty(i >> 1)) {
                     reinterpret_cast<uint4*>(gv.shape)[i] = reinterpret_cast<const uint4*>(l_shape)[i];
@@ -1129,7 +1130,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     if (kCanMulti && c->is_multi_agent) {
         if (stage) MD_LAUNCH(true, false, kCanMulti);
         else MD_LAUNCH(false, false, kCanMulti);
-    } else if (kCanRespawn && c->traffic_mode != 0) {
+    } else if (kCanRespawn && (c->traffic_mode == 1 || c->traffic_mode == 2)) {
         if (stage) MD_LAUNCH(true, kCanRespawn, false);
         else MD_LAUNCH(false, kCanRespawn, false);
     } else if (stage) {
@@ -1163,6 +1164,30 @@ int check_world(const MdWorld* w) {
     NEED(w->quad_off); NEED(w->quads); NEED(w->quad_kind); NEED(w->grid); NEED(w->cell_start); NEED(w->cell_items);
     return MD_OK;
 }
+
+// traffic_mode respawn / hybrid: the respawn-lane tables, the env RNG and the route snapshot must be there
+int check_traffic_mode(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    if (c->traffic_mode == 0) return MD_OK;
+    if (c->traffic_mode < 0 || c->traffic_mode > 3 || c->is_multi_agent) {
+        snprintf(g_err, sizeof g_err, "traffic_mode=%d is not valid here (0 trigger, 1 respawn, 2 hybrid, 3 replay; "
+                 "single-agent envs)", c->traffic_mode);
+        return MD_EINVAL;
+    }
+    if (c->traffic_mode == 3) {
+        NEED(s->track_shape); NEED(s->track_dyn); NEED(s->nav);
+        if (c->track_len <= 0) {
+            snprintf(g_err, sizeof g_err, "traffic_mode 3 (replay) needs MdConfig.track_len > 0");
+            return MD_EINVAL;
+        }
+        return MD_OK;
+    }
+    int r = check_world(w);
+    if (r != MD_OK) return r;
+    NEED(s->rng); NEED(s->route_nodes0); NEED(s->route_roads0); NEED(s->final_lane0); NEED(s->final_lane);
+    NEED(w->spawn_off); NEED(w->spawn_lane); NEED(w->spawn_route); NEED(w->spawn_route_meta);
+    return MD_OK;
+}
+
 
 }  // namespace
 
@@ -1279,6 +1304,8 @@ __attribute__((visibility("default"))) int md_integrate(const MdWorld* w, const 
     r = check_state(s);
     if (r != MD_OK) return r;
     NEED(s->dyn); NEED(s->param); NEED(s->action);
+    r = check_traffic_mode(w, s, c);
+    if (r != MD_OK) return r;
     return launch<PH_INTEGRATE>(w, s, c, nullptr, 0, 0, stream);
 }
 
@@ -1333,21 +1360,6 @@ __attribute__((visibility("default"))) int md_idm(const MdWorld* w, const MdStat
     NEED(s->dyn); NEED(s->nav); NEED(s->pid); NEED(s->action); NEED(s->route_roads); NEED(s->idm_rand);
     NEED(w->node_adj_off); NEED(w->node_adj); NEED(w->node_off);
     return launch<PH_IDM>(w, s, c, nullptr, 0, 0, stream);
-}
-
-// traffic_mode respawn / hybrid: the respawn-lane tables, the env RNG and the route snapshot must be there
-int check_traffic_mode(const MdWorld* w, const MdState* s, const MdConfig* c) {
-    if (c->traffic_mode == 0) return MD_OK;
-    if (c->traffic_mode < 0 || c->traffic_mode > 2 || c->is_multi_agent) {
-        snprintf(g_err, sizeof g_err, "traffic_mode=%d is not valid here (0 trigger, 1 respawn, 2 hybrid; single-agent envs)",
-                 c->traffic_mode);
-        return MD_EINVAL;
-    }
-    int r = check_world(w);
-    if (r != MD_OK) return r;
-    NEED(s->rng); NEED(s->route_nodes0); NEED(s->route_roads0); NEED(s->final_lane0); NEED(s->final_lane);
-    NEED(w->spawn_off); NEED(w->spawn_lane); NEED(w->spawn_route); NEED(w->spawn_route_meta);
-    return MD_OK;
 }
 
 __attribute__((visibility("default"))) int md_traffic_after_step(const MdWorld* w, const MdState* s, const MdConfig* c,

@@ -212,7 +212,8 @@ def make_md_config(cfg, E, A, cap, n_beams):
                  "auto_reset"):
         setattr(k, name, int(bool(cfg[name])))
     # density ~ 0: PGTrafficManager.reset returns before any mode-specific set-up (traffic_manager.py:62-63)
-    k.traffic_mode = {"trigger": 0, "respawn": 1, "hybrid": 2}[cfg["traffic_mode"]] if abs(cfg["traffic_density"]) >= 1e-2 else 0
+    k.traffic_mode = {"trigger": 0, "respawn": 1, "hybrid": 2, "replay": 3}[cfg["traffic_mode"]] \
+        if abs(cfg["traffic_density"]) >= 1e-2 else 0
     k.max_lane_width = 4.5      # BaseMap.MAX_LANE_WIDTH (component/map/base_map.py:38)
     k.total_width = (3 + 1) * 4.5  # (MAX_LANE_NUM + 1) * MAX_LANE_WIDTH (obs/state_obs.py:92)
     k.curve_radius_max = 60.0   # BlockParameterSpace.CURVE radius max
@@ -253,6 +254,8 @@ class BatchedEngine:
                                    "fallback".format(cfg["device"]))
         self.host = host
         self._noise_gen = None
+        self._rec = None
+        self._tracks = None
         self.build()
 
     # -- upload helpers ---------------------------------------------------------------------------
@@ -313,6 +316,44 @@ class BatchedEngine:
             self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
                                self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, (h.n_side or 2) + 6)
         self._lidar_noise()
+        if self._rec is not None:
+            self._record_frame()
+
+    # -- record / replay of the traffic (the role of RecordManager / ReplayManager for the movers of the batch,
+    #    manager/record_manager.py:35-135, manager/replay_manager.py:21-195, policy/replay_policy.py:43-67) ---------
+    def start_recording(self, max_steps):
+        """Call right after reset(): frame 0 is the reset state, frame k the state after the k-th step.  Frames are
+        device tensors (32 + 8 bytes per slot and step); recording stops by itself when the buffer is full."""
+        torch = self.torch
+        n = self.E * self.cap
+        self._rec = dict(shape=torch.empty((max_steps + 1, n * 32), dtype=torch.uint8, device=self.device),
+                         dyn=torch.empty((max_steps + 1, n, 2), dtype=torch.float32, device=self.device), n=0)
+        self._record_frame()
+
+    def _record_frame(self):
+        r = self._rec
+        if r["n"] >= r["shape"].shape[0]:
+            return
+        r["shape"][r["n"]].copy_(self.state_dev["shape"])
+        r["dyn"][r["n"], :, 0].copy_(self.dyn_f.reshape(-1, 8)[:, 0])      # heading
+        r["dyn"][r["n"], :, 1].copy_(self.dyn_f.reshape(-1, 8)[:, 1])      # speed
+        r["n"] += 1
+
+    def stop_recording(self):
+        """-> dict(shape=[T, E*cap*32] uint8, dyn=[T, E*cap, 2] float32, seeds=...) of the T recorded frames."""
+        r, self._rec = self._rec, None
+        return dict(shape=r["shape"][:r["n"]].contiguous(), dyn=r["dyn"][:r["n"]].contiguous(),
+                    seeds=list(self.host.seeds), cap=self.cap)
+
+    def set_tracks(self, tracks):
+        """traffic_mode 'replay': every non-agent slot follows these recorded frames (episode step k -> frame k; the
+        last frame is held afterwards).  The tracks must come from the same scenario assignment and capacity."""
+        if list(tracks["seeds"]) != list(self.host.seeds) or tracks["cap"] != self.cap:
+            raise ValueError("tracks were recorded with another scenario assignment or mover capacity")
+        self._tracks = dict(shape=tracks["shape"].to(self.device).contiguous(), dyn=tracks["dyn"].to(self.device).contiguous())
+        self.s.track_shape = self._tracks["shape"].data_ptr()
+        self.s.track_dyn = self._tracks["dyn"].data_ptr()
+        self.k.track_len = int(self._tracks["shape"].shape[0])
 
     def _lidar_noise(self):
         """LidarStateObservation._add_noise_to_cloud_points (obs/state_obs.py:234-244): gaussian noise (clipped to

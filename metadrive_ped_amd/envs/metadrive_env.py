@@ -129,6 +129,22 @@ class BatchedMetaDriveEnv:
     def close(self):
         self.engine = None
 
+    # -- record / replay of the traffic (RecordManager / ReplayManager / ReplayTrafficParticipantPolicy) ------------
+    def start_recording(self, max_steps):
+        """Right after reset(): keep the pose of every mover for the next `max_steps` steps (device memory)."""
+        self.engine.start_recording(max_steps)
+
+    def stop_recording(self):
+        return self.engine.stop_recording()
+
+    def load_tracks(self, tracks):
+        """For an env built with traffic_mode='replay': the traffic follows `tracks` (from stop_recording() of an env
+        with the same scenarios) instead of reacting; call before reset()."""
+        if self.config["traffic_mode"] != "replay":
+            raise ValueError("load_tracks needs config traffic_mode='replay'")
+        self.lazy_init()
+        self.engine.set_tracks(tracks)
+
     # -- state checkpoint (the role of BaseEngine/BaseManager get_state / set_state, manager/base_manager.py:116-135,
     #    and of BaseVehicle.get_state / set_state, component/vehicle/base_vehicle.py:808-846: everything that
     #    evolves is already a flat array here, so a checkpoint is a dict of numpy arrays) -----------------------

@@ -108,7 +108,7 @@ class EnvScene:
         density = cfg["traffic_density"]
         slot = A
         if abs(density) >= 1e-2:
-            if cfg["traffic_mode"] not in ("trigger", "respawn", "hybrid"):
+            if cfg["traffic_mode"] not in ("trigger", "respawn", "hybrid", "replay"):
                 raise ValueError("No such mode named {}".format(cfg["traffic_mode"]))  # traffic_manager.py:71
             if cfg["traffic_mode"] == "respawn":
                 # _create_respawn_vehicles (traffic_manager.py:213-228): every vehicle drives from step 0

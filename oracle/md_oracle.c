@@ -118,7 +118,10 @@ EXPORT int ref_line_detector(const MdWorld* w, const MdState* s, const MdConfig*
  * -----------------------------------------------------------------------------------------*/
 EXPORT int ref_integrate(const MdWorld* w, const MdState* s, const MdConfig* c) {
     (void)w;
-    for (int n = 0; n < c->n_envs * c->cap; ++n) md_integrate_mover(s, c, n);
+    for (int e = 0; e < c->n_envs; ++e) {
+        MdState v = md_env_view(s, c, e); /* env-local slots: the replay mode tells agents from traffic by slot */
+        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
+    }
     return MD_OK;
 }
 
@@ -247,7 +250,7 @@ EXPORT int ref_traffic_after_step(const MdWorld* w, const MdState* s, const MdCo
         if (!drives(sh->flags) || (sh->flags & MD_F_AGENT)) continue;
         if (!(s->flags[n] & MD_FL_ON_LANE)) sh->flags &= ~MD_F_ALIVE;
     }
-    if (c->traffic_mode != 0)
+    if (c->traffic_mode == 1 || c->traffic_mode == 2)
         for (int e = 0; e < c->n_envs; ++e) {
             MdState v = md_env_view(s, c, e);
             md_traffic_respawn_env(w, w->lanes + w->lane_off[w->env_map[e]], &v, c, w->env_map[e]);
@@ -346,7 +349,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
             s->action[2 * (base + j)] = 0.0f;
             s->action[2 * (base + j) + 1] = 0.0f;
         }
-        if (c->is_multi_agent || c->traffic_mode != 0) { /* routes are rewritten by respawns */
+        if (c->is_multi_agent || c->traffic_mode == 1 || c->traffic_mode == 2) { /* routes are rewritten by respawns */
             memcpy(&s->route_nodes[(size_t)base * MD_ROUTE_LEN], &s->route_nodes0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
             memcpy(&s->route_roads[(size_t)base * MD_ROUTE_LEN], &s->route_roads0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
             memcpy(&s->final_lane[base], &s->final_lane0[base], sizeof(int32_t) * c->cap);
@@ -370,7 +373,8 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
     const int plan_ahead = !c->is_multi_agent;
     if (!just_reset) {
         if (!plan_ahead) idm_env(w, s, c, e);
-        for (int j = 0; j < c->cap; ++j) md_integrate_mover(s, c, base + j);
+        MdState v = md_env_view(s, c, e);
+        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
     }
     for (int j = 0; j < c->cap; ++j) localize_mover(w, s, c, e, base + j);
     for (int j = 0; j < c->cap; ++j) contacts_mover(w, s, c, e, j);
@@ -379,7 +383,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         if (!drives(sh->flags) || (sh->flags & MD_F_AGENT)) continue;
         if (!(s->flags[base + j] & MD_FL_ON_LANE)) sh->flags &= ~MD_F_ALIVE;
     }
-    if (c->traffic_mode != 0) {
+    if (c->traffic_mode == 1 || c->traffic_mode == 2) {
         MdState v = md_env_view(s, c, e);
         md_traffic_respawn_env(w, w->lanes + w->lane_off[w->env_map[e]], &v, c, w->env_map[e]);
     }

@@ -125,6 +125,14 @@ class OracleWorld:
                       C.c_uint32(BatchedEngine.LANE_LINE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim,
                       (h.n_side or 2) + 6)
 
+    def set_tracks(self, shape, dyn):
+        """traffic_mode 'replay': frames [T, E*cap] of MdShape records and [T, E*cap, 2] (heading, speed)."""
+        self._track_shape = np.ascontiguousarray(shape)
+        self._track_dyn = np.ascontiguousarray(dyn, np.float32)
+        self.s.track_shape = self._track_shape.ctypes.data
+        self.s.track_dyn = self._track_dyn.ctypes.data
+        self.k.track_len = int(self._track_shape.shape[0])
+
     def reset(self):
         self.state["need_reset"][:] = 1
         self.call("ref_step")

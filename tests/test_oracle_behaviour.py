@@ -308,3 +308,54 @@ def test_others_block_of_the_observation(cs_dist):
                 r = math.hypot(sh["hl"][e, j], sh["hw"][e, j])
                 assert math.hypot(sh["cx"][e, j] - sh["cx"][e, 0], sh["cy"][e, j] - sh["cy"][e, 0]) <= 50.0 + r + 1e-3
     assert seen > 50
+
+
+def test_replay_traffic_mode_reproduces_a_recorded_episode():
+    """traffic_mode 'replay' (ReplayTrafficParticipantPolicy, policy/replay_policy.py:43-67): the traffic takes its
+    poses from recorded frames.  Replaying with the SAME agent actions reproduces the recorded observations
+    exactly; with other actions the traffic still follows the recording (no reaction)."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E, T = 6, 120
+    base = dict(num_envs=E, num_scenarios=E, traffic_density=0.3, horizon=1000, auto_reset=False)   # no restarts: frame k = step k
+    rec_host = HostScene(make_config(dict(base)))
+    o = ob.OracleWorld(rec_host)
+    o.reset()
+    n = E * rec_host.cap
+    shape = np.zeros((T + 1, n), dtype=abi.SHAPE_DT)
+    dyn = np.zeros((T + 1, n, 2), np.float32)
+    obs_rec = []
+
+    def grab(k):
+        shape[k] = o.state["shape"]
+        dyn[k, :, 0] = o.state["dyn"]["heading"]
+        dyn[k, :, 1] = o.state["dyn"]["speed"]
+
+    grab(0)
+    acts = [np.tile(np.array([0.02 * math.sin(0.1 * t), 0.5], np.float32), (E, 1, 1)) for t in range(T)]
+    for t in range(T):
+        o.step(acts[t])
+        grab(t + 1)
+        obs_rec.append(o.obs.copy())
+    assert not (o.state["nav"]["steps"].reshape(E, -1)[:, 0] < T).any(), "episodes must not have restarted while recording"
+    moved = np.abs(shape["cx"][T] - shape["cx"][0]).reshape(E, -1)[:, 1:]
+    assert (moved > 1.0).any()                                            # some traffic did drive
+
+    rp_host = HostScene(make_config(dict(base, traffic_mode="replay")))
+    assert rp_host.cap == rec_host.cap and rp_host.md_config.traffic_mode == 3
+    r = ob.OracleWorld(rp_host)
+    r.set_tracks(shape, dyn)
+    r.reset()
+    for t in range(T):
+        r.step(acts[t])
+        assert r.obs.tobytes() == obs_rec[t].tobytes(), "replay diverged at step %d" % t
+    # other actions: traffic poses still equal the recording, step for step
+    r2 = ob.OracleWorld(HostScene(make_config(dict(base, traffic_mode="replay"))))
+    r2.set_tracks(shape, dyn)
+    r2.reset()
+    for t in range(60):
+        r2.step(np.tile(np.array([0.0, 0.1], np.float32), (E, 1, 1)))
+        got = r2.state["shape"].reshape(E, -1)
+        want = shape[t + 1].reshape(E, -1)
+        for f in ("cx", "cy", "c", "s"):
+            assert np.array_equal(got[f][:, 1:], want[f][:, 1:])
