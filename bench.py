@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--cap", type=int, default=0, help="mover slots per env (0 = smallest that fits)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl"],
+    p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl", "replay"],
                    help="metadrive = BASELINE configs[1] (the headline line); safe = configs[3] per-GPU shard (8192 "
                         "SafeMetaDriveEnv); marl = configs[2] (1024 x 40-agent roundabout, 240 beams)")
     p.add_argument("--cpu-envs", type=int, default=2048)
@@ -84,6 +84,13 @@ def main():
         from metadrive_ped_amd.envs.metadrive_env import BatchedSafeMetaDriveEnv
         cfg = make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, horizon=1000)))
         label = "BASELINE configs[3] shard: %d SafeMetaDriveEnv per GPU (accident_prob 0.8, density 0.05), 240 beams" % E
+    elif args.workload == "replay":
+        if args.envs == 4096:
+            E = common["num_envs"] = 2048
+            common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
+        cfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="replay"))
+        label = ("BASELINE configs[4] stand-in: %d envs replaying recorded traffic tracks (200 frames, non-reactive) on 3-block "
+                 "PG maps, 240-beam lidar -- ScenarioNet data is not available here" % E)
     else:
         if args.envs == 4096:
             E = common["num_envs"] = 1024
@@ -95,8 +102,29 @@ def main():
     t0 = time.time()
     from metadrive_ped_amd.engine import HostScene
     host = HostScene(cfg)
+    rhost = None
+    if args.workload == "replay":   # the recording run's scenes: also built before the GPU is touched (fork pool)
+        rcfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="trigger"))
+        rhost = HostScene(rcfg)
     torch.cuda.set_device(local_rank)
+    tracks = None
+    if args.workload == "replay":
+        # record the tracks first: the same scenarios with reacting (trigger-mode IDM) traffic, 200 steps
+        reng = BatchedEngine(rcfg, host=rhost)
+        reng.reset()
+        reng.start_recording(200)
+        g0 = torch.Generator(device="cpu")
+        g0.manual_seed(1000 + rank)
+        for i in range(200):
+            a0 = torch.rand(E, 1, 2, generator=g0) * 2 - 1
+            a0[..., 1] = a0[..., 1].abs() * 0.9 + 0.1
+            a0[..., 0] *= 0.25
+            reng.step(a0.to(reng.device))
+        tracks = reng.stop_recording()
+        del reng
     eng = BatchedEngine(cfg, host=host)
+    if tracks is not None:
+        eng.set_tracks(tracks)
     build_s = time.time() - t0
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
