@@ -30,7 +30,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
-    marl_map=None,          # None | "roundabout" | "intersection" (set by the multi-agent env classes)
+    marl_map=None,          # None | "roundabout" | "intersection" | "bottleneck" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",
@@ -60,7 +60,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     block_dist_config=None,  # None -> BLOCK_TYPE_DISTRIBUTION_V2
     random_lane_width=False,
     random_lane_num=False,
-    map_config=dict(type="block_num", config=None, lane_width=3.5, lane_num=3, exit_length=50),
+    map_config=dict(type="block_num", config=None, lane_width=3.5, lane_num=3, exit_length=50,
+                    neck_lane_num=1, neck_length=20),   # the last two: multi-agent bottleneck map only (marl_bottleneck.py:13)
     store_map=True,
     traffic_density=0.1,
     need_inverse_traffic=False,

@@ -23,19 +23,24 @@ STATE_ARRAY_SPECS = None  # filled below
 
 def _build_marl(cfg, scene_cfg, uniq):
     """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
-    from metadrive_ped_amd.mapgen.pg import MAIntersectionMap, MARoundaboutMap
-    from metadrive_ped_amd.marl import SPAWN_ROADS, RoundaboutScene
+    from metadrive_ped_amd.mapgen.pg import MABottleneckMap, MAIntersectionMap, MARoundaboutMap
+    from metadrive_ped_amd.marl import FIXED_DESTINATION, SPAWN_ROADS, RoundaboutScene
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     mc = cfg["map_config"]
     kind = cfg["marl_map"]
     if kind not in SPAWN_ROADS:
         raise NotImplementedError("multi-agent map {!r} is not built (built: {})".format(kind, sorted(SPAWN_ROADS)))
-    cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]
-    pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
+    if kind == "bottleneck":
+        pg = MABottleneckMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+                             neck_lane_num=mc["neck_lane_num"], neck_length=mc["neck_length"])
+    else:
+        cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]
+        pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
     mt = MapTables(pg)
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
-    scenes = {s: RoundaboutScene(s, mt, sc_cfg, SPAWN_ROADS[kind]) for s in uniq}
-    return mt, scenes, spawn_tables(mt, SPAWN_ROADS[kind], mc["lane_num"])
+    fixed = FIXED_DESTINATION[kind]
+    scenes = {s: RoundaboutScene(s, mt, sc_cfg, SPAWN_ROADS[kind], fixed) for s in uniq}
+    return mt, scenes, spawn_tables(mt, SPAWN_ROADS[kind], mc["lane_num"], fixed)
 
 
 def _build_one(job):

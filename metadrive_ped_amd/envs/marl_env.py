@@ -145,3 +145,23 @@ class BatchedMultiAgentIntersectionEnv(BatchedMultiAgentRoundaboutEnv):
         import copy
         merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
         super().__init__(merged)
+
+
+class BatchedMultiAgentBottleneckEnv(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py:10-140): 20 agents, 4 lanes narrowing to 1 and
+    widening again, traffic in both directions, side (4 beams) and lane-line (4 beams) detectors in the observation.
+    Its reward / out-of-road rules equal MetaDriveEnv's with on_continuous_line_done (cross_yellow_line_done=True)."""
+    MAP_DEFAULTS = dict(marl_map="bottleneck", num_agents=20,
+                        map_config=dict(exit_length=60, lane_num=4, neck_lane_num=1, neck_length=20),
+                        vehicle_config=dict(side_detector=dict(num_lasers=4, distance=50),
+                                            lane_line_detector=dict(num_lasers=4, distance=20)))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)

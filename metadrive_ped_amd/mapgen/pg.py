@@ -240,7 +240,8 @@ def create_road_from(lane, lane_num, road, block_net, global_net, ignore_check=F
     return no_cross
 
 
-def create_adverse_road(road, block_net, global_net, ignore_check=False):
+def create_adverse_road(road, block_net, global_net, ignore_check=False, center_line_type=None, side_lane_line_type=None,
+                        inner_lane_line_type=None):
     """CreateAdverseRoad (create_pg_block_utils.py:202-281)"""
     a, b = road
     lanes = block_net.lanes(a, b)
@@ -254,9 +255,26 @@ def create_adverse_road(road, block_net, global_net, ignore_check=False):
         clockwise = not ref.clockwise
         radius = ref.radius + (num - 1) * w if not clockwise else ref.radius - (num - 1) * w
         sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
-    ok = create_road_from(sym, num // 2, negate_road(a, b), block_net, global_net, ignore_check)
+    ok = create_road_from(sym, num // 2, negate_road(a, b), block_net, global_net, ignore_check,
+                          center_line_type=center_line_type, side_lane_line_type=side_lane_line_type,
+                          inner_lane_line_type=inner_lane_line_type)
     lanes[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
     return ok
+
+
+def wave_lanes(pre_lane, lateral_dist, wave_length, last_straight_length, lane_width, toward_left=True):
+    """create_wave_lanes (create_pg_block_utils.py:359-380): two opposite arcs that shift a lane sideways by
+    2 * lateral_dist over wave_length, then a straight of last_straight_length."""
+    angle = np.pi - 2 * np.arctan(wave_length / (2 * lateral_dist))
+    radius = wave_length / (2 * math.sin(angle))
+    arc1, mid = bend_then_straight(pre_lane, 10, radius, angle, not toward_left, lane_width, (LINE_NONE, LINE_NONE))
+    # StraightLane.reset_start_end: pull the connecting straight back so that the second arc starts where the first ends
+    new_start, new_end = mid.position(-10, 0), mid.position(mid.length - 10, 0)
+    mid.start, mid.end = np.asarray(new_start, dtype=np.float64), np.asarray(new_end, dtype=np.float64)
+    mid.refresh()
+    arc2, straight = bend_then_straight(mid, last_straight_length, radius, angle, toward_left, lane_width,
+                                        (LINE_NONE, LINE_NONE))
+    return arc1, arc2, straight
 
 
 def bend_then_straight(prev, follow_len, radius, angle, clockwise, width, line_types):
@@ -829,6 +847,142 @@ class MARoundaboutMap:
     bfs_route = None  # bound below
 
 
+class Bottleneck(Block):
+    """Lane-count change (pgblock/bottleneck.py:10-30); `extra_config` = construct_from_config's dict."""
+    SPACE = BlockParameterSpace.BOTTLENECK
+
+    def __init__(self, *a, extra_config=None, **k):
+        super().__init__(*a, **k)
+        self.extra_config = dict(extra_config or {})
+
+    def road_node(self, part, idx):
+        return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
+
+    def intermediate_spawn_lanes(self):
+        return [lanes for lanes in super().intermediate_spawn_lanes() if isinstance(lanes[0], StraightLane)]
+
+    def _single(self, lane, road, side_t):
+        return create_road_from(lane, 1, road, self.net, self.global_net, center_line_type=LINE_NONE,
+                                side_lane_line_type=side_t, inner_lane_line_type=LINE_NONE)
+
+
+class Merge(Bottleneck):
+    """Outer lanes bend inwards and end: n lanes -> n - lane_num (pgblock/bottleneck.py:33-175)."""
+    ID = "y"
+
+    def plug(self):
+        self.config.update(self.extra_config)
+        p = self.config
+        self.lane_width = self.basic_lane.width
+        center = LINE_CONTINUOUS if p["solid_center_line"] else LINE_BROKEN
+        blen = p["bottle_len"]
+        start_node = self.pre_socket.positive[1]
+        straight_n = max(1, int(self.lane_num - p["lane_num"]))
+        circ_n = self.lane_num - straight_n
+        side0 = LINE_SIDE if circ_n == 0 else LINE_NONE
+        ref = self.positive_lanes[straight_n - 1].extended(blen, (LINE_NONE, LINE_NONE))
+        straight_road = (start_node, self.road_node(0, 0))
+        ok = create_road_from(ref, straight_n, straight_road, self.net, self.global_net, center_line_type=center,
+                              side_lane_line_type=side0, inner_lane_line_type=LINE_NONE)
+        ok = create_adverse_road(straight_road, self.net, self.global_net, inner_lane_line_type=LINE_NONE,
+                                 side_lane_line_type=side0, center_line_type=center) and ok
+        ref = ref.extended(p[Parameter.length], (LINE_NONE, LINE_NONE))
+        socket_road = (self.road_node(0, 0), self.road_node(0, 1))
+        ok = create_road_from(ref, straight_n, socket_road, self.net, self.global_net, center_line_type=center,
+                              side_lane_line_type=LINE_SIDE, inner_lane_line_type=LINE_BROKEN) and ok
+        ok = create_adverse_road(socket_road, self.net, self.global_net, inner_lane_line_type=LINE_BROKEN,
+                                 side_lane_line_type=LINE_SIDE, center_line_type=center) and ok
+        neg_socket = negate_road(*socket_road)
+        self.add_socket(Socket(socket_road, neg_socket))
+        for index, lane in enumerate(self.positive_lanes[straight_n:], 1):
+            lat = index * self.lane_width / 2
+            inner = self.road_node(1, index)
+            side_t = LINE_SIDE if index == self.lane_num - straight_n else LINE_NONE
+            c1, c2, _ = wave_lanes(lane, lat, blen, 5, self.lane_width)
+            road_1, road_2 = (start_node, inner), (inner, self.road_node(0, 0))
+            ok = self._single(c1, road_1, side_t) and ok
+            ok = self._single(c2, road_2, side_t) and ok
+            lane_b = self.net.lanes(*neg_socket)[-1]
+            c2b, c1b, _ = wave_lanes(lane_b, lat, blen, 5, self.lane_width, False)
+            ok = self._single(c2b, negate_road(*road_2), side_t) and ok
+            ok = self._single(c1b, negate_road(*road_1), side_t) and ok
+        return ok
+
+
+class Split(Bottleneck):
+    """Extra lanes branch off outwards: n lanes -> n + lane_num (pgblock/bottleneck.py:178-325)."""
+    ID = "Y"
+
+    def plug(self):
+        self.config.update(self.extra_config)
+        p = self.config
+        self.lane_width = self.basic_lane.width
+        center = LINE_CONTINUOUS if p["solid_center_line"] else LINE_BROKEN
+        blen = p["bottle_len"]
+        start_node = self.pre_socket.positive[1]
+        straight_n = self.lane_num
+        circ_n = int(p["lane_num"])
+        total = straight_n + circ_n
+        ref = self.positive_lanes[straight_n - 1].extended(blen, (LINE_NONE, LINE_NONE))
+        straight_road = (start_node, self.road_node(0, 0))
+        ok = create_road_from(ref, straight_n, straight_road, self.net, self.global_net, center_line_type=center,
+                              side_lane_line_type=LINE_NONE, inner_lane_line_type=LINE_NONE)
+        ok = create_adverse_road(straight_road, self.net, self.global_net, inner_lane_line_type=LINE_NONE,
+                                 side_lane_line_type=LINE_NONE, center_line_type=center) and ok
+        lane = self.positive_lanes[-1]
+        socket_ref = None
+        for index in range(1, circ_n + 1):
+            lat = index * self.lane_width / 2
+            inner = self.road_node(1, index)
+            side_t = LINE_SIDE if index == circ_n else LINE_NONE
+            c1, c2, straight = wave_lanes(lane, lat, blen, p[Parameter.length], self.lane_width, False)
+            if index == circ_n:
+                socket_ref = straight
+            ok = self._single(c1, (start_node, inner), side_t) and ok
+            ok = self._single(c2, (inner, self.road_node(0, 0)), side_t) and ok
+        socket_road = (self.road_node(0, 0), self.road_node(0, 1))
+        ok = create_road_from(socket_ref, total, socket_road, self.net, self.global_net, center_line_type=LINE_CONTINUOUS,
+                              side_lane_line_type=LINE_SIDE, inner_lane_line_type=LINE_BROKEN) and ok
+        ok = create_adverse_road(socket_road, self.net, self.global_net, inner_lane_line_type=LINE_BROKEN,
+                                 side_lane_line_type=LINE_SIDE, center_line_type=LINE_CONTINUOUS) and ok
+        neg_socket = negate_road(*socket_road)
+        self.add_socket(Socket(socket_road, neg_socket))
+        lanes = self.net.lanes(*neg_socket)
+        for index, lane in enumerate(lanes[self.lane_num:], 1):
+            lat = index * self.lane_width / 2
+            inner = self.road_node(1, index)
+            side_t = LINE_SIDE if index == circ_n else LINE_NONE
+            c1, c2, _ = wave_lanes(lane, lat, blen, 5, self.lane_width)
+            ok = self._single(c1, negate_road(inner, self.road_node(0, 0)), side_t) and ok
+            ok = self._single(c2, negate_road(start_node, inner), side_t) and ok
+        return ok
+
+
+BLOCK_CLASSES.update(Merge=Merge, Split=Split)
+
+
+class MABottleneckMap:
+    """FirstPGBlock + Merge + Split: the map of MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py:28-69):
+    `bottle_lane_num` lanes narrow to `neck_lane_num` over `neck_length` metres and widen again."""
+    def __init__(self, lane_num=4, lane_width=3.5, exit_length=60, neck_lane_num=1, neck_length=20):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        merge = Merge(1, list(first.sockets.values())[0], self.net, 1,
+                      extra_config=dict(lane_num=lane_num - neck_lane_num, length=neck_length))
+        merge.construct()
+        split = Split(2, list(merge.sockets.values())[0], self.net, 1,
+                      extra_config=dict(length=exit_length, lane_num=lane_num - neck_lane_num))
+        split.construct()
+        self.blocks = [first, merge, split]
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
 class MAIntersectionMap:
     """FirstPGBlock + one InterSection (seed 1, U-turns on): the map of MultiAgentIntersectionEnv
     (envs/marl_envs/marl_intersection.py:27-70)."""
@@ -959,3 +1113,4 @@ def bfs_route(net, start_node, goal):
 
 MARoundaboutMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MAIntersectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+MABottleneckMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

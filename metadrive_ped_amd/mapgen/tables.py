@@ -252,7 +252,7 @@ class MapTables:
 RESPAWN_REGION_LONGITUDE = 8.0  # manager/spawn_manager.py:28
 
 
-def spawn_tables(mt, spawn_roads, lane_num):
+def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False):
     """Respawn places (slot 0 of every spawn road x lane) and, for each, the route to every destination
     (end node of the reversed spawn roads): SpawnManager._auto_fill_spawn_roads_randomly /
     get_available_respawn_places (manager/spawn_manager.py:123-209), RoundaboutSpawnManager.
@@ -260,6 +260,8 @@ def spawn_tables(mt, spawn_roads, lane_num):
     from metadrive_ped_amd.mapgen.pg import negate_road
     pg = mt.pg_map
     dests = [negate_road(*r)[1] for r in spawn_roads]
+    if fixed_destination:   # one destination per place: the default of NodeNetworkNavigation.reset
+        dests = [None]
     places, lanes, routes, meta = [], [], [], []
     for road in spawn_roads:
         for li in range(lane_num):
@@ -270,6 +272,8 @@ def spawn_tables(mt, spawn_roads, lane_num):
             places.append([pos[0], pos[1], math.cos(h), math.sin(h), h, 0.0, 0.0, 0.0])
             lanes.append(mt.lane_id[(road[0], road[1], li)])
             for d in dests:
+                if d is None:
+                    d = destination_for(pg, pg.seed, (road[0], road[1], li))
                 nodes, roads_, n, fin = route_arrays(mt, (road[0], road[1], li), d)
                 routes.append([nodes, roads_])
                 meta.append([n, fin])

@@ -25,7 +25,12 @@ ROUNDABOUT_SPAWN_ROADS = [(">>", ">>>"), negate_road("1O0_2_", "1O0_3_"), negate
 # MAIntersectionConfig.spawn_roads (envs/marl_envs/marl_intersection.py:13-18)
 INTERSECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("1X0_0_", "1X0_1_"), negate_road("1X1_0_", "1X1_1_"),
                             negate_road("1X2_0_", "1X2_1_")]
-SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS)
+# MABottleneckConfig.spawn_roads (envs/marl_envs/marl_bottleneck.py:11)
+BOTTLENECK_SPAWN_ROADS = [(">>", ">>>"), negate_road("2Y0_0_", "2Y0_1_")]
+SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS)
+# roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
+# bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)
+FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 
@@ -33,7 +38,7 @@ REGION_LONG, REGION_LAT = 8.0, 3.0
 class RoundaboutScene:
     """Per-env arrays (cap == num_agents slots, all agents) for one env seed.  `spawn_roads` selects the map
     family (the roundabout's by default); everything else is SpawnManager's and shared."""
-    def __init__(self, seed, mt, cfg, spawn_roads=None):
+    def __init__(self, seed, mt, cfg, spawn_roads=None, fixed_destination=False):
         ROUNDABOUT_SPAWN_ROADS = spawn_roads if spawn_roads is not None else globals()["ROUNDABOUT_SPAWN_ROADS"]
         A = cfg["agents_per_env"]
         cap = cfg["cap"]
@@ -70,7 +75,11 @@ class RoundaboutScene:
             long = REGION_LONG / 2 + j * REGION_LONG + rng.uniform(-(REGION_LONG - MAX_VEHICLE_LENGTH) / 2,
                                                                    (REGION_LONG - MAX_VEHICLE_LENGTH) / 2)
             lat = rng.uniform(-(REGION_LAT - MAX_VEHICLE_WIDTH) / 2, (REGION_LAT - MAX_VEHICLE_WIDTH) / 2)
-            dest = dests[int(rng.randint(len(dests)))]
+            if fixed_destination:
+                from metadrive_ped_amd.mapgen.tables import destination_for
+                dest = destination_for(pg, seed, (road[0], road[1], li))
+            else:
+                dest = dests[int(rng.randint(len(dests)))]
             pos = lane.position(long, lat)
             h = wrap_to_pi(lane.heading_theta_at(long))
             sh = self.shape[a]

@@ -73,6 +73,12 @@ class BlockParameterSpace:
         "inner_radius": BoxSpace(min=15, max=45),
         "angle": ConstantSpace(60),
     }
+    BOTTLENECK = {
+        Parameter.length: BoxSpace(min=20, max=50),
+        "lane_num": DiscreteSpace(min=1, max=2),
+        "bottle_len": ConstantSpace(20),
+        "solid_center_line": ConstantSpace(0),
+    }
     STRAIGHT = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
     CURVE = {
         Parameter.length: BoxSpace(min=40.0, max=80.0),

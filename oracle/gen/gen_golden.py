@@ -439,6 +439,38 @@ def section_ma_intersection():
                                       config={k: float(v) for k, v in dict(blk.get_config()).items()}))
 
 
+def section_ma_bottleneck():
+    """Map of MultiAgentBottleneckEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 20 m)
+    + Split (back to 4, exit 60 m) as MABottleneckMap._generate builds it (marl_bottleneck.py:28-69)."""
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.bottleneck import Merge, Split
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_bottleneck import MABottleneckConfig
+    from metadrive.manager.spawn_manager import SpawnManager
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, 4, MagicMock(), MagicMock(), length=60)
+    merge = Merge(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok1 = merge.construct_from_config(dict(lane_num=3, length=20), MagicMock(), MagicMock())
+    split = Split(2, merge.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok2 = split.construct_from_config({"length": 60, "lane_num": 3}, MagicMock(), MagicMock())
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+    spawn_roads = [[r.start_node, r.end_node] for r in MABottleneckConfig["spawn_roads"]]
+    routes = []
+    for sr in MABottleneckConfig["spawn_roads"]:
+        for er in MABottleneckConfig["spawn_roads"]:
+            dest = (-er).end_node
+            path = net.shortest_path((sr.start_node, sr.end_node, 0), dest)
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest, path=path))
+    dump("ma_bottleneck.json", dict(no_cross=bool(ok1 and ok2), roads=roads, spawn_roads=spawn_roads, routes=routes,
+                                    max_capacity=int(SpawnManager.max_capacity(MABottleneckConfig["spawn_roads"], 60, 4)),
+                                    num_agents=int(MABottleneckConfig["num_agents"]),
+                                    merge_config={k: float(v) for k, v in dict(merge.get_config()).items()},
+                                    split_config={k: float(v) for k, v in dict(split.get_config()).items()}))
+
+
 def section_idm():
     """IDM longitudinal model, desired gap, PID steering and the front/back object search
     (SURVEY 8a-10): IDMPolicy.acceleration / desired_gap / steering_control and
@@ -540,6 +572,21 @@ def section_pg_maps_v2():
     specs += [(200 + seed, 2, 3.0, 50, "block_num", 5) for seed in range(0, 4)]
     specs += [(300, 3, 3.5, 50, "block_sequence", "XTO"), (301, 3, 3.5, 50, "block_sequence", "rRX"),
               (302, 2, 3.5, 50, "block_sequence", "TXT")]
+    _pg_maps_cases("pg_maps_v2.json", specs)
+
+
+def section_pg_maps_v3():
+    """Block sequences with the lane-count changing blocks Merge 'y' / Split 'Y' (zero probability in the default
+    distribution, reachable through `map="..."`)."""
+    specs = [(400, 3, 3.5, 50, "block_sequence", "yY"), (401, 3, 3.5, 50, "block_sequence", "SyY"),
+             (402, 2, 3.5, 50, "block_sequence", "YyC"), (403, 3, 3.0, 50, "block_sequence", "yYX"),
+             (404, 2, 3.5, 50, "block_sequence", "YS"), (405, 3, 3.5, 50, "block_sequence", "CyS")]
+    _pg_maps_cases("pg_maps_v3.json", specs)
+
+
+def _pg_maps_cases(fname, specs):
+    from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
+    cases = []
     for seed, lane_num, lane_width, exit_length, method, parameter in specs:
         big, net = build_reference_map(seed, lane_num, lane_width, exit_length, method, parameter, PGBlockDistConfig)
         for f, td in net.graph.items():
@@ -560,10 +607,10 @@ def section_pg_maps_v2():
             spawn.append([[list(l.index) for l in lanes] for lanes in b.get_intermediate_spawn_lanes()])
         cases.append(dict(seed=seed, lane_num=lane_num, lane_width=lane_width, exit_length=exit_length,
                           method=method, parameter=parameter, blocks=blocks, roads=roads, spawn_lanes=spawn))
-    dump("pg_maps_v2.json", dict(cases=cases))
+    dump(fname, dict(cases=cases))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection)
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -24,14 +24,14 @@ def test_config_contract(cs_dist):
 
 
 def test_unbuilt_block_type_fails_loudly():
-    """Every block type of the default distribution is built; the zero-probability ones (forks, merge/split,
-    parking lot, toll gate, bidirection) are not and say so instead of silently changing the map."""
+    """Every block type of the default distribution (and Merge / Split) is built; the other zero-probability ones
+    (forks, parking lot, toll gate, bidirection) are not and say so instead of silently changing the map."""
     from collections import OrderedDict
     from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2, BlockDist, PGMap
     for seed in range(10):
         PGMap(seed)
     d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
-    d["Merge"] = 1.0
+    d["ParkingLot"] = 1.0
     with pytest.raises(NotImplementedError, match="not built yet"):
         PGMap(0, block_dist=BlockDist(d))
 

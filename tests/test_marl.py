@@ -227,3 +227,82 @@ def test_intersection_rollout_parity_gpu():
             assert_state_equal(eng.download_state(), orc.state, where="intersection step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="intersection final")
     assert (orc.state["next_agent_id"] > A).all()
+
+
+# ---- multi-agent bottleneck (envs/marl_envs/marl_bottleneck.py; blocks pgblock/bottleneck.py) -------------------
+def _bottle_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentBottleneckEnv
+    base = dict(num_envs=3, num_scenarios=3)
+    base.update(kw)
+    return BatchedMultiAgentBottleneckEnv(base).config
+
+
+def test_bottleneck_map_equals_reference():
+    from metadrive_ped_amd.mapgen.pg import MABottleneckMap
+    from metadrive_ped_amd.marl import BOTTLENECK_SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_bottleneck.json")) as f:
+        g = json.load(f)
+    m = MABottleneckMap()
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]
+    for (a, b, lanes), ref in zip(roads, g["roads"]):
+        assert len(lanes) == len(ref["lanes"])
+        for l, rl in zip(lanes, ref["lanes"]):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+            np.testing.assert_allclose([l.length, *l.start, *l.end], [rl["length"], *rl["start"], *rl["end"]], atol=1e-9)
+    assert [list(r) for r in BOTTLENECK_SPAWN_ROADS] == g["spawn_roads"]
+    for r in g["routes"]:
+        assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    assert g["max_capacity"] == 48 and g["num_agents"] == 20
+    for k, v in g["merge_config"].items():
+        assert float(m.blocks[1].config[k]) == v
+    for k, v in g["split_config"].items():
+        assert float(m.blocks[2].config[k]) == v
+
+
+def test_bottleneck_lifecycle_on_oracle():
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 2, 20
+    host = HostScene(_bottle_cfg(num_envs=E, num_scenarios=E))
+    assert host.cap == A and host.obs_dim == 4 + 6 + 4 + 10 + 72         # side + lane-line detectors in the obs
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert (_counts(o.state, E)[0] == A).all()
+    # both directions are populated and every agent's route leads to the far end of the map
+    nav = o.state["nav"].reshape(E, -1)
+    assert (nav["route_len"] >= 4).all()
+    rng = np.random.RandomState(6)
+    for t in range(300):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.6
+        a[..., 0] = rng.uniform(-0.15, 0.15, (E, A))
+        o.step(a)
+        act, dy = _counts(o.state, E)
+        assert ((act + dy) <= A).all()
+        obs = o.obs.reshape(E, A, -1)
+        assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+    assert (o.state["next_agent_id"] > A).all()
+
+
+@pytest.mark.gpu
+def test_bottleneck_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 6, 20
+    eng = BatchedEngine(_bottle_cfg(num_envs=E, num_scenarios=E))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="bottleneck reset")
+    rng = np.random.RandomState(9)
+    for t in range(250):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.7
+        a[..., 0] = rng.uniform(-0.2, 0.2, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="bottleneck step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="bottleneck final")
+    assert (orc.state["next_agent_id"] > A).all()
