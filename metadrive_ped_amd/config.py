@@ -117,7 +117,9 @@ def _merge(dst, src, path=""):
         else:
             old = dst[k]
             if old is not None and v is not None and not isinstance(old, dict):
+                # utils/config.py:241-250: int <-> float are interchangeable
                 ok = isinstance(v, type(old)) or (isinstance(old, float) and isinstance(v, int)) or \
+                    (isinstance(old, int) and not isinstance(old, bool) and isinstance(v, float)) or \
                     (k == "map" and isinstance(v, (int, str))) or (k == "horizon")
                 if not ok:
                     raise TypeError("Attempting to update '{}{}' with type {}, expected {}".format(

@@ -234,3 +234,43 @@ def test_random_lanes_and_inverse_traffic_rollout_parity():
         if t % 30 == 0:
             assert_state_equal(eng.download_state(), orc.state, where="random lanes step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="random lanes final")
+
+
+@pytest.mark.parametrize("name,cfg_kw,steps", [
+    # BASELINE configs[0] shape: one env, map 'S', no traffic, lidar off -> 19-dim obs
+    ("c1_single_env", dict(num_envs=1, num_scenarios=1, start_seed=1010, map="S", traffic_density=0.0,
+                           vehicle_config=dict(lidar=dict(num_lasers=0, distance=0))), 120),
+    # maximum mover capacity (128 slots: two 64-wide chunks everywhere), dense traffic on 5-block maps
+    ("max_capacity", dict(num_envs=6, num_scenarios=6, map=5, traffic_density=0.6, mover_capacity=128, horizon=300), 260),
+    # maximum beam count, and beam counts that are not a multiple of the 64-wide sector
+    ("beams_1024", dict(num_envs=4, num_scenarios=4, vehicle_config=dict(lidar=dict(num_lasers=1024, distance=50))), 60),
+    ("beams_30", dict(num_envs=4, num_scenarios=4, vehicle_config=dict(lidar=dict(num_lasers=30, distance=50))), 60),
+    ("beams_100_short_range", dict(num_envs=4, num_scenarios=4, vehicle_config=dict(lidar=dict(num_lasers=100, distance=12.5))), 60),
+    # explicit capacity smaller than the auto choice would be; no traffic at all; long straight-only map
+    ("no_traffic_tight_cap", dict(num_envs=8, num_scenarios=8, traffic_density=0.0, mover_capacity=8, map="SSS"), 150),
+])
+def test_edge_configurations_parity(name, cfg_kw, steps):
+    """Sizes at the limits of the ABI (MD_MAX_CAP, MD_MAX_BEAMS), degenerate ones (one env, lidar off, no traffic)
+    and ragged ones (beam counts that leave a partial sector): HIP == oracle, bit for bit."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    cfg = make_config(cfg_kw)
+    eng = BatchedEngine(cfg)
+    E = eng.E
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where=name + " reset")
+    for t in range(steps):
+        a = scripted_actions(E, 1, t, seed=23)
+        a[:, :, 0] *= 0.3
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 40 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="%s step %d" % (name, t))
+    assert_state_equal(eng.download_state(), orc.state, where=name + " final")
+    if name == "max_capacity":
+        fl = eng.host.state["shape0"]["flags"].reshape(E, -1)
+        assert ((fl & 0xF) == 1).sum(1).max() > 64, "the scene must actually use slots beyond the first 64-wide chunk"
