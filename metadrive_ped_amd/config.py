@@ -148,6 +148,11 @@ def make_config(user=None):
         cfg["block_dist_config"] = BlockDist()
     elif isinstance(cfg["block_dist_config"], dict):
         cfg["block_dist_config"] = BlockDist(cfg["block_dist_config"])
+    if cfg["is_multi_agent"] and abs(cfg["traffic_density"]) >= 1e-2:
+        raise NotImplementedError("traffic_density > 0 in a multi-agent env is not built (the reference's multi-agent "
+                                  "envs run without traffic: multi_agent_metadrive.py:58)")
+    if cfg["is_multi_agent"] and abs(cfg["accident_prob"]) >= 1e-2:
+        raise NotImplementedError("accident scenes in a multi-agent env are not built")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
