@@ -678,6 +678,132 @@ __device__ void trigger_env(const MdLane* lanes, const MdState& s, const MdConfi
 }
 
 // ------------------------------------------------------------------------------------------------
+// Multi-agent lifecycle of one env by the whole workgroup: the block-parallel form of md_lifecycle_env
+// (include/md_entity.h, which the oracle runs serially).  Per-agent state machine: one thread per agent; the
+// search for a safe spawn place -- (place, vehicle) overlap tests, 8 x 40 of them -- spread over all threads with
+// an LDS OR per place; the respawn itself (RNG draws, slot rewrite) on thread 0.  md_lifecycle_env re-scans
+// after a respawn; that second scan can never find a place (every safe place of the first scan is marked used,
+// the unsafe ones are still occupied), so one scan is exact.  scratch: >= 4 ints of LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ void lifecycle_block(const MdWorld& w, const MdState& s, const MdConfig& c, int m, int tid, int nthreads,
+                                int* scratch) {
+    const int A = c.agents_per_env;
+    int* cnt_active = scratch;      // agents that keep driving
+    int* cnt_dying = scratch + 1;   // bodies waiting out delay_done
+    int* hit_mask = scratch + 2;    // bit p: spawn place p is occupied
+    if (tid == 0) {
+        s.env_steps[0] += 1;
+        *cnt_active = 0;
+        *cnt_dying = 0;
+        *hit_mask = 0;
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += nthreads) {
+        MdShape* sh = &s.shape[a];
+        MdNav* nav = &s.nav[a];
+        if (!(sh->flags & MD_F_ALIVE)) continue;
+        bool count_down = true;
+        if (!(sh->flags & MD_F_STATIC)) {
+            const uint32_t fl = s.flags[a];
+            if (nav->done || (fl & MD_FL_TRUNCATED)) {
+                if ((fl & MD_FL_ARRIVE_DEST) || c.delay_done <= 0) {
+                    sh->flags &= ~MD_F_ALIVE;
+                    count_down = false;
+                } else {
+                    sh->flags |= MD_F_STATIC;
+                    nav->timer = c.delay_done;
+                    s.dyn[a].speed = 0.0f;
+                }
+            } else {
+                atomicAdd(cnt_active, 1);
+                count_down = false;
+            }
+        }
+        if (count_down) {
+            nav->timer -= 1;
+            if (nav->timer <= 0) sh->flags &= ~MD_F_ALIVE;
+            else atomicAdd(cnt_dying, 1);
+        }
+    }
+    __syncthreads();
+    const bool horizon_open = !(c.horizon > 0 && s.env_steps[0] >= c.horizon);
+    const bool may_respawn = c.allow_respawn && horizon_open && w.spawn_off != nullptr && (*cnt_active + *cnt_dying < A);
+    if (may_respawn) {  // block-uniform
+        const int p0 = w.spawn_off[m];
+        const int np_ = min(w.spawn_off[m + 1] - p0, 32);
+        for (int idx = tid; idx < np_ * c.cap; idx += nthreads) {
+            const int p = idx / c.cap, j = idx - p * c.cap;
+            const MdShape o = s.shape[j];
+            if (!md_present(o.flags) || md_kind_of(o.flags) != MD_KIND_VEHICLE) continue;
+            const float* pl = w.spawn_place + 8 * (size_t)(p0 + p);
+            if (md_obb_obb(pl[0], pl[1], pl[2], pl[3], MD_RESPAWN_HALF_LEN, MD_RESPAWN_HALF_WID, o.cx, o.cy, o.c, o.s, o.hl, o.hw))
+                atomicOr(hit_mask, 1 << p);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t all = np_ >= 32 ? 0xFFFFFFFFu : ((1u << np_) - 1u);
+            uint32_t safe = ~(uint32_t)(*hit_mask) & all;
+            const int n_safe = __popc(safe);
+            int slot = -1;
+            for (int a = 0; a < A; ++a)
+                if (!(s.shape[a].flags & MD_F_ALIVE)) { slot = a; break; }
+            if (n_safe > 0) {
+                int k = (int)(md_rng_next(s.rng) % (uint32_t)n_safe);   // ascending place order, like the serial `safe[]`
+                while (k-- > 0) safe &= safe - 1;
+                const int p = __ffs((int)safe) - 1;
+                if (slot >= 0) {
+                    const float* pl = w.spawn_place + 8 * (size_t)(p0 + p);
+                    const int dest = (int)(md_rng_next(s.rng) % (uint32_t)w.n_dest);
+                    const size_t ri = ((size_t)(p0 + p) * w.n_dest + dest);
+                    const int32_t* rt = w.spawn_route + ri * 2 * MD_ROUTE_LEN;
+                    MdShape* sh = &s.shape[slot];
+                    sh->cx = pl[0];
+                    sh->cy = pl[1];
+                    sh->c = pl[2];
+                    sh->s = pl[3];
+                    sh->flags = MD_KIND_VEHICLE | MD_F_ALIVE | MD_F_AGENT | MD_F_SPAWNED;
+                    sh->aux = -1;
+                    MdDyn* d = &s.dyn[slot];
+                    d->heading = pl[4];
+                    d->speed = 0.0f;
+                    d->steering = 0.0f;
+                    d->throttle = 0.0f;
+                    d->last_x = pl[0];
+                    d->last_y = pl[1];
+                    d->last_c = pl[2];
+                    d->last_s = pl[3];
+                    MdNav* nav = &s.nav[slot];
+                    nav->lane = w.spawn_lane[p0 + p];
+                    nav->route_len = w.spawn_route_meta[2 * ri];
+                    nav->ck0 = 0;
+                    nav->ck1 = (nav->route_len <= 2) ? 0 : 1;
+                    nav->target_lane = -1;
+                    nav->timer = 0;
+                    nav->steps = 0;
+                    nav->done = 0;
+                    s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
+                    for (int q = 0; q < MD_ROUTE_LEN; ++q) {
+                        s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
+                        s.route_roads[(size_t)slot * MD_ROUTE_LEN + q] = rt[MD_ROUTE_LEN + q];
+                    }
+                    s.pid[slot].energy = 0.0f;
+                    s.flags[slot] = 0;
+                    s.action[2 * slot] = 0.0f;
+                    s.action[2 * slot + 1] = 0.0f;
+                    s.agent_id[slot] = s.next_agent_id[0];
+                    s.next_agent_id[0] += 1;
+                    *cnt_active += 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // episode over: nobody left and nobody can come back
+    if (tid == 0 && c.auto_reset && *cnt_active == 0 && !(c.allow_respawn && horizon_open)) s.need_reset[0] = 1;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
 // The per-env kernel.  PH selects the phases (a compile-time mask: the single-phase entry points
 // instantiate it with one bit, md_step with all of them).
 // ------------------------------------------------------------------------------------------------
@@ -762,7 +888,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     }
     if (kLidarOnly) {
         copy16(l_shape, gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
-    } else if (kBlock == 256) {
+    } else if (kBlock >= 256) {
         // Fast path: ALL global loads of the stage-in are issued before the first LDS store, so the whole image
         // arrives in one memory round trip (a chain of copy loops waits for each loop's loads in turn: 7 trips,
         // ~9 k cycles per env).  16-B units per array at cap <= 128: shape/dyn/pid/param <= 256 (one per thread),
@@ -787,7 +913,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         }
         if (tid < n64) r_nav0 = g_nav[tid];
         if (tid < nrr) r_rr0 = g_rr[tid];
-        if (tid + 256 < nrr) r_rr1 = g_rr[tid + 256];
+        if (tid + kBlock < nrr) r_rr1 = g_rr[tid + kBlock];
         if (pc) {
             r_act = (kFusedAct && tid < c.agents_per_env) ? reinterpret_cast<const float2*>(gv.agent_action)[tid]
                                                           : reinterpret_cast<const float2*>(gv.action)[tid];
@@ -808,9 +934,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         }
         if (tid < n64) reinterpret_cast<uint4*>(l_nav)[tid] = r_nav0;
         if (tid < nrr) reinterpret_cast<uint4*>(l_rroads)[tid] = r_rr0;
-        if (tid + 256 < nrr) reinterpret_cast<uint4*>(l_rroads)[tid + 256] = r_rr1;
-        for (int i = tid + 256; i < n64; i += 256) reinterpret_cast<uint4*>(l_nav)[i] = g_nav[i];
-        for (int i = tid + 512; i < nrr; i += 256) reinterpret_cast<uint4*>(l_rroads)[i] = g_rr[i];
+        if (tid + kBlock < nrr) reinterpret_cast<uint4*>(l_rroads)[tid + kBlock] = r_rr1;
+        for (int i = tid + kBlock; i < n64; i += kBlock) reinterpret_cast<uint4*>(l_nav)[i] = g_nav[i];
+        for (int i = tid + 2 * kBlock; i < nrr; i += kBlock) reinterpret_cast<uint4*>(l_rroads)[i] = g_rr[i];
         if (pc) {
             reinterpret_cast<float2*>(l_action)[tid] = r_act;
             l_flags[tid] = r_fl;
@@ -885,8 +1011,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MD_STAMP_AT(1);
 
     if ((PH & PH_LIFECYCLE) && MULTI && !just_reset) {
-        if (tid == 0) md_lifecycle_env(&w, &s, &c, w.env_map[e]);
-        __syncthreads();
+        lifecycle_block(w, s, c, w.env_map[e], tid, kBlock, reinterpret_cast<int*>(l_onlane));
     }
 
     // Single-agent envs plan the traffic one step AHEAD (see the observe stage below): the IDM decision of step
