@@ -108,11 +108,17 @@ MD_HD void md_replay_mover(const MdState* s, const MdConfig* c, int n) {
     d->speed = s->track_dyn[2 * at + 1];
 }
 
+MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n);
+
+/* What the step does with slot n between "actions are known" and "poses are new": replay mode moves the
+ * non-agent slots along their tracks, everything else integrates.  (Apart from md_integrate_mover so that the
+ * trigger-mode kernel does not carry the replay code: it costs 4 % there.) */
+MD_HD void md_advance_mover(const MdState* s, const MdConfig* c, int n) {
+    if (c->traffic_mode == 3 && n >= c->agents_per_env) md_replay_mover(s, c, n);
+    else md_integrate_mover(s, c, n);
+}
+
 MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
-    if (c->traffic_mode == 3 && n >= c->agents_per_env) {
-        md_replay_mover(s, c, n);
-        return;
-    }
     MdShape* sh = &s->shape[n];
     if (!md_drives(sh->flags) || (sh->flags & MD_F_SPAWNED)) return;
     MdDyn* d = &s->dyn[n];

@@ -620,8 +620,9 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const Md
 // Observation / reward / done of one agent by one wave: the nine independent geometric evaluations
 // (md_observe_task) run on lanes 0..8 at once, lane 0 gathers them with v_readlane and combines.
 // ------------------------------------------------------------------------------------------------
-__device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
-                                   int just_reset, int lane_id, float* wave_scratch /* LDS, MD_OBS_TASKS*5 floats */) {
+// One agent per wave (`a` wave-uniform: its context lives in scalar registers) -- the single-agent envs' form.
+__device__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
+                                    int just_reset, int lane_id, float* wave_scratch /* LDS, MD_OBS_TASKS*5 floats */) {
     MdObsCtx k;
     md_observe_ctx(lanes, roads, &s, a, &k);
     if (lane_id < MD_OBS_TASKS) {
@@ -630,12 +631,38 @@ __device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, con
 #pragma unroll
         for (int i = 0; i < 5; ++i) wave_scratch[lane_id * 5 + i] = mine[i];
     }
-    // same wave: the LDS unit executes a wave's ds_write / ds_read in order; the fence keeps the
-    // compiler from moving lane 0's reads above the other lanes' writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane_id == 0) md_observe_combine(&k, &s, &c, a, just_reset, (const float (*)[5])wave_scratch);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Up to FOUR agents per wave: 16-lane group g serves agent a_base + g (tasks on its lanes 0..8, combine on its
+// lane 0): a 40-agent env finishes in 3 rounds of 4 waves instead of 10 (multi-agent kernels only).
+constexpr int kObsGroups = 4;
+constexpr int kObsScratch = kObsGroups * 48;  // floats of LDS per wave: MD_OBS_TASKS * 5 (= 45) per group, padded
+
+__device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a_base,
+                                   int just_reset, int lane_id, float* wave_scratch /* LDS, kObsScratch floats */) {
+    const int g = lane_id >> 4, sub = lane_id & 15;
+    const int a = a_base + g;
+    const bool live = a < c.agents_per_env;
+    float* scratch = wave_scratch + g * 48;
+    MdObsCtx k;
+    if (live) md_observe_ctx(lanes, roads, &s, a, &k);
+    if (live && sub < MD_OBS_TASKS) {
+        float mine[5];
+        md_observe_task(sub, &k, &s, &c, a, mine);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) scratch[sub * 5 + i] = mine[i];
+    }
+    // same wave: the LDS unit executes a wave's ds_write / ds_read in order; the fence keeps the
+    // compiler from moving the combining lanes' reads above the other lanes' writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (live && sub == 0) md_observe_combine(&k, &s, &c, a, just_reset, (const float (*)[5])scratch);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -820,7 +847,7 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
 constexpr int kStageMaxLanes = 64;
 constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot removed in this step
 
-// RESPAWN: traffic_mode respawn / hybrid (compiled apart: its slot-rewriting code costs the common trigger-mode
+// RESPAWN: the non-trigger traffic modes -- respawn / hybrid / replay (compiled apart: its slot-rewriting code costs the common trigger-mode
 // kernel 8 VGPRs and one wave of occupancy when it is merely branched around).
 // Threads per env workgroup.  256 = 4 waves: measured best (tools/run_blocks.sh rebuilds with -DMD_ENV_BLOCK=128/64).
 #ifndef MD_ENV_BLOCK
@@ -861,8 +888,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     const int n_stage_lanes = STAGE_MAP ? w.max_lanes : 0, n_stage_roads = STAGE_MAP ? w.max_roads : 0;
     MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
     MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + n_stage_lanes);
-    float* l_scratch = reinterpret_cast<float*>(l_roads + n_stage_roads) + wave * 48;  // per-wave observe results
-    MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + n_stage_roads) + kWaves * 48);
+    constexpr int kScratch = MULTI ? kObsScratch : 48;  // floats per wave (launch<> sizes the LDS image the same way)
+    float* l_scratch = reinterpret_cast<float*>(l_roads + n_stage_roads) + wave * kScratch;  // per-wave observe results
+    MdParam* l_param = reinterpret_cast<MdParam*>(reinterpret_cast<float*>(l_roads + n_stage_roads) + kWaves * kScratch);
     int32_t* l_final = reinterpret_cast<int32_t*>(l_param + cap);
     unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
     uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_det + 2 * c.agents_per_env);  // fused step: localize / contacts results,
@@ -980,7 +1008,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             l_action[2 * j + 1] = 0.0f;
             l_flags[j] = 0u;
         }
-        if (MULTI || RESPAWN) {  // respawns rewrote the routes: restore them too
+        if (MULTI || (RESPAWN && c.traffic_mode != 3)) {  // respawns rewrote the routes: restore them too
             for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
                 gv.route_nodes[i] = gv.route_nodes0[i];
                 l_rroads[i] = gv.route_roads0[i];
@@ -1032,7 +1060,10 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     }
     MD_STAMP_AT(3);
     if ((PH & PH_INTEGRATE) && !just_reset) {
-        for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
+        for (int j = tid; j < cap; j += kBlock) {
+            if (RESPAWN) md_advance_mover(&s, &c, j);  // the non-trigger traffic modes' kernel (respawn / hybrid / replay)
+            else md_integrate_mover(&s, &c, j);
+        }
         __syncthreads();
     }
     MD_STAMP_AT(4);
@@ -1103,7 +1134,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         // (reads poses / lanes / speeds, writes the traffic slots' action, IDM timer / target lane and PID state:
         // disjoint from what observe writes -- obs, reward, the agent's flags / steps / energy).
         if (wave == 0) {
-            for (int a = 0; a < c.agents_per_env; ++a) observe_agent_wave(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+            for (int a = 0; a < c.agents_per_env; ++a) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
         } else {
             for (int j = c.agents_per_env + wave - 1; j < cap; j += kWaves - 1) {
                 const int f = s.shape[j].flags;  // wave-uniform
@@ -1112,7 +1143,12 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         }
         MD_STAMP_AT(8);
     } else if (PH & PH_OBSERVE) {
-        for (int a = wave; a < c.agents_per_env; a += kWaves) observe_agent_wave(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+        if (MULTI) {
+            for (int a = wave * kObsGroups; a < c.agents_per_env; a += kWaves * kObsGroups)
+                observe_agent_wave(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+        } else {
+            for (int a = wave; a < c.agents_per_env; a += kWaves) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+        }
         MD_STAMP_AT(8);
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
@@ -1234,12 +1270,13 @@ template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
     const bool stage = w->max_lanes <= kStageMaxLanes;
+    constexpr bool kCanMultiLds = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;  // same rule as the MULTI kernel variant below
     // the lidar-only kernel stages nothing but the shapes: asking for the full image would cost it occupancy
     const size_t lds = (PH == PH_LIDAR) ? (size_t)c->cap * sizeof(MdShape) + 16 :
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
-                       (MD_ENV_BLOCK / 64) * 48 * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
+                       (MD_ENV_BLOCK / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
                        (size_t)c->cap * 8;
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
@@ -1248,14 +1285,14 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     }
     const dim3 grid(c->n_envs);
     const hipStream_t st = (hipStream_t)stream;
-    constexpr bool kCanRespawn = (PH & (PH_TRAFFIC | PH_RESET)) != 0;
+    constexpr bool kCanRespawn = (PH & (PH_TRAFFIC | PH_RESET | PH_INTEGRATE)) != 0;
     constexpr bool kCanMulti = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;
 #define MD_LAUNCH(STAGE, RESP, MUL) \
     hipLaunchKernelGGL((env_kernel<PH, STAGE, RESP, MUL>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset)
     if (kCanMulti && c->is_multi_agent) {
         if (stage) MD_LAUNCH(true, false, kCanMulti);
         else MD_LAUNCH(false, false, kCanMulti);
-    } else if (kCanRespawn && (c->traffic_mode == 1 || c->traffic_mode == 2)) {
+    } else if (kCanRespawn && c->traffic_mode != 0) {
         if (stage) MD_LAUNCH(true, kCanRespawn, false);
         else MD_LAUNCH(false, kCanRespawn, false);
     } else if (stage) {

@@ -59,7 +59,7 @@ def _build_one(job):
     pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
     mt = MapTables(pg)
-    if scene_cfg["traffic_mode"] != "trigger" and abs(scene_cfg["traffic_density"]) >= 1e-2:
+    if scene_cfg["traffic_mode"] in ("respawn", "hybrid") and abs(scene_cfg["traffic_density"]) >= 1e-2:
         from metadrive_ped_amd.mapgen.tables import respawn_tables
         mt.respawn = respawn_tables(mt, s)
     return mt, EnvScene(s, mt, scene_cfg)

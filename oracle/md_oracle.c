@@ -120,7 +120,7 @@ EXPORT int ref_integrate(const MdWorld* w, const MdState* s, const MdConfig* c) 
     (void)w;
     for (int e = 0; e < c->n_envs; ++e) {
         MdState v = md_env_view(s, c, e); /* env-local slots: the replay mode tells agents from traffic by slot */
-        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
+        for (int j = 0; j < c->cap; ++j) md_advance_mover(&v, c, j);
     }
     return MD_OK;
 }
@@ -374,7 +374,7 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
     if (!just_reset) {
         if (!plan_ahead) idm_env(w, s, c, e);
         MdState v = md_env_view(s, c, e);
-        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
+        for (int j = 0; j < c->cap; ++j) md_advance_mover(&v, c, j);
     }
     for (int j = 0; j < c->cap; ++j) localize_mover(w, s, c, e, base + j);
     for (int j = 0; j < c->cap; ++j) contacts_mover(w, s, c, e, j);
