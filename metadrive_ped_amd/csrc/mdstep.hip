@@ -847,7 +847,8 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
 constexpr int kStageMaxLanes = 64;
 constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot removed in this step
 
-// RESPAWN: the non-trigger traffic modes -- respawn / hybrid / replay (compiled apart: its slot-rewriting code costs the common trigger-mode
+// RESPAWN: the variant for everything off the headline path -- traffic modes respawn / hybrid / replay, detected
+// sets for the `num_others` block (compiled apart: its slot-rewriting code costs the common trigger-mode
 // kernel 8 VGPRs and one wave of occupancy when it is merely branched around).
 // Threads per env workgroup.  256 = 4 waves: measured best (tools/run_blocks.sh rebuilds with -DMD_ENV_BLOCK=128/64).
 #ifndef MD_ENV_BLOCK
@@ -895,7 +896,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
     uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_det + 2 * c.agents_per_env);  // fused step: localize / contacts results,
     uint32_t* l_cfl = l_onlane + cap;                                                  // merged into flags afterwards
-    const bool track_det = (PH == PH_ALL) && g.detected != nullptr;
+    // detected sets: only the RESPAWN ("everything else") and MULTI variants carry the tracking code; launch<> picks
+    // one of them whenever MdState.detected is set, so the lean trigger-mode kernel pays nothing for it
+    const bool track_det = (PH == PH_ALL) && (RESPAWN || MULTI) && g.detected != nullptr;
 
     const MdState gv = md_env_view(&g, &c, e);  // this env's slices of the global arrays
     constexpr bool kLidarOnly = (PH == PH_LIDAR);
@@ -1008,7 +1011,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             l_action[2 * j + 1] = 0.0f;
             l_flags[j] = 0u;
         }
-        if (MULTI || (RESPAWN && c.traffic_mode != 3)) {  // respawns rewrote the routes: restore them too
+        if (MULTI || (RESPAWN && (c.traffic_mode == 1 || c.traffic_mode == 2))) {  // respawns rewrote the routes: restore them too
             for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
                 gv.route_nodes[i] = gv.route_nodes0[i];
                 l_rroads[i] = gv.route_roads0[i];
@@ -1292,7 +1295,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     if (kCanMulti && c->is_multi_agent) {
         if (stage) MD_LAUNCH(true, false, kCanMulti);
         else MD_LAUNCH(false, false, kCanMulti);
-    } else if (kCanRespawn && c->traffic_mode != 0) {
+    } else if (kCanRespawn && (c->traffic_mode != 0 || (PH == PH_ALL && s->detected != nullptr))) {
         if (stage) MD_LAUNCH(true, kCanRespawn, false);
         else MD_LAUNCH(false, kCanRespawn, false);
     } else if (stage) {
