@@ -460,8 +460,9 @@ __device__ __forceinline__ void wave_argmin(float& key, int& slot) {
     slot = bs;
 }
 
+// wave_list: >= 24 ints of LDS private to this wave (the compacted candidate list)
 __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
-                                 const MdConfig& c, int m, int slot, int lane_id) {
+                                 const MdConfig& c, int m, int slot, int lane_id, int* wave_list) {
     constexpr float kInf = 3.0e38f;
     MdIdmPlan plan;
     plan.success = plan.use_ref = plan.fail = 0;
@@ -501,19 +502,33 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const Md
             cur_long[i] = bcast_f(my_cur, i);
             left_long[i] = (plan.ids[i] >= 0) ? lanes[plan.ids[i]].length - cur_long[i] : 0.0f;
         }
-        const int npairs = c.cap * 3;
-        if (npairs <= 64) {
-            // (2) every (scanned lane i, object j) pair on its own lane of the wave: ONE Frenet evaluation
+        // candidate objects (get_surrounding_objects: within 50 m, present, not the vehicle itself), compacted in
+        // ascending slot order into wave_list: usually a handful, whatever the slot capacity is
+        int n_cand = 0;
+        for (int j0 = 0; j0 < c.cap; j0 += 64) {
+            const int j = j0 + lane_id;
+            const bool is_c = j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j < c.cap ? j : 0], px, py);
+            const unsigned long long mk = __ballot(is_c);
+            const int rank = n_cand + __popcll(mk & ((1ull << lane_id) - 1ull));
+            if (is_c && rank < 21) wave_list[rank] = j;
+            n_cand += __popcll(mk);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int npairs = n_cand * 3;
+        if (npairs <= 63) {
+            // (2) every (scanned lane i, candidate j) pair on its own lane of the wave: ONE Frenet evaluation
             //     per pair (on lane i for a same-lane object, on the object's lane for a connected one)
             float val = 0.0f;
             int meta = 0;  // bit0 same-lane, bit1 lane i precedes obj lane, bit2 obj lane precedes lane i, bits 4-5 i, bits 8.. j
-            {
+            if (n_cand > 0) {
                 const int p = lane_id;
-                const int i = p / c.cap;
-                const int j = p - i * c.cap;
+                const int i = p / n_cand;
+                const int j = (p < npairs) ? wave_list[p - i * n_cand] : 0;
                 const int id_i = (i == 0) ? plan.ids[0] : ((i == 1) ? plan.ids[1] : plan.ids[2]);
                 const float cur_i = (i == 0) ? cur_long[0] : ((i == 1) ? cur_long[1] : cur_long[2]);
-                if (p < npairs && id_i >= 0 && j != slot && md_idm_is_candidate(&s.shape[j], px, py)) {
+                if (p < npairs && id_i >= 0) {
                     const int ol = md_obj_lane_of(&s, j);
                     const MdLane* L = &lanes[id_i];
                     int mt = (i << 4) | (j << 8);
@@ -1057,7 +1072,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         MD_STAMP_AT(2);
         for (int j = c.agents_per_env + wave; j < cap; j += kWaves) {
             const int f = s.shape[j].flags;  // wave-uniform
-            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane);
+            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
         }
         __syncthreads();
     }
@@ -1141,7 +1156,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         } else {
             for (int j = c.agents_per_env + wave - 1; j < cap; j += kWaves - 1) {
                 const int f = s.shape[j].flags;  // wave-uniform
-                if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane);
+                if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
             }
         }
         MD_STAMP_AT(8);
