@@ -61,7 +61,8 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
 }
 
 /* observation layout offsets (obs/state_obs.py:64-151) */
-MD_HD int md_obs_mid(const MdConfig* c) { return c->n_side > 0 ? c->n_side : 2; }              /* heading_diff ... */
+MD_HD int md_obs_base(const MdConfig* c) { return c->random_agent_model ? 2 : 0; }               /* [length, width] first */
+MD_HD int md_obs_mid(const MdConfig* c) { return md_obs_base(c) + (c->n_side > 0 ? c->n_side : 2); } /* heading_diff ... */
 MD_HD int md_obs_ll(const MdConfig* c) { return md_obs_mid(c) + 6; }                             /* lane-line block  */
 MD_HD int md_obs_navi(const MdConfig* c) { return md_obs_ll(c) + (c->n_lane_line > 0 ? c->n_lane_line : 1); }
 /* "others" block: num_others nearest detected vehicles x 4 dims (+4 with add_others_navi), between navi and cloud */
@@ -243,9 +244,14 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     /* ---- state obs (obs/state_obs.py:64-151) ---- */
     float speed_kmh = md_fabs(d->speed) * 3.6f;
     const MdParam* P = &s->param[n];
+    const int o_base = md_obs_base(c);
+    if (o_base) { /* random_agent_model: the vehicle's own size (LENGTH / MAX_LENGTH, WIDTH / MAX_WIDTH; state_obs.py:70-75) */
+        obs[0] = md_clip(2.0f * s->shape[n].hl / 10.0f, 0.0f, 1.0f);
+        obs[1] = md_clip(2.0f * s->shape[n].hw / 2.5f, 0.0f, 1.0f);
+    }
     if (c->n_side <= 0) { /* side detector off: distances to the route's left / right border */
-        obs[0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
-        obs[1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
+        obs[o_base + 0] = md_clip(to_left / c->total_width, 0.0f, 1.0f);
+        obs[o_base + 1] = md_clip(to_right / c->total_width, 0.0f, 1.0f);
     }
     obs[o_mid + 0] = r[1][0];
     obs[o_mid + 1] = md_clip((speed_kmh + 1.0f) / (P->max_speed_kmh + 1.0f), 0.0f, 1.0f);

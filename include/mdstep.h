@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 4
+#define MD_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -273,7 +273,7 @@ typedef struct MdConfig {
     int32_t agents_per_env;
     int32_t cap;               /* mover slots per env                                            */
     int32_t n_beams;           /* lidar num_lasers (0 = lidar off)                               */
-    int32_t obs_dim;           /* (n_side or 2) + 6 + (n_lane_line or 1) + 10 + n_beams  (= 19 + n_beams by default) */
+    int32_t obs_dim;           /* [2 if random_agent_model] + (n_side or 2) + 6 + (n_lane_line or 1) + 10 + [others] + n_beams (= 19 + n_beams by default) */
     int32_t substeps;          /* decision_repeat (envs/base_env.py:186)  = 5                     */
     int32_t horizon;           /* 0 = None                                                       */
     float dt;                  /* physics_world_step_size (envs/base_env.py:185) = 0.02          */
@@ -307,7 +307,7 @@ typedef struct MdConfig {
     int32_t num_others;        /* vehicle_config.lidar.num_others: nearest detected vehicles in the obs (0 = none) */
     int32_t add_others_navi;   /* vehicle_config.lidar.add_others_navi                            */
     int32_t track_len;         /* frames in MdState.track_* (traffic_mode 3); later steps hold the last frame */
-    int32_t pad2;
+    int32_t random_agent_model;/* 1: two extra leading obs dims, length / 10 and width / 2.5 (obs/state_obs.py:70-75) */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

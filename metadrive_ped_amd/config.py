@@ -104,7 +104,7 @@ BATCH_DEFAULT_CONFIG = dict(
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
 )
 
-_OFF_ONLY = dict(use_render=False, image_observation=False, random_agent_model=False, random_traffic=False)
+_OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False)
 
 
 def _merge(dst, src, path=""):
@@ -151,6 +151,9 @@ def make_config(user=None):
     if cfg["is_multi_agent"] and abs(cfg["traffic_density"]) >= 1e-2:
         raise NotImplementedError("traffic_density > 0 in a multi-agent env is not built (the reference's multi-agent "
                                   "envs run without traffic: multi_agent_metadrive.py:58)")
+    if cfg["is_multi_agent"] and cfg["random_agent_model"]:
+        raise NotImplementedError("random_agent_model in a multi-agent env is not built (a respawn would have to draw a "
+                                  "new vehicle class on the device)")
     if cfg["is_multi_agent"] and abs(cfg["accident_prob"]) >= 1e-2:
         raise NotImplementedError("accident scenes in a multi-agent env are not built")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:

@@ -78,7 +78,8 @@ class HostScene:
         vc = cfg["vehicle_config"]
         self.n_side = int(vc["side_detector"]["num_lasers"]) if vc["side_detector"]["distance"] > 0 else 0
         self.n_ll = int(vc["lane_line_detector"]["num_lasers"]) if vc["lane_line_detector"]["distance"] > 0 else 0
-        self.state_dim = (self.n_side or 2) + 6 + (self.n_ll or 1) + 10   # 19 with both detectors off
+        self.obs_base = 2 if cfg["random_agent_model"] else 0            # [length, width] lead the state dims
+        self.state_dim = self.obs_base + (self.n_side or 2) + 6 + (self.n_ll or 1) + 10   # 19 with everything off
         # "others" block only exists with the lidar on (obs/state_obs.py:172-183)
         self.num_others = int(vc["lidar"]["num_others"]) if self.n_beams > 0 else 0
         self.add_others_navi = bool(vc["lidar"]["add_others_navi"]) and self.num_others > 0
@@ -99,7 +100,7 @@ class HostScene:
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
-                         random_lane_num=cfg["random_lane_num"])
+                         random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
@@ -191,6 +192,7 @@ class HostScene:
         self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
         self.md_config.n_side, self.md_config.n_lane_line = self.n_side, self.n_ll
         self.md_config.num_others, self.md_config.add_others_navi = self.num_others, int(self.add_others_navi)
+        self.md_config.random_agent_model = int(bool(cfg["random_agent_model"]))
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
@@ -316,10 +318,10 @@ class BatchedEngine:
         h = self.host
         if h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
             self.line_detector(self._side_beams, h.n_side, float(self.cfg["vehicle_config"]["side_detector"]["distance"]),
-                               self.SIDE_MASK, self.state_dev["obs"], h.obs_dim, 0)
+                               self.SIDE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base)
         if h.n_ll:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
             self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
-                               self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, (h.n_side or 2) + 6)
+                               self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base + (h.n_side or 2) + 6)
         self._lidar_noise()
         if self._rec is not None:
             self._record_frame()

@@ -78,7 +78,7 @@ class BatchedMetaDriveEnv:
         n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
         n_o = lidar["num_others"] * (8 if lidar["add_others_navi"] else 4) if n > 0 else 0
-        self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 10 + n_o + n
+        self._obs_dim = (2 if self.config["random_agent_model"] else 0) + (n_s or 2) + 6 + (n_l or 1) + 10 + n_o + n
         self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
         self.action_space = make_action_space(self.config)
         self.start_seed = self.config["start_seed"]

@@ -99,9 +99,14 @@ class EnvScene:
         else:
             spawn_idx = cfg["spawn_lane_index"][2]
         spawn_lane_index = (FirstBlock.NODE_1, FirstBlock.NODE_2, spawn_idx)
+        agent_model = cfg["agent_vehicle_model"]
+        if cfg.get("random_agent_model", False):
+            # VehicleAgentManager._create_agents -> random_vehicle_type(self.np_random), uniform over the five
+            # classes (manager/agent_manager.py:41, component/vehicle/vehicle_type.py:269-281)
+            agent_model = str(agent_mgr.np_random.choice(["s", "m", "l", "xl", "default"], p=[0.2] * 5))
         vehicle_seed = engine.generate_seed()
         agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
-        self._place_vehicle(0, cfg["agent_vehicle_model"], vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
+        self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
                             cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT)
 
         # ---- traffic (trigger mode) ----

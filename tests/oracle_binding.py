@@ -119,11 +119,11 @@ class OracleWorld:
         vc = h.cfg["vehicle_config"]
         if h.n_side:
             self.call("ref_line_detector", C.c_void_p(h.side_beams.ctypes.data), h.n_side, C.c_float(vc["side_detector"]["distance"]),
-                      C.c_uint32(BatchedEngine.SIDE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim, 0)
+                      C.c_uint32(BatchedEngine.SIDE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim, h.obs_base)
         if h.n_ll:
             self.call("ref_line_detector", C.c_void_p(h.ll_beams.ctypes.data), h.n_ll, C.c_float(vc["lane_line_detector"]["distance"]),
                       C.c_uint32(BatchedEngine.LANE_LINE_MASK), C.c_void_p(self.state["obs"].ctypes.data), h.obs_dim,
-                      (h.n_side or 2) + 6)
+                      h.obs_base + (h.n_side or 2) + 6)
 
     def set_tracks(self, shape, dyn):
         """traffic_mode 'replay': frames [T, E*cap] of MdShape records and [T, E*cap, 2] (heading, speed)."""

@@ -274,3 +274,33 @@ def test_edge_configurations_parity(name, cfg_kw, steps):
     if name == "max_capacity":
         fl = eng.host.state["shape0"]["flags"].reshape(E, -1)
         assert ((fl & 0xF) == 1).sum(1).max() > 64, "the scene must actually use slots beyond the first 64-wide chunk"
+
+
+def test_random_agent_model_rollout_parity():
+    """random_agent_model with side + lane-line detectors and the others block: every optional obs section at once
+    (offsets: 2 size dims | side cloud | 5 + yaw | lane-line cloud | navi 10 | others 16 | lidar)."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    E = 32
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, random_agent_model=True, traffic_density=0.2, horizon=200,
+                           vehicle_config=dict(side_detector=dict(num_lasers=8, distance=50),
+                                               lane_line_detector=dict(num_lasers=4, distance=20),
+                                               lidar=dict(num_lasers=120, distance=50, num_others=4))))
+    eng = BatchedEngine(cfg)
+    assert eng.obs_dim == 2 + 8 + 6 + 4 + 10 + 16 + 120
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="agent model reset")
+    for t in range(220):
+        a = scripted_actions(E, 1, t, seed=31)
+        a[:, :, 0] *= 0.3
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 40 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="agent model step %d" % t)
+    st = eng.download_state()
+    assert_state_equal(st, orc.state, where="agent model final")
+    assert len(np.unique(st["obs"][:, 0])) >= 3           # several vehicle classes in the batch

@@ -359,3 +359,35 @@ def test_replay_traffic_mode_reproduces_a_recorded_episode():
         want = shape[t + 1].reshape(E, -1)
         for f in ("cx", "cy", "c", "s"):
             assert np.array_equal(got[f][:, 1:], want[f][:, 1:])
+
+
+def test_random_agent_model_obs_and_types():
+    """random_agent_model (manager/agent_manager.py:41, obs/state_obs.py:24-27,70-75): the agent's class is drawn
+    per scenario among s / m / l / xl / default and its length / 10, width / 2.5 lead the observation (21 + 240)."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.pg_space import VEHICLE_TYPES
+    E = 24
+    host = HostScene(make_config(dict(num_envs=E, num_scenarios=E, random_agent_model=True, traffic_density=0.0)))
+    assert host.obs_dim == 21 + 240 and host.md_config.random_agent_model == 1
+    types = [host.scenes[s].vehicle_cfgs[0]["type"] for s in host.seeds]
+    assert set(types) <= {"s", "m", "l", "xl", "default"} and len(set(types)) >= 3
+    o = ob.OracleWorld(host)
+    o.reset()
+    o.step(np.tile(np.array([0.0, 0.4], np.float32), (E, 1, 1)))
+    obs = o.obs
+    for e, t in enumerate(types):
+        assert obs[e, 0] == pytest.approx(VEHICLE_TYPES[t]["length"] / 10.0, abs=1e-6)
+        assert obs[e, 1] == pytest.approx(VEHICLE_TYPES[t]["width"] / 2.5, abs=1e-6)
+    plain = ob.OracleWorld(HostScene(make_config(dict(num_envs=E, num_scenarios=E, traffic_density=0.0))))
+    plain.reset()
+    plain.step(np.tile(np.array([0.0, 0.4], np.float32), (E, 1, 1)))
+    # same scenarios without the option: default car everywhere; where the random draw was "default" the rest of
+    # the observation agrees (the spawn-lane draw precedes the class draw; the vehicle's own seed is the engine's)
+    assert "default" in types
+    for e, t in enumerate(types):
+        if t == "default":
+            assert np.array_equal(obs[e, 2:], plain.obs[e, :])
+    with pytest.raises(NotImplementedError):
+        from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
+        BatchedMultiAgentRoundaboutEnv(dict(random_agent_model=True))
