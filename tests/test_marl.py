@@ -306,3 +306,32 @@ def test_bottleneck_rollout_parity_gpu():
             assert_state_equal(eng.download_state(), orc.state, where="bottleneck step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="bottleneck final")
     assert (orc.state["next_agent_id"] > A).all()
+
+
+@pytest.mark.gpu
+def test_marl_others_block_parity_gpu():
+    """Multi-agent env with the `num_others` observation block (each agent sees its nearest detected vehicles) and
+    detected sets: the MULTI kernel variant carries the tracking code too."""
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 4, 40
+    cfg = _marl_cfg(num_envs=E, num_scenarios=E, vehicle_config=dict(lidar=dict(num_lasers=72, distance=40, num_others=4)))
+    eng = BatchedEngine(cfg)
+    assert eng.obs_dim == 19 + 16 + 72
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="marl others reset")
+    rng = np.random.RandomState(12)
+    for t in range(120):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.6
+        a[..., 0] = rng.uniform(-0.2, 0.2, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 30 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="marl others step %d" % t)
+    st = eng.download_state()
+    assert_state_equal(st, orc.state, where="marl others final")
+    assert (st["detected"] != 0).any() and (st["obs"][:, 19:35] != 0).any()
