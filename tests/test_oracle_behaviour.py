@@ -391,3 +391,46 @@ def test_random_agent_model_obs_and_types():
     with pytest.raises(NotImplementedError):
         from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
         BatchedMultiAgentRoundaboutEnv(dict(random_agent_model=True))
+
+
+@pytest.mark.parametrize("steering", [-0.01, 0.01])
+@pytest.mark.parametrize("distance", [10, 50, 100])
+def test_out_of_road_coincides_with_side_detector(steering, distance):
+    """tests/test_functionality/test_out_of_road.py:7-39: drifting off a long straight road, the episode ends when
+    the side detector's nearest return is closer than the chassis diagonal (in units of the detector range)."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    cfg = make_config(dict(num_envs=1, num_scenarios=1, map="SSSSSSSSSSS", auto_reset=False,
+                           vehicle_config=dict(side_detector=dict(num_lasers=120, distance=distance))))
+    host = HostScene(cfg)
+    o = ob.OracleWorld(host)
+    o.reset()
+    sh = o.state["shape"][0]
+    tolerance = math.sqrt((2 * sh["hw"]) ** 2 + (2 * sh["hl"]) ** 2) / distance
+    act = np.array([[[steering, 1.0]]], np.float32)
+    for t in range(3000):
+        o.step(act)
+        fl = int(o.state["flags"][0])
+        if fl & (abi.FL_TERMINATED | abi.FL_TRUNCATED):
+            side = o.obs[0, :120]
+            assert side.min() < tolerance, (side.min(), tolerance)
+            assert fl & abi.FL_OUT_OF_ROAD
+            break
+    else:
+        raise AssertionError("the episode never ended")
+
+
+def test_sidewalk_and_line_contacts_with_hard_left():
+    """tests/test_functionality/test_collision.py:22-49: steering -0.5 at full throttle from the spawn point crosses a
+    broken line, a continuous white line and hits the sidewalk within 100 steps."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    host = HostScene(make_config(dict(num_envs=1, num_scenarios=1, traffic_density=0.0, auto_reset=False)))
+    o = ob.OracleWorld(host)
+    o.reset()
+    seen = 0
+    for t in range(100):
+        o.step(np.array([[[-0.5, 1.0]]], np.float32))
+        seen |= int(o.state["flags"][0])
+    assert seen & abi.FL_CRASH_SIDEWALK
+    assert seen & abi.FL_ON_BROKEN and seen & abi.FL_ON_WHITE_CONT
