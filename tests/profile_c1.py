@@ -2,10 +2,10 @@
 """BASELINE configs[0] (plumbing, no GPU): the shape of the reference's examples/profile_metadrive.py:9-43 on the
 CPU oracle -- ONE MetaDriveEnv, map 'S', traffic_density 0, lidar off (19-dim obs), action [0, 1], 10 000
 steps, reset on done -- reported as steps/s of one host thread.  The reference's README quotes "+1000 FPS"
-for its own engine (README.md:38; published, unverified here, different physics).  TEST INFRASTRUCTURE user:
+for its own engine (README.md:38; published, unverified here, different physics).  TEST INFRASTRUCTURE:
 this script drives the oracle, not the product path.
 
-Usage: python tools/profile_c1.py [-n 10000]
+Usage: python tests/profile_c1.py [-n 10000]
 """
 import argparse
 import os
@@ -16,7 +16,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # lives under tests/: only test infrastructure may drive the oracle
 
 
 def main():

@@ -304,3 +304,30 @@ def test_random_agent_model_rollout_parity():
     st = eng.download_state()
     assert_state_equal(st, orc.state, where="agent model final")
     assert len(np.unique(st["obs"][:, 0])) >= 3           # several vehicle classes in the batch
+
+
+@pytest.mark.parametrize("M", [4, 16, 64])
+def test_lidar_microbench_cases_bit_exact(M):
+    """The synthetic shape tables of tools/lidar_microbench.py (M boxes in a 100 m square around each ego, 240
+    beams): md_lidar on a bare MdShape table == ref_lidar, bit for bit."""
+    import ctypes as C
+    import os
+    import sys
+    import torch
+    from metadrive_ped_amd import _lib, abi
+    import oracle_binding as ob
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lidar_microbench as lm
+    E, B = 512, 240
+    shape, beams, cap = lm.make_case(E, M, B)
+    lib = _lib.load()
+    t_shape = torch.from_numpy(shape.view(np.uint8)).cuda()
+    t_beams = torch.from_numpy(beams).cuda()
+    out = torch.empty(E, B, device="cuda")
+    w, s, k = lm.structs(abi, E, cap, B, t_shape.data_ptr(), t_beams.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.md_lidar(C.byref(w), C.byref(s), C.byref(k), C.c_void_p(out.data_ptr()), B, 0, st), "md_lidar")
+    torch.cuda.synchronize()
+    ref = ob.lidar_raw(shape, beams, E, cap, B, 50.0)
+    assert np.array_equal(ref.view(np.uint32), out.cpu().numpy().view(np.uint32))
+    assert (ref < 1.0).mean() > 0.05
