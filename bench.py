@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--cap", type=int, default=0, help="mover slots per env (0 = smallest that fits)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-lane-follow", action="store_true", help="skip the scripted-driver operating point")
     p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl", "replay"],
                    help="metadrive = BASELINE configs[1] (the headline line); safe = configs[3] per-GPU shard (8192 "
                         "SafeMetaDriveEnv); marl = configs[2] (1024 x 40-agent roundabout, 240 beams)")
@@ -247,6 +248,38 @@ def main():
     lidar["fp32_peak_tflops"] = FP32_PEAK_TFLOPS
     lidar["fp32_frac"] = round(lidar["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
 
+    # ---- second operating point (N=1, single-agent workloads): a scripted lane-following driver instead of random
+    #      actions.  Episodes last several hundred steps, more traffic blocks get triggered (about twice the driving
+    #      vehicles per env), so the step is heavier: reported next to `value`, never instead of it. ----
+    lane_follow = None
+    if rank == 0 and world == 1 and A == 1 and args.workload in ("metadrive", "safe") and not args.no_lane_follow:
+        o_hd, o_v, o_lat = eng.host.obs_base + (eng.host.n_side or 2), eng.host.obs_base + (eng.host.n_side or 2) + 1, \
+            eng.host.obs_base + (eng.host.n_side or 2) + 6
+        act_buf = torch.zeros(E, 1, 2, device=dev)
+
+        def drive():
+            ob_ = eng.obs[:, 0, :]
+            act_buf[:, 0, 0] = (4.0 * (ob_[:, o_hd] - 0.5) + 2.0 * (ob_[:, o_lat] - 0.5)).clamp_(-1.0, 1.0)
+            act_buf[:, 0, 1] = (ob_[:, o_v] < 0.35).to(torch.float32) * 0.5
+            eng.step(act_buf)
+
+        eng.reset()
+        for i in range(300):            # let the batch reach its steady mix of episode phases
+            drive()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_lf = 200
+        for i in range(n_lf):
+            drive()
+        torch.cuda.synchronize()
+        dt_lf = time.perf_counter() - t0
+        f_lf = eng.shape_f.view(torch.int32)[..., 6]
+        drv = (((f_lf & 0x10) != 0) & ((f_lf & 0x40) == 0) & ((f_lf & 0xF) == 1) & ((f_lf & 0x80) == 0)).sum().item() / E
+        lane_follow = dict(value=round(n_lf * E / dt_lf, 1), unit="agent-steps/s", ms_per_step=round(dt_lf / n_lf * 1e3, 4),
+                           driving_vehicles_per_env=round(drv, 2),
+                           policy="steer = clip(4 (heading_diff - .5) + 2 (lateral - .5)), throttle .5 below 28 km/h; "
+                                  "computed from the observation with four torch element-wise ops per step (included)")
+
     # ---- optional gather (N>1): obs + reward + flags to every rank over RCCL ----
     with_gather = None
     if world > 1:
@@ -316,7 +349,7 @@ def main():
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=label,
                         envs_per_gpu=E, active_agent_fraction=round(active_frac, 3), agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
-            roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, with_gather=with_gather,
+            roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, lane_follow_policy=lane_follow, with_gather=with_gather,
             host_build_s=round(build_s, 1))
         print(json.dumps(line))
     if world > 1:
