@@ -369,6 +369,13 @@ __device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdCon
     const int n = slot;
     const MdShape me = s.shape[n];
     if (!md_drives(me.flags)) return;
+    if (!(me.flags & MD_F_AGENT)) {  // traffic: nothing reads its crash / line flags (see the oracle's contacts_mover)
+        if (lane_id == 0) {
+            if (cfl_out) cfl_out[n] = 0u;
+            else s.flags[n] &= MD_FL_ON_LANE;
+        }
+        return;
+    }
     uint32_t fl = 0;
     for (int j0 = 0; j0 < c.cap; j0 += 64) {
         const int j = j0 + lane_id;
@@ -1097,10 +1104,16 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             if (j0 == 0) drv_lo = mk;
             else drv_hi = mk;
         }
+        // contacts only for agents (traffic's crash flags are never read): their slots are the first A
+        const int A_ = c.agents_per_env;
+        const unsigned long long a_lo = A_ >= 64 ? ~0ull : ((1ull << A_) - 1ull);
+        const unsigned long long a_hi = A_ <= 64 ? 0ull : (A_ >= 128 ? ~0ull : ((1ull << (A_ - 64)) - 1ull));
+        const unsigned long long adrv_lo = drv_lo & a_lo, adrv_hi = drv_hi & a_hi;
         const int nd = __popcll(drv_lo) + __popcll(drv_hi);
-        for (int item = wave; item < 2 * nd; item += kWaves) {
-            int k = item < nd ? item : item - nd;  // k-th driving slot
-            unsigned long long lo = drv_lo, hi = drv_hi;
+        const int na = __popcll(adrv_lo) + __popcll(adrv_hi);
+        for (int item = wave; item < nd + na; item += kWaves) {
+            int k = item < nd ? item : item - nd;  // k-th driving slot / k-th driving agent
+            unsigned long long lo = item < nd ? drv_lo : adrv_lo, hi = item < nd ? drv_hi : adrv_hi;
             int slot = -1;
             while (k >= 0) {
                 if (lo) {
@@ -1130,7 +1143,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MD_STAMP_AT(6);
     if (PH & PH_TRAFFIC) {
         for (int j = tid; j < cap; j += kBlock) {
-            if (kFused && md_drives(s.shape[j].flags)) s.flags[j] = l_onlane[j] | l_cfl[j];
+            if (kFused && md_drives(s.shape[j].flags))  // traffic slots carry no contact flags (l_cfl is written for agents only)
+                s.flags[j] = l_onlane[j] | ((s.shape[j].flags & MD_F_AGENT) ? l_cfl[j] : 0u);
             const int f = s.shape[j].flags;
             if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) {
                 s.shape[j].flags = f & ~MD_F_ALIVE;

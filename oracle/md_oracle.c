@@ -206,6 +206,12 @@ static void contacts_mover(const MdWorld* w, const MdState* s, const MdConfig* c
     int n = base + slot;
     const MdShape* me = &s->shape[n];
     if (!drives(me->flags)) return;
+    if (!(me->flags & MD_F_AGENT)) {
+        /* traffic: BaseVehicle._state_check runs for every vehicle in the reference, but nothing ever reads a
+         * traffic vehicle's crash / line flags (IDM, rewards, infos and removal only use on_lane): not computed */
+        s->flags[n] &= MD_FL_ON_LANE;
+        return;
+    }
     uint32_t keep = s->flags[n] & (MD_FL_ON_LANE);
     uint32_t fl = 0;
     for (int j = 0; j < c->cap; ++j) {

@@ -38,12 +38,23 @@ def main():
     acts[..., 1] = acts[..., 1].abs() * 0.9 + 0.1
     acts[..., 0] *= 0.25
     acts = acts.cuda()
-    for i in range(80):
-        eng.step(acts[i % 16])
+    lane_follow = os.environ.get("POLICY", "random") == "lane"   # scripted driver: longer episodes, more traffic awake
+
+    def next_action(i):
+        if not lane_follow:
+            return acts[i % 16]
+        ob_ = eng.obs[:, 0, :]
+        a = torch.zeros(E, 1, 2, device="cuda")
+        a[:, 0, 0] = (4.0 * (ob_[:, 2] - 0.5) + 2.0 * (ob_[:, 8] - 0.5)).clamp_(-1.0, 1.0)
+        a[:, 0, 1] = (ob_[:, 3] < 0.35).to(torch.float32) * 0.5
+        return a
+
+    for i in range(400 if lane_follow else 80):
+        eng.step(next_action(i))
     buf = torch.zeros(E * 32, dtype=torch.int64, device="cuda")
     eng.lib.md_debug_set_stamp_buffer.argtypes = [C.c_void_p]
     assert eng.lib.md_debug_set_stamp_buffer(buf.data_ptr()) == 0
-    eng.step(acts[0])
+    eng.step(next_action(0))
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().reshape(E, 32)
     st = raw[:, :12].astype(np.int64)
