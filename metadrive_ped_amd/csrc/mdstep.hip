@@ -646,7 +646,9 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const Md
 __device__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
                                     int just_reset, int lane_id, float* wave_scratch /* LDS, MD_OBS_TASKS*5 floats */) {
     MdObsCtx k;
+    MD_FINE_STAMP(a == 0 && lane_id == 0, 8);
     md_observe_ctx(lanes, roads, &s, a, &k);
+    MD_FINE_STAMP(a == 0 && lane_id == 0, 9);
     if (lane_id < MD_OBS_TASKS) {
         float mine[5];
         md_observe_task(lane_id, &k, &s, &c, a, mine);
@@ -656,8 +658,10 @@ __device__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    MD_FINE_STAMP(a == 0 && lane_id == 0, 10);
     if (lane_id == 0) md_observe_combine(&k, &s, &c, a, just_reset, (const float (*)[5])wave_scratch);
     __builtin_amdgcn_wave_barrier();
+    MD_FINE_STAMP(a == 0 && lane_id == 0, 11);
 }
 
 // Up to FOUR agents per wave: 16-lane group g serves agent a_base + g (tasks on its lanes 0..8, combine on its

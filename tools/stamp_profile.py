@@ -77,6 +77,11 @@ def main():
     if len(li):
         print("idm(first traffic slot) fine over %d envs: plan %.0f | scan %.0f | decide %.0f (p50 cycles)" % (
             len(li), np.median(li[:, 5] - li[:, 4]), np.median(li[:, 6] - li[:, 5]), np.median(li[:, 7] - li[:, 6])))
+    ok = (fine[:, 8] > 0) & (fine[:, 11] > fine[:, 8])
+    lo = fine[ok]
+    if len(lo):
+        print("observe(agent) fine: context %.0f | nine tasks %.0f | combine + stores %.0f (p50 cycles)" % (
+            np.median(lo[:, 9] - lo[:, 8]), np.median(lo[:, 10] - lo[:, 9]), np.median(lo[:, 11] - lo[:, 10])))
     flags = eng.shape_f.view(torch.int32)[..., 6]
     drv = (((flags & 0x10) != 0) & ((flags & 0x40) == 0) & ((flags & 0xF) == 1)).sum(dim=1).cpu().numpy()
     print("driving vehicles/env: mean %.2f max %d" % (drv.mean(), drv.max()))
