@@ -11,8 +11,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/trace.log 2>&1
-timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-lane-follow > $OUT/trace.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-lane-follow > $OUT/pmc_fetch.log 2>&1
+timeout -k 10 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-lane-follow > $OUT/pmc_write.log 2>&1
 python tools/summarize_profile.py $OUT $OUT/pmc_traffic.json > $OUT/summary.txt
 cat $OUT/summary.txt
