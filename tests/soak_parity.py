@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Long parity soak (not collected by pytest: run by hand on the GPU box): thousands of steps of HIP against the
+oracle on a few hundred envs per configuration, comparing every state array at the end of each 250-step chunk.
+Usage: python tests/soak_parity.py [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    E = 256
+    configs = dict(
+        default=dict(),
+        hybrid=dict(traffic_mode="hybrid", traffic_density=0.2),
+        respawn=dict(traffic_mode="respawn", traffic_density=0.15),
+        safe=dict(accident_prob=0.8, traffic_density=0.05, crash_vehicle_done=False, crash_object_done=False),
+        dense5=dict(map=5, traffic_density=0.3),
+    )
+    for name, extra in configs.items():
+        cfg = make_config(dict(dict(num_envs=E, num_scenarios=E, horizon=1000), **extra))
+        eng = BatchedEngine(cfg)
+        orc = ob.OracleWorld(eng.host)
+        eng.reset()
+        orc.reset()
+        rng = np.random.RandomState(7)
+        t0 = time.time()
+        for t in range(steps):
+            # a mix of random and lane-keeping actions so that both short and long episodes occur
+            obs = orc.obs
+            steer = np.clip(4.0 * (obs[:, 2] - 0.5) + 2.0 * (obs[:, 8] - 0.5), -1, 1)
+            rnd = rng.uniform(-1, 1, (E, 2)).astype(np.float32)
+            use_rnd = (np.arange(E) % 3 == 0)
+            a = np.stack([np.where(use_rnd, rnd[:, 0] * 0.3, steer), np.where(use_rnd, np.abs(rnd[:, 1]), (obs[:, 3] < 0.35) * 0.5)], 1)
+            a = a.astype(np.float32)[:, None, :]
+            eng.step(torch.from_numpy(a).to(eng.device))
+            orc.step(a, threads=8)
+            if (t + 1) % 250 == 0:
+                assert_state_equal(eng.download_state(), orc.state, where="%s step %d" % (name, t + 1))
+        fl = orc.state["shape"]["flags"].reshape(E, -1)
+        drv = (((fl & 0x10) != 0) & ((fl & 0x40) == 0) & ((fl & 0xF) == 1) & ((fl & 0x80) == 0)).sum(1).mean()
+        print("%-8s %d steps x %d envs bit-exact (%.0f s, %.1f driving vehicles per env at the end)" % (name, steps, E, time.time() - t0, drv), flush=True)
+
+
+def main_marl():
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,
+                                                 BatchedMultiAgentRoundaboutEnv)
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    E = 48
+    for cls in (BatchedMultiAgentRoundaboutEnv, BatchedMultiAgentIntersectionEnv, BatchedMultiAgentBottleneckEnv):
+        cfg = cls(dict(num_envs=E, num_scenarios=E)).config
+        eng = BatchedEngine(cfg)
+        A = eng.A
+        orc = ob.OracleWorld(eng.host)
+        eng.reset()
+        orc.reset()
+        rng = np.random.RandomState(3)
+        t0 = time.time()
+        o_hd = (eng.host.n_side or 2)
+        for t in range(steps):
+            obs = orc.obs.reshape(E, A, -1)
+            steer = np.clip(4.0 * (obs[..., o_hd] - 0.5) + 2.0 * (obs[..., o_hd + 6] - 0.5), -1, 1)
+            rnd = rng.uniform(-1, 1, (E, A, 2)).astype(np.float32)
+            use_rnd = (np.arange(A)[None, :] % 4 == 0)
+            a = np.stack([np.where(use_rnd, rnd[..., 0] * 0.3, steer), np.where(use_rnd, np.abs(rnd[..., 1]), (obs[..., o_hd + 1] < 0.3) * 0.5)], -1)
+            a = a.astype(np.float32)
+            eng.step(torch.from_numpy(a).to(eng.device))
+            orc.step(a, threads=8)
+            if (t + 1) % 250 == 0:
+                assert_state_equal(eng.download_state(), orc.state, where="%s step %d" % (cls.__name__, t + 1))
+        print("%-36s %d steps x %d envs x %d agents bit-exact (%.0f s, %d agents created per env)" %
+              (cls.__name__, steps, E, A, time.time() - t0, int(orc.state["next_agent_id"].mean())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
+    main_marl()
