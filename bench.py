@@ -63,6 +63,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL, host tensors
+    # for the two collectives): exercises rank / seed / barrier / reduction / printing logic, measures nothing.
+    rehearse = os.environ.get("MD_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     import torch
     import torch.distributed as dist
     from metadrive_ped_amd.config import make_config
@@ -128,7 +133,10 @@ def main():
         eng.set_tracks(tracks)
     build_s = time.time() - t0
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = eng.device
     A, cap, B = eng.A, eng.cap, eng.n_beams
 
@@ -161,7 +169,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    el = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -290,11 +298,16 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             eng.step(actions[i % n_act])
-            dist.all_gather_into_tensor(obs_g, eng.obs.reshape(-1))
-            dist.all_gather_into_tensor(rew_g, eng.reward.reshape(-1))
+            if rehearse:   # gloo: host copies stand in for the RCCL gather
+                o_cpu, r_cpu = eng.obs.reshape(-1).cpu(), eng.reward.reshape(-1).cpu()
+                dist.all_gather([torch.empty_like(o_cpu) for _ in range(world)], o_cpu)
+                dist.all_gather([torch.empty_like(r_cpu) for _ in range(world)], r_cpu)
+            else:
+                dist.all_gather_into_tensor(obs_g, eng.obs.reshape(-1))
+                dist.all_gather_into_tensor(rew_g, eng.reward.reshape(-1))
         torch.cuda.synchronize()
         barrier()
-        eg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        eg = torch.tensor([time.perf_counter() - t0], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(eg, op=dist.ReduceOp.MAX)
         with_gather = dict(value=round(total_agent_steps / float(eg.item()), 1), unit="agent-steps/s",
                            collective="all_gather_into_tensor(obs,reward)")
