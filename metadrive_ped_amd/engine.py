@@ -43,6 +43,20 @@ def _build_marl(cfg, scene_cfg, uniq):
     return mt, scenes, spawn_tables(mt, SPAWN_ROADS[kind], mc["lane_num"], fixed)
 
 
+def _build_one_marl_pg(job):
+    """MultiAgentMetaDrive on procedurally generated maps (envs/marl_envs/multi_agent_metadrive.py:12-61): one PG map per
+    scenario seed like the single-agent env, agents spawn on the first block's exit road, destination = the far end."""
+    from metadrive_ped_amd.mapgen.tables import spawn_tables
+    from metadrive_ped_amd.marl import PG_SPAWN_ROADS, RoundaboutScene
+    s, mc, dist, scene_cfg = job
+    pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+               generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
+    mt = MapTables(pg)
+    mt.respawn = spawn_tables(mt, PG_SPAWN_ROADS, mc["lane_num"], fixed_destination=True)   # stacked per map by WorldTables
+    sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
+    return mt, RoundaboutScene(s, mt, sc_cfg, PG_SPAWN_ROADS, True)
+
+
 def _build_one(job):
     """One scenario seed -> (MapTables, EnvScene).  Module-level so that a fork pool can run it."""
     s, mc, dist, scene_cfg = job
@@ -104,10 +118,16 @@ class HostScene:
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
-        if cfg["is_multi_agent"]:
-            if not cfg["mover_capacity"]:
-                scene_cfg["cap"] = cap = A
-                self.cap = cap
+        shared_map = cfg["is_multi_agent"] and cfg["marl_map"] != "pg"
+        build_fn = _build_one
+        if cfg["is_multi_agent"] and not cfg["mover_capacity"]:
+            scene_cfg["cap"] = cap = A
+            self.cap = cap
+            jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
+        if cfg["is_multi_agent"] and not shared_map:
+            build_fn = _build_one_marl_pg
+            self.spawn = dict(n_dest=1)          # per-map spawn tables travel with the map tables
+        if shared_map:
             mt, marl_scenes, self.spawn = _build_marl(cfg, scene_cfg, uniq)
             built = [(mt, marl_scenes[s]) for s in uniq]
         elif len(jobs) >= 64 and workers > 1:
@@ -118,14 +138,14 @@ class HostScene:
             # handler rides along into the forked workers and a SIGTERM there can hang the whole run
             pool = mp.get_context("fork").Pool(workers)
             try:
-                built = pool.map(_build_one, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
+                built = pool.map(build_fn, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
             finally:
                 pool.close()
                 pool.join()
         else:
-            built = [_build_one(j) for j in jobs]
+            built = [build_fn(j) for j in jobs]
         for s, (mt, sc) in zip(uniq, built):
-            if cfg["is_multi_agent"]:
+            if shared_map:
                 map_of_seed[s] = 0
                 if not tables:
                     tables.append(mt)
@@ -143,7 +163,7 @@ class HostScene:
         self.scenes = scenes
         env_map = [map_of_seed[s] for s in seeds]
         self.world = WorldTables(tables, env_map, beam_table(self.n_beams))
-        if self.spawn is not None:
+        if self.spawn is not None and shared_map:
             a = self.world.arrays
             a["spawn_off"] = np.asarray([0, len(self.spawn["spawn_lane"])], np.int32)
             for k in ("spawn_place", "spawn_lane", "spawn_route", "spawn_route_meta"):

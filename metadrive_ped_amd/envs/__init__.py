@@ -1,3 +1,3 @@
 from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv, BatchedSafeMetaDriveEnv  # noqa: F401
 from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,  # noqa: F401
-                                             BatchedMultiAgentRoundaboutEnv)
+                                             BatchedMultiAgentMetaDrive, BatchedMultiAgentRoundaboutEnv)

@@ -165,3 +165,20 @@ class BatchedMultiAgentBottleneckEnv(BatchedMultiAgentRoundaboutEnv):
         import copy
         merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
         super().__init__(merged)
+
+
+class BatchedMultiAgentMetaDrive(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentMetaDrive itself (envs/marl_envs/multi_agent_metadrive.py:12-128): 15 agents on an ordinary procedurally
+    generated map (one per scenario seed, 3 blocks, 3 lanes), all spawning on the first block's exit road (5 slots x 3
+    lanes) and driving to the far end of the map."""
+    MAP_DEFAULTS = dict(marl_map="pg", num_agents=15, map=3, map_config=dict(exit_length=50, lane_num=3))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)

@@ -27,6 +27,8 @@ INTERSECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("1X0_0_", "1X0_1_"), nega
                             negate_road("1X2_0_", "1X2_1_")]
 # MABottleneckConfig.spawn_roads (envs/marl_envs/marl_bottleneck.py:11)
 BOTTLENECK_SPAWN_ROADS = [(">>", ">>>"), negate_road("2Y0_0_", "2Y0_1_")]
+# MultiAgentMetaDrive on PG maps: MULTI_AGENT_METADRIVE_DEFAULT_CONFIG.spawn_roads (multi_agent_metadrive.py:27)
+PG_SPAWN_ROADS = [(">>", ">>>")]
 SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS)
 # roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
 # bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)

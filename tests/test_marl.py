@@ -335,3 +335,67 @@ def test_marl_others_block_parity_gpu():
     st = eng.download_state()
     assert_state_equal(st, orc.state, where="marl others final")
     assert (st["detected"] != 0).any() and (st["obs"][:, 19:35] != 0).any()
+
+
+# ---- MultiAgentMetaDrive on procedurally generated maps (envs/marl_envs/multi_agent_metadrive.py) ----------------
+def _pg_marl_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentMetaDrive
+    base = dict(num_envs=4, num_scenarios=4)
+    base.update(kw)
+    return BatchedMultiAgentMetaDrive(base).config
+
+
+def test_pg_multi_agent_env_on_oracle():
+    """15 agents on the first block's exit road of a different PG map per scenario (max_capacity = 5 slots x 3 lanes:
+    spawn_manager.py:107-121), respawn places = the first slot of each lane, destination = the far end of the map."""
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 4, 15
+    host = HostScene(_pg_marl_cfg(num_envs=E, num_scenarios=E))
+    assert host.cap == A and host.world.n_maps == E
+    assert list(np.diff(host.world.arrays["spawn_off"])) == [3] * E
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert (_counts(o.state, E)[0] == A).all()
+    sh = o.state["shape"].reshape(E, -1)
+    for e in range(E):
+        for i in range(A):
+            for j in range(i + 1, A):
+                assert not ob.load().ref_obb_obb(sh[e, i:i + 1].ctypes.data, sh[e, j:j + 1].ctypes.data)
+    # every agent's route ends on the last road of ITS map
+    nav = o.state["nav"].reshape(E, -1)
+    assert (nav["route_len"] >= 3).all()
+    for t in range(300):
+        obs = o.obs.reshape(E, A, -1)
+        steer = np.clip(4 * (obs[..., 2] - 0.5) + 2 * (obs[..., 8] - 0.5), -1, 1)
+        a = np.stack([steer, (obs[..., 3] < 0.3) * 0.5], -1).astype(np.float32)
+        a[:, ::4, 0] = 0.3                      # every fourth agent wanders off the road
+        o.step(a)
+        act, dy = _counts(o.state, E)
+        assert ((act + dy) <= A).all()
+    assert (o.state["next_agent_id"] >= A).all() and (o.state["next_agent_id"] > A).any()
+    with pytest.raises(ValueError):
+        HostScene(_pg_marl_cfg(num_agents=16))        # more agents than spawn slots
+
+
+@pytest.mark.gpu
+def test_pg_multi_agent_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 12, 15
+    eng = BatchedEngine(_pg_marl_cfg(num_envs=E, num_scenarios=E))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="pg marl reset")
+    for t in range(400):
+        obs = orc.obs.reshape(E, A, -1)
+        steer = np.clip(4 * (obs[..., 2] - 0.5) + 2 * (obs[..., 8] - 0.5), -1, 1)
+        a = np.stack([steer, (obs[..., 3] < 0.3) * 0.5], -1).astype(np.float32)
+        a[:, ::4, 0] = 0.3                      # every fourth agent wanders off: crashes, dying bodies, respawns
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 40 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="pg marl step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="pg marl final")
+    assert (orc.state["next_agent_id"] > A).any()
