@@ -136,7 +136,9 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     float x = sh->cx, y = sh->cy, psi = d->heading, v = d->speed;
     MdBicycle bike;
     md_bicycle_prepare(steer, thr, &s->param[n], &bike);
-    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, thr, &bike, &s->param[n], c->dt);
+    float cp, sp;
+    md_sincos(psi + bike.beta, &sp, &cp);
+    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, &cp, &sp, thr, &bike, &s->param[n], c->dt);
     sh->cx = x;
     sh->cy = y;
     d->heading = psi;

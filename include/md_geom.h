@@ -288,8 +288,13 @@ MD_HD void md_bicycle_prepare(float steer, float throttle, const MdParam* P, MdB
     b->sb_over_lr = sb / P->lr;
 }
 
-MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float throttle, const MdBicycle* b,
-                              const MdParam* P, float dt) {
+/* (cp, sp) = cos / sin of the direction of travel psi + beta, carried from sub-step to sub-step: the heading turns
+ * by d = vm sin(beta)/lr dt (at most ~0.16 rad) per sub-step, and the pair is ROTATED by d with the series
+ * sin d = d (1 - d^2/6 + d^4/120), cos d = 1 - d^2/2 + d^4/24 - d^6/720 (truncation below 1e-9) instead of being
+ * re-evaluated with the full sincos: one sincos per step instead of five.  psi itself accumulates exactly as
+ * before, and the pose's own (cos psi, sin psi) is taken from it once at the end of the step. */
+MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float* cp_io, float* sp_io, float throttle,
+                              const MdBicycle* b, const MdParam* P, float dt) {
     float vv = *v;
     float speed_kmh = md_fabs(vv) * 3.6f;
     float acc = 0.0f, dec = 0.0f;
@@ -308,12 +313,17 @@ MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float th
         vnew = vnew + dv;
         if (vnew > 0.0f) vnew = 0.0f;
     }
-    float sp, cp;
-    md_sincos(*psi + b->beta, &sp, &cp);
+    float sp = *sp_io, cp = *cp_io;
     float vm = 0.5f * (vv + vnew);
     *x = *x + vm * cp * dt;
     *y = *y + vm * sp * dt;
-    *psi = md_wrap_to_pi(*psi + vm * b->sb_over_lr * dt);
+    float d = vm * b->sb_over_lr * dt;
+    *psi = md_wrap_to_pi(*psi + d);
+    float d2 = d * d;
+    float sd = d * (1.0f - d2 * (0.16666667f - d2 * 0.0083333333f));
+    float cd = 1.0f - d2 * (0.5f - d2 * (0.041666667f - d2 * 0.0013888889f));
+    *cp_io = cp * cd - sp * sd;
+    *sp_io = sp * cd + cp * sd;
     *v = vnew;
 }
 

@@ -485,7 +485,9 @@ EXPORT int ref_obb_quad(const MdShape* a, const float* q) { return md_obb_quad(a
 EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, float dt, int n) {
     MdBicycle b;
     md_bicycle_prepare(steer, thr, P, &b);
-    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], thr, &b, P, dt);
+    float cp, sp;
+    md_sincos(st4[2] + b.beta, &sp, &cp);
+    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], &cp, &sp, thr, &b, P, dt);
 }
 EXPORT void ref_probe_math(int op, const float* a, const float* b, float* out, int n) {
     for (int i = 0; i < n; ++i) out[i] = md_probe_eval(op, a[i], b[i]);
