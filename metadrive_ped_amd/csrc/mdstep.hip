@@ -87,7 +87,7 @@ __device__ __forceinline__ int wave_min_i(int v, bool valid, int none) {
 // Lidar for one (agent, sector) work item, executed by one wave.
 // ------------------------------------------------------------------------------------------------
 // det: LDS words [2] of agent a's detected set (nullptr = not tracked)
-__device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int a, int sec, int lane,
+__device__ __forceinline__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c, int a, int sec, int lane,
                            float* __restrict__ out_row, unsigned long long* det) {
     const MdShape me = s.shape[a];  // wave-uniform (s is the env-local, LDS-staged view)
     const int beam = sec * 64 + lane;
@@ -181,7 +181,7 @@ __device__ void lidar_item(const MdWorld& w, const MdState& s, const MdConfig& c
 }
 
 // (Keeping the sectors off the wave that runs the agent's observe chain was tried: 154 vs 145 us, worse.)
-__device__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
+__device__ __forceinline__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
                             float* out, int out_stride, int out_offset, unsigned long long* l_det) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
     const int nsec = (c.n_beams + 63) >> 6;
@@ -230,7 +230,7 @@ __device__ __forceinline__ int grid_clampi(int v, int lo, int hi) { return v < l
 // ------------------------------------------------------------------------------------------------
 // onlane_out: nullptr = write the ON_LANE bit into s.flags[n] (stand-alone phase); otherwise store the bare
 // decision there and leave s.flags alone (fused step: contacts run concurrently and own the other bits).
-__device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
+__device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
                                  int n, int lane_id, uint32_t* onlane_out = nullptr) {
     // n = slot inside the env-local view; lanes / roads = this env's map tables (LDS copies)
     const MdShape sh = s.shape[n];
@@ -361,9 +361,138 @@ __device__ void localize_vehicle(const MdWorld& w, const MdLane* lanes, const Md
 }
 
 // ------------------------------------------------------------------------------------------------
+// Localisation of TWO vehicles by one wave (lanes 0-31: slot_a, lanes 32-63: slot_b; -1 = half idle): the form the
+// fused step uses when more vehicles drive than the workgroup has waves.  Same arithmetic, same candidate order and
+// tie-breaks as localize_vehicle; the per-vehicle data are per-lane values here (uniform within a half), cross-lane
+// reads go through __shfl, votes through the matching half of a 64-bit ballot.  Results go to onlane_out.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
+                              int slot_a, int slot_b, int lane_id, uint32_t* onlane_out) {
+    const int h = lane_id >> 5, hl = lane_id & 31, hbase = h << 5;
+    const int n = h ? slot_b : slot_a;
+    const bool act = n >= 0;  // (slots handed in always drive)
+    const int nn = act ? n : 0;
+    struct { float cx, cy, c, s; } sh;   // only what the search needs, per lane
+    sh.cx = s.shape[nn].cx;
+    sh.cy = s.shape[nn].cy;
+    sh.c = s.shape[nn].c;
+    sh.s = s.shape[nn].s;
+    struct { int lane, ck0, ck1, route_len; } nav;
+    nav.lane = s.nav[nn].lane;
+    nav.ck0 = s.nav[nn].ck0;
+    nav.ck1 = s.nav[nn].ck1;
+    nav.route_len = s.nav[nn].route_len;
+    const int m = w.env_map[e];
+    const int32_t* rroads = s.route_roads + (size_t)nn * MD_ROUTE_LEN;
+    const int32_t* rnodes = s.route_nodes + (size_t)nn * MD_ROUTE_LEN;
+    const int cur_road = rroads[nav.ck0];
+    const bool has_next = nav.ck1 != nav.ck0;
+    const int next_road = has_next ? rroads[nav.ck1] : -1;
+    const MdGrid g = w.grid[m];
+    const int gx = (int)md_floor((sh.cx - g.x0) * g.inv_cell);
+    const int gy = (int)md_floor((sh.cy - g.y0) * g.inv_cell);
+    int it0 = 0, it1 = 0;
+    if (act && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny) {
+        const int cell = g.cell_base + gy * g.nx + gx;
+        it0 = w.cell_start[cell];
+        it1 = w.cell_start[cell + 1];
+    }
+    int on_lane = 0;
+    int best_any = -1, best_cur = -1, best_next = -1;
+    float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
+    const auto half_of = [&](unsigned long long b) { return (unsigned)(h ? (b >> 32) : (b & 0xFFFFFFFFull)); };
+    for (int itb = it0; __ballot(itb < it1) != 0ull; itb += 32) {
+        const int it = itb + hl;
+        int l = -1;
+        bool pass = false;
+        if (it < it1) {
+            l = w.cell_items[it];
+            if (l >= 0) {
+                const MdLane* L = &lanes[l];
+                pass = !(sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1);
+            }
+        }
+        unsigned mask = half_of(__ballot(pass));
+        unsigned inside = 0u;  // bit k: candidate held by lane k of MY half contains the point
+        while (__ballot(mask != 0u) != 0ull) {
+            const bool mine = mask != 0u;
+            const int k = mine ? (__ffs((int)mask) - 1) : 0;
+            if (mine) mask &= mask - 1;
+            const int lk = __shfl(l, hbase + k, 64);
+            bool outside = false;
+            int hn = 0;
+            if (mine) {
+                const MdLane* L = &lanes[lk];
+                hn = L->hull_n;
+                const float* xy = md_lane_hull(L, w.hull_xy);
+                for (int i = hl; i < hn; i += 32) {
+                    const int j = (i + 1 == hn) ? 0 : i + 1;
+                    const float ex = xy[2 * j] - xy[2 * i], ey = xy[2 * j + 1] - xy[2 * i + 1];
+                    const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
+                    if (cr < 0.0f) outside = true;
+                }
+            }
+            const unsigned out_h = half_of(__ballot(outside));
+            if (mine && out_h == 0u && hn >= 3) inside |= 1u << k;
+        }
+        if (inside != 0u) on_lane = 1;
+        float my_dist = 3.0e38f;
+        int my_road = -1;
+        if ((inside >> hl) & 1u) {
+            const MdLane* L = &lanes[l];
+            float ls, llat;
+            md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
+            const float lh = md_lane_heading_at(L, ls);
+            float hs_, hc_;
+            md_sincos(lh, &hs_, &hc_);
+            const float cosangle = hc_ * sh.c + hs_ * sh.s;
+            if (cosangle > 0.0f) {
+                my_dist = md_lane_distance(L, ls, llat);
+                my_road = L->road;
+            }
+        }
+        while (__ballot(inside != 0u) != 0ull) {
+            const bool mine = inside != 0u;
+            const int k = mine ? (__ffs((int)inside) - 1) : 0;
+            if (mine) inside &= inside - 1;
+            const float dist = __shfl(my_dist, hbase + k, 64);
+            const int road = __shfl(my_road, hbase + k, 64);
+            const int lk = __shfl(l, hbase + k, 64);
+            if (!mine || road < 0) continue;
+            if (dist < d_any) { d_any = dist; best_any = lk; }
+            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
+            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
+        }
+    }
+    if (hl != 0 || !act) return;  // lane 0 of each half commits its vehicle
+    int lane = -1;
+    if (best_cur >= 0) lane = best_cur;
+    else if (!has_next) lane = best_any;
+    else if (best_next >= 0) lane = best_next;
+    else lane = best_any;
+    onlane_out[n] = on_lane ? MD_FL_ON_LANE : 0u;
+    if (lane < 0) lane = nav.lane;
+    s.nav[n].lane = lane;
+    if (lane < 0) return;
+    if (nav.ck0 == nav.ck1) return;
+    float ls, llat;
+    md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    if (!(ls < 5.0f)) return;
+    const int start_node = roads[lanes[lane].road].start_node;
+    const int kk = nav.route_len;
+    int idx = -1;
+    for (int j = nav.ck1; j < kk - 1; ++j) {
+        if (rnodes[j] == start_node) { idx = j; break; }
+    }
+    if (idx < 0) return;
+    s.nav[n].ck0 = idx;
+    s.nav[n].ck1 = (idx + 1 == kk - 1) ? idx : idx + 1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Contacts, one wave per vehicle.
 // ------------------------------------------------------------------------------------------------
-__device__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id,
+__device__ __forceinline__ void contacts_vehicle(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int lane_id,
                                  uint32_t* cfl_out = nullptr) {
     const int base = 0;  // env-local view
     const int n = slot;
@@ -468,7 +597,7 @@ __device__ __forceinline__ void wave_argmin(float& key, int& slot) {
 }
 
 // wave_list: >= 24 ints of LDS private to this wave (the compacted candidate list)
-__device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
+__device__ __forceinline__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
                                  const MdConfig& c, int m, int slot, int lane_id, int* wave_list) {
     constexpr float kInf = 3.0e38f;
     MdIdmPlan plan;
@@ -643,7 +772,7 @@ __device__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const Md
 // (md_observe_task) run on lanes 0..8 at once, lane 0 gathers them with v_readlane and combines.
 // ------------------------------------------------------------------------------------------------
 // One agent per wave (`a` wave-uniform: its context lives in scalar registers) -- the single-agent envs' form.
-__device__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
+__device__ __forceinline__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a,
                                     int just_reset, int lane_id, float* wave_scratch /* LDS, MD_OBS_TASKS*5 floats */) {
     MdObsCtx k;
     MD_FINE_STAMP(a == 0 && lane_id == 0, 8);
@@ -669,7 +798,7 @@ __device__ void observe_agent_wave1(const MdLane* lanes, const MdRoad* roads, co
 constexpr int kObsGroups = 4;
 constexpr int kObsScratch = kObsGroups * 48;  // floats of LDS per wave: MD_OBS_TASKS * 5 (= 45) per group, padded
 
-__device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a_base,
+__device__ __forceinline__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, const MdState& s, const MdConfig& c, int a_base,
                                    int just_reset, int lane_id, float* wave_scratch /* LDS, kObsScratch floats */) {
     const int g = lane_id >> 4, sub = lane_id & 15;
     const int a = a_base + g;
@@ -695,7 +824,7 @@ __device__ void observe_agent_wave(const MdLane* lanes, const MdRoad* roads, con
 // ------------------------------------------------------------------------------------------------
 // Traffic trigger (wave 0) -- PGTrafficManager.before_step, manager/traffic_manager.py:80-88
 // ------------------------------------------------------------------------------------------------
-__device__ void trigger_env(const MdLane* lanes, const MdState& s, const MdConfig& c, int lane_id) {
+__device__ __forceinline__ void trigger_env(const MdLane* lanes, const MdState& s, const MdConfig& c, int lane_id) {
     const int base = 0;  // env-local view
     int my_min = 0x7fffffff;
     for (int j = lane_id; j < c.cap; j += 64) {
@@ -738,7 +867,7 @@ __device__ void trigger_env(const MdLane* lanes, const MdState& s, const MdConfi
 // after a respawn; that second scan can never find a place (every safe place of the first scan is marked used,
 // the unsafe ones are still occupied), so one scan is exact.  scratch: >= 4 ints of LDS.
 // ------------------------------------------------------------------------------------------------
-__device__ void lifecycle_block(const MdWorld& w, const MdState& s, const MdConfig& c, int m, int tid, int nthreads,
+__device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState& s, const MdConfig& c, int m, int tid, int nthreads,
                                 int* scratch) {
     const int A = c.agents_per_env;
     int* cnt_active = scratch;      // agents that keep driving
@@ -1115,22 +1244,37 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         const unsigned long long adrv_lo = drv_lo & a_lo, adrv_hi = drv_hi & a_hi;
         const int nd = __popcll(drv_lo) + __popcll(drv_hi);
         const int na = __popcll(adrv_lo) + __popcll(adrv_hi);
-        for (int item = wave; item < nd + na; item += kWaves) {
-            int k = item < nd ? item : item - nd;  // k-th driving slot / k-th driving agent
-            unsigned long long lo = item < nd ? drv_lo : adrv_lo, hi = item < nd ? drv_hi : adrv_hi;
+        const auto kth = [](unsigned long long lo, unsigned long long hi, int k) {  // k-th set bit of (hi:lo), -1 if none
             int slot = -1;
             while (k >= 0) {
                 if (lo) {
                     slot = __ffsll((long long)lo) - 1;
                     lo &= lo - 1;
-                } else {
+                } else if (hi) {
                     slot = 64 + __ffsll((long long)hi) - 1;
                     hi &= hi - 1;
+                } else {
+                    return -1;
                 }
                 --k;
             }
-            if (item < nd) localize_vehicle(w, lanes, roads, s, e, slot, lane, l_onlane);
-            else contacts_vehicle(w, s, c, e, slot, lane, l_cfl);
+            return slot;
+        };
+        if (nd + na <= kWaves) {
+            // everything fits one round: one wave per job, the vehicle's data in scalar registers
+            for (int item = wave; item < nd + na; item += kWaves) {
+                if (item < nd) localize_vehicle(w, lanes, roads, s, e, kth(drv_lo, drv_hi, item), lane, l_onlane);
+                else contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item - nd), lane, l_cfl);
+            }
+        } else {
+            // many vehicles awake: two localisations per wave (32 lanes each), halving the rounds
+            const int npair = (nd + 1) >> 1;
+            for (int item = wave; item < npair + na; item += kWaves) {
+                if (item < npair)
+                    localize_pair(w, lanes, roads, s, e, kth(drv_lo, drv_hi, 2 * item), kth(drv_lo, drv_hi, 2 * item + 1), lane, l_onlane);
+                else
+                    contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item - npair), lane, l_cfl);
+            }
         }
         __syncthreads();
     } else {
