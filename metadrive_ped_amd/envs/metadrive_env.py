@@ -137,6 +137,12 @@ class BatchedMetaDriveEnv:
     def stop_recording(self):
         return self.engine.stop_recording()
 
+    def export_scenarios(self, tracks, envs=None):
+        """BaseEnv.export_scenarios (envs/base_env.py:775-836) for a recorded batch: one scenario description (the
+        reference's unified dict format, see scenario_export.py) per env of `envs` from stop_recording()'s tracks."""
+        from metadrive_ped_amd.scenario_export import tracks_to_scenarios
+        return tracks_to_scenarios(tracks, self.engine.host, envs)
+
     def load_tracks(self, tracks):
         """For an env built with traffic_mode='replay': the traffic follows `tracks` (from stop_recording() of an env
         with the same scenarios) instead of reacting; call before reset()."""

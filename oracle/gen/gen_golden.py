@@ -610,7 +610,47 @@ def _pg_maps_cases(fname, specs):
     dump(fname, dict(cases=cases))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3)
+def scenario_export_case():
+    """The recorded episode both the generator and tests/test_scenario_export.py export (oracle-driven, CPU only)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import oracle_binding as ob
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.scenario_export import tracks_to_scenarios
+    E, T = 3, 80
+    host = HostScene(make_config(dict(num_envs=E, num_scenarios=E, start_seed=20, traffic_density=0.2, accident_prob=1.0,
+                                      traffic_mode="respawn", horizon=1000, auto_reset=False)))
+    o = ob.OracleWorld(host)
+    o.reset()
+    acts = [np.tile(np.array([0.03 * math.sin(0.07 * t), 0.6], np.float32), (E, 1, 1)) for t in range(T)]
+    return tracks_to_scenarios(ob.record_episode(o, acts), host)
+
+
+def section_scenario_export():
+    """Episodes exported by metadrive_ped_amd.scenario_export, judged by the REFERENCE's own
+    ScenarioDescription.sanity_check(valid_check=True) and summarised by its update_summaries
+    (scenario/scenario_description.py:199-257, :417-437).  The fixture holds the reference's summaries of our export."""
+    from metadrive.scenario.scenario_description import ScenarioDescription as SD
+    out = []
+    for sc in scenario_export_case():
+        sc["metadata"].pop("object_summary")
+        sc["metadata"].pop("number_summary")
+        SD.sanity_check(sc, check_self_type=True, valid_check=True)
+        sd = SD(sc)
+        SD.update_summaries(sd)
+        ns = dict(sd["metadata"]["number_summary"])
+        ns.pop("map_height_diff")          # -inf for a flat map without road-line features; not JSON
+        for k in ("object_types", "num_traffic_light_types"):
+            ns[k] = sorted(ns[k])
+        ns["num_moving_objects_each_type"] = dict(ns["num_moving_objects_each_type"])
+        out.append(dict(id=sc["id"], length=sc["length"], sdc_moving_dist=float(SD.sdc_moving_dist(sd)),
+                        object_summary=sd["metadata"]["object_summary"], number_summary=ns))
+    dump("scenario_export.json", dict(accepted_by_reference_sanity_check=True, scenarios=out))
+
+
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
+                       scenario_export=section_scenario_export)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -148,6 +148,21 @@ class OracleWorld:
         return self.state["obs"]
 
 
+def record_episode(o, actions):
+    """Drive OracleWorld `o` (already reset) through `actions` and return the frames in BatchedEngine.stop_recording's
+    layout: frame 0 = the reset state, frame k = the state after step k."""
+    T, n = len(actions), o.host.E * o.host.cap
+    shape = np.zeros((T + 1, n), dtype=abi.SHAPE_DT)
+    dyn = np.zeros((T + 1, n, 2), np.float32)
+    for k in range(T + 1):
+        if k:
+            o.step(actions[k - 1])
+        shape[k] = o.state["shape"]
+        dyn[k, :, 0] = o.state["dyn"]["heading"]
+        dyn[k, :, 1] = o.state["dyn"]["speed"]
+    return dict(shape=shape, dyn=dyn, seeds=list(o.host.seeds), cap=o.host.cap)
+
+
 def lidar_raw(shape, beam_cs, E, cap, n_beams, lidar_range):
     """ref_lidar on a bare shape table (one agent per env in slot 0): the lidar micro-bench's checker."""
     lib = load()

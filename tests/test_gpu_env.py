@@ -135,6 +135,7 @@ def test_record_then_replay_traffic():
     from helpers import assert_state_equal
     from metadrive_ped_amd.envs import BatchedMetaDriveEnv
     import oracle_binding as ob
+    from metadrive_ped_amd.scenario_export import tracks_to_scenarios
     E, T = 16, 150
     base = dict(num_envs=E, num_scenarios=E, traffic_density=0.25, horizon=1000, auto_reset=False)
     acts = [torch.from_numpy(scripted_actions(E, 1, t, seed=17)[:, 0] * np.array([0.1, 1.0], np.float32)).cuda() for t in range(T)]
@@ -147,6 +148,16 @@ def test_record_then_replay_traffic():
         obs_rec.append(o.cpu().numpy().copy())
     tracks = rec.stop_recording()
     assert tracks["shape"].shape[0] == T + 1
+    # export_scenarios of the device recording == the export of the same rollout recorded from the oracle
+    o_rec = ob.OracleWorld(rec.engine.host, rec.engine.host.clone_state())
+    o_rec.reset()
+    sc_gpu = rec.export_scenarios(tracks, envs=[0, E - 1])
+    sc_cpu = tracks_to_scenarios(ob.record_episode(o_rec, [a.cpu().numpy()[:, None, :] for a in acts]), rec.engine.host, [0, E - 1])
+    for a, b in zip(sc_gpu, sc_cpu):
+        assert a["id"] == b["id"] and set(a["tracks"]) == set(b["tracks"])
+        for oid in a["tracks"]:
+            for k, v in a["tracks"][oid]["state"].items():
+                assert v.tobytes() == b["tracks"][oid]["state"][k].tobytes(), (oid, k)
     rp = BatchedMetaDriveEnv(dict(base, traffic_mode="replay"))
     rp.load_tracks(tracks)
     rp.reset()
