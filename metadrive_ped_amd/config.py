@@ -92,6 +92,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     out_of_road_done=True,
     force_seed_spawn_manager=False,
     spawn_roads=None,
+    # VaryingDynamicsEnv (envs/varying_dynamics_env.py:14-25): None = off, else {parameter: (min, max) | None}
+    random_dynamics=None,
 )
 
 # batched-engine keys (no counterpart in the reference: it steps one world per process)
@@ -154,6 +156,12 @@ def make_config(user=None):
     if cfg["is_multi_agent"] and cfg["random_agent_model"]:
         raise NotImplementedError("random_agent_model in a multi-agent env is not built (a respawn would have to draw a "
                                   "new vehicle class on the device)")
+    if cfg["is_multi_agent"] and cfg["random_dynamics"]:
+        raise NotImplementedError("random_dynamics: 'Only supporting single-agent now!' (varying_dynamics_env.py:46)")
+    if cfg["random_dynamics"]:
+        unknown = set(cfg["random_dynamics"]) - {"max_engine_force", "max_brake_force", "wheel_friction", "max_steering", "mass"}
+        if unknown:
+            raise KeyError("random_dynamics: unknown parameter(s) {}".format(sorted(unknown)))
     if cfg["is_multi_agent"] and abs(cfg["accident_prob"]) >= 1e-2:
         raise NotImplementedError("accident scenes in a multi-agent env are not built")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:

@@ -1014,7 +1014,7 @@ constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot
 // 123 us against 133 us at the compiler's own choice (6 waves) and 131 us at 8 (64 VGPRs, more spills) --
 // the step is latency-bound, so resident workgroups per CU count.  Other instantiations keep the default.
 template <int PH, bool RESPAWN, bool MULTI>
-constexpr int env_waves_per_eu() { return (PH == PH_ALL && !RESPAWN && !MULTI && MD_ENV_BLOCK == 256) ? 7 : 0; }
+constexpr int env_waves_per_eu() { return (PH == PH_ALL && !RESPAWN && !MULTI && MD_ENV_BLOCK >= 128) ? 7 : 0; }
 
 template <int PH, bool STAGE_MAP, bool RESPAWN = false, bool MULTI = false>
 __global__ __launch_bounds__(MD_ENV_BLOCK)

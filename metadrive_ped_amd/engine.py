@@ -114,7 +114,8 @@ class HostScene:
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
-                         random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"])
+                         random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
+                         random_dynamics=cfg["random_dynamics"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)

@@ -222,3 +222,37 @@ class BatchedSafeMetaDriveEnv(BatchedMetaDriveEnv):
         merged = dict(self.SAFE_DEFAULTS)
         merged.update(config or {})
         super().__init__(merged)
+
+
+class BatchedVaryingDynamicsEnv(BatchedMetaDriveEnv):
+    """VaryingDynamicsEnv (metadrive/envs/varying_dynamics_env.py:14-60): the agent's engine force, brake force,
+    wheel friction, maximum steering angle and mass are drawn per scenario seed from config["random_dynamics"]
+    ({parameter: (min, max) | None}); like there, the same scenario seed always gives the same dynamics, so use
+    num_scenarios > 1 for a spread.  `dynamics_parameters()` is the batch form of agent.get_dynamics_parameters()."""
+    VARYING_DEFAULTS = dict(
+        vehicle_config=dict(vehicle_model="varying_dynamics"),
+        random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600), wheel_friction=(0.1, 2.5),
+                             max_steering=(10, 80), mass=(300, 3000)))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(copy.deepcopy(cls.VARYING_DEFAULTS))
+
+    def __init__(self, config=None):
+        import copy
+        merged = copy.deepcopy(self.VARYING_DEFAULTS)
+        for k, v in (config or {}).items():
+            if k == "vehicle_config":
+                merged["vehicle_config"].update(v)
+            else:
+                merged[k] = v
+        super().__init__(merged)
+
+    def dynamics_parameters(self):
+        """-> list (one dict per env) of the agent's max_engine_force / max_brake_force / wheel_friction / max_steering
+        / mass, as sampled for its scenario."""
+        self.lazy_init()
+        keys = ("max_engine_force", "max_brake_force", "wheel_friction", "max_steering", "mass")
+        h = self.engine.host
+        return [{k: h.scenes[s].vehicle_cfgs[0][k] for k in keys if k in h.scenes[s].vehicle_cfgs[0]} for s in h.seeds]

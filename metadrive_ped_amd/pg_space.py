@@ -115,6 +115,9 @@ class VehicleParameterSpace:
 VEHICLE_TYPES = {
     "default": dict(length=4.515, width=1.852, height=1.19, mass=1100, lf=1.05234, lr=1.4166,
                     space=VehicleParameterSpace.DEFAULT_VEHICLE),
+    # VaryingDynamicsVehicle (vehicle_type.py:168-187): the default vehicle whose dynamics come from its config
+    "varying_dynamics": dict(length=4.515, width=1.852, height=1.19, mass=1100, lf=1.05234, lr=1.4166,
+                             space=VehicleParameterSpace.DEFAULT_VEHICLE),
     "static_default": dict(length=4.515, width=1.852, height=1.19, mass=1100, lf=1.05234, lr=1.4166,
                            space=VehicleParameterSpace.STATIC_DEFAULT_VEHICLE),
     "xl": dict(length=5.74, width=2.3, height=2.8, mass=1600, lf=1.726, lr=1.075, space=VehicleParameterSpace.XL_VEHICLE),

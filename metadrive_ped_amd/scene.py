@@ -36,16 +36,24 @@ TRAFFIC_TYPE_KEYS = ["s", "m", "l", "xl", "default"]  # vehicle_type.py:269-275 
 TRAFFIC_TYPE_P = [0.2, 0.3, 0.3, 0.2, 0.0]            # traffic_manager.py:298-301
 
 
-def vehicle_param_record(vtype, vehicle_seed, substep_dt):
-    """MdParam + (length, width) of a vehicle of class `vtype` seeded with `vehicle_seed`."""
+def vehicle_param_record(vtype, vehicle_seed, substep_dt, overrides=None):
+    """MdParam + (length, width) of a vehicle of class `vtype` seeded with `vehicle_seed`.  `overrides` are the
+    agent-config values laid over the sampled parameters (BaseVehicle.__init__: sample_parameters through
+    BaseObject.__init__, then update_config(vehicle_config), base_vehicle.py:136-138): max_engine_force,
+    max_brake_force, wheel_friction, max_steering, mass of the varying-dynamics vehicle (vehicle_type.py:168-187)."""
     spec = VEHICLE_TYPES[vtype]
     rng = get_np_random(vehicle_seed)
     cfg = sample_parameters(rng, spec["space"])
+    mass = spec["mass"]
+    if overrides:
+        cfg.update({k: v for k, v in overrides.items() if k != "mass"})
+        mass = overrides.get("mass", mass)
+        cfg["mass"] = mass
     rec = np.zeros((), dtype=abi.PARAM_DT)
     rec["max_steer"] = math.radians(cfg["max_steering"])
-    rec["accel_gain"] = 4.0 * cfg["max_engine_force"] / spec["mass"]
-    rec["brake_gain"] = 4.0 * cfg["max_brake_force"] / (spec["mass"] * substep_dt)
-    rec["roll_decel"] = 4.0 * 2.0 / (spec["mass"] * substep_dt)
+    rec["accel_gain"] = 4.0 * cfg["max_engine_force"] / mass
+    rec["brake_gain"] = 4.0 * cfg["max_brake_force"] / (mass * substep_dt)
+    rec["roll_decel"] = 4.0 * 2.0 / (mass * substep_dt)
     rec["max_speed_kmh"] = cfg["max_speed_km_h"]
     rec["lf"], rec["lr"] = spec["lf"], spec["lr"]
     rec["fric_decel"] = cfg["wheel_friction"] * GRAVITY
@@ -93,6 +101,17 @@ class EnvScene:
 
         # ---- agents (single agent: slot 0) ----
         assert A == 1, "multi-agent scenes are built by the MARL scene builder"
+        # VaryingDynamicsAgentManager.reset (envs/varying_dynamics_env.py:29-49): one uniform draw per randomised
+        # parameter, in the config's key order, from the agent manager's stream BEFORE the agents are created
+        dynamics = None
+        if cfg.get("random_dynamics"):
+            dynamics = {}
+            for name, rng_ in cfg["random_dynamics"].items():
+                if rng_ is None:
+                    continue
+                if not isinstance(rng_, (tuple, list)) or len(rng_) != 2 or rng_[1] < rng_[0]:
+                    raise ValueError("Unknown parameter range: {}".format(rng_))
+                dynamics[name] = rng_[0] if rng_[1] == rng_[0] else float(agent_mgr.np_random.uniform(rng_[0], rng_[1]))
         lane_num = pg_map.lane_num
         if cfg["random_spawn_lane_index"]:
             spawn_idx = int(agent_mgr.np_random.randint(lane_num))
@@ -107,7 +126,7 @@ class EnvScene:
         vehicle_seed = engine.generate_seed()
         agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
         self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
-                            cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT)
+                            cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics)
 
         # ---- traffic (trigger mode) ----
         density = cfg["traffic_density"]
@@ -290,11 +309,11 @@ class EnvScene:
         self.dyn[slot]["heading"] = heading
         return slot
 
-    def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags):
+    def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags, overrides=None):
         t = self.tables
         pg_map = t.pg_map
         lane = pg_map.net.lanes(lane_index[0], lane_index[1])[lane_index[2]]
-        prm, length, width, cfg = vehicle_param_record(vtype, vehicle_seed, dt)
+        prm, length, width, cfg = vehicle_param_record(vtype, vehicle_seed, dt, overrides)
         self.vehicle_cfgs[slot] = dict(type=vtype, seed=vehicle_seed, **cfg)
         pos = lane.position(longitude, lateral)
         heading = lane.heading_theta_at(longitude)

@@ -32,6 +32,20 @@ def test_env_api_contract(cs_dist):
     obs2, _ = env.reset(seed=5)                          # re-base scenarios: maps regenerate
     assert env.current_seeds[0] == 5
     env.close()
+    # old gym API (envs/gym_wrapper.py of the reference): 4-tuple step, reset -> obs, attributes pass through
+    from metadrive_ped_amd.envs.gym_wrapper import createGymWrapper
+    from metadrive_ped_amd.envs import BatchedVaryingDynamicsEnv
+    genv = createGymWrapper(BatchedVaryingDynamicsEnv)(dict(num_envs=E, num_scenarios=E, block_dist_config=cs_dist, horizon=30))
+    o = genv.reset()
+    assert tuple(o.shape) == (E, 259) and genv.num_envs == E and genv.observation_space.shape == (259, )
+    assert len(genv.dynamics_parameters()) == E and len({d["mass"] for d in genv.dynamics_parameters()}) == E
+    done_seen = False
+    for t in range(35):
+        out = genv.step(torch.from_numpy(scripted_actions(E, 1, t)[:, 0]).cuda())
+        assert len(out) == 4 and out[2].dtype == torch.bool
+        done_seen |= bool(out[2].any())
+    assert done_seen                                    # horizon 30: done = terminated | truncated shows up
+    genv.close()
 
 
 def test_full_size_properties(cs_dist):

@@ -1,4 +1,5 @@
 """Host-side logic: config contract, spaces, scene construction, static grid."""
+import math
 import numpy as np
 import pytest
 
@@ -184,3 +185,49 @@ def test_random_lane_width_num_and_inverse_traffic():
 
     assert oncoming_on_simple_blocks(inv) > 0 and oncoming_on_simple_blocks(plain) == 0
     assert sum(inv.scenes[s].n_traffic for s in inv.seeds) > sum(plain.scenes[s].n_traffic for s in plain.seeds)
+
+
+def test_varying_dynamics_env_draws_and_behaviour():
+    """VaryingDynamicsEnv (envs/varying_dynamics_env.py:14-60): per scenario seed the agent manager's stream gives
+    one uniform per randomised parameter in config order BEFORE the agents are created; the vehicle then takes
+    them over its sampled parameters.  Same seed -> same dynamics; a stronger engine accelerates harder (oracle)."""
+    import oracle_binding as ob
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedVaryingDynamicsEnv
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.rng import get_np_random
+    cfg = BatchedVaryingDynamicsEnv.default_config()
+    assert cfg["vehicle_config"]["vehicle_model"] == "varying_dynamics"
+    ranges = cfg["random_dynamics"]
+    assert list(ranges) == ["max_engine_force", "max_brake_force", "wheel_friction", "max_steering", "mass"]
+    E = 8
+    cfg.update(num_envs=E, num_scenarios=E, start_seed=40, traffic_density=0.0, map="SS")
+    cfg["random_dynamics"]["wheel_friction"] = None          # not randomised: keeps the class value, draws nothing
+    cfg["random_dynamics"]["max_steering"] = (35, 35)        # degenerate range: the value, no draw
+    h = HostScene(cfg)
+    for e, s in enumerate(h.seeds):
+        rng = get_np_random(s)
+        want = {k: float(rng.uniform(*ranges[k])) for k in ("max_engine_force", "max_brake_force", "mass")}
+        got = h.scenes[s].vehicle_cfgs[0]
+        for k, v in want.items():
+            assert got[k] == v and ranges[k][0] <= v <= ranges[k][1]
+        assert got["max_steering"] == 35 and abs(got["wheel_friction"] - 0.9) < 1e-6
+        p = h.state["param0"][e * h.cap] if "param0" in h.state else h.scenes[s].param[0]
+        assert abs(float(p["accel_gain"]) - 4.0 * want["max_engine_force"] / want["mass"]) < 1e-4 * float(p["accel_gain"])
+        assert abs(float(p["max_steer"]) - math.radians(35)) < 1e-6
+    h2 = HostScene(cfg)
+    assert all(h2.scenes[s].vehicle_cfgs[0] == h.scenes[s].vehicle_cfgs[0] for s in h.seeds)
+    # full throttle for 2 s: speed ordering follows accel_gain (below the speed limit)
+    o = ob.OracleWorld(h)
+    o.reset()
+    for _ in range(20):
+        o.step(np.tile(np.array([0.0, 1.0], np.float32), (E, 1, 1)))
+    speed = o.state["dyn"]["speed"].reshape(E, -1)[:, 0]
+    gain = np.array([float(h.scenes[s].param[0]["accel_gain"]) for s in h.seeds])
+    slow = speed < 20.0
+    assert slow.sum() >= 3 and (np.argsort(speed[slow]) == np.argsort(gain[slow])).all()
+    with pytest.raises(KeyError):
+        HostScene(make_config(dict(random_dynamics=dict(wheel_radius=(1, 2)))))
+    with pytest.raises(NotImplementedError):
+        from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+        BatchedMultiAgentRoundaboutEnv(dict(random_dynamics=dict(mass=(300, 3000))))
