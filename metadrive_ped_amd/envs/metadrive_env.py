@@ -85,10 +85,11 @@ class BatchedMetaDriveEnv:
         self.episode_rewards = None
 
     # -- lifecycle ----------------------------------------------------------------------------
-    def lazy_init(self):
+    def lazy_init(self, host=None):
+        """`host`: a HostScene already built from this env's config (e.g. before the GPU was touched)."""
         if self.engine is None:
             from metadrive_ped_amd.engine import BatchedEngine
-            self.engine = BatchedEngine(self.config)
+            self.engine = BatchedEngine(self.config, host=host)
 
     def reset(self, seed=None):
         """seed: None keeps the scenario assignment; an int re-bases it (env e gets scenario

@@ -187,3 +187,33 @@ def test_record_then_replay_traffic():
     assert_state_equal(rp.engine.download_state(), orc.state, where="replay final")
     with pytest.raises(ValueError):
         BatchedMetaDriveEnv(dict(base)).load_tracks(tracks)
+
+
+def test_double_buffered_sub_batches_equal_the_whole_batch():
+    """envs/pipeline.py: S sub-batches stepped on S HIP streams give, env for env, the observations / rewards / flags
+    of the whole batch stepped in one launch (same scenarios, same actions), bit for bit."""
+    import torch
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    from metadrive_ped_amd.envs.pipeline import SubBatchedEnvs
+    E, S, T = 48, 3, 120
+    user = dict(num_envs=E, num_scenarios=E, traffic_density=0.2, horizon=80, mover_capacity=48)
+    whole = BatchedMetaDriveEnv(dict(user))
+    sub = SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=S)
+    sub.build_host()
+    o_w, _ = whole.reset()
+    o_s = [o for o, _ in sub.reset()]
+    sub.synchronize()
+    assert torch.equal(torch.cat(o_s), o_w)
+    n = E // S
+    for t in range(T):
+        a = torch.from_numpy(scripted_actions(E, 1, t, seed=5)[:, 0]).cuda()
+        torch.cuda.synchronize()                      # `a` was made on the default stream
+        ow, rw, tw, cw, _ = whole.step(a)
+        res = sub.step([a[k * n:(k + 1) * n] for k in range(S)])
+        sub.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat([r[0] for r in res]), ow), "obs differ at step %d" % t
+        assert torch.equal(torch.cat([r[1] for r in res]), rw) and torch.equal(torch.cat([r[2] for r in res]), tw)
+        assert torch.equal(torch.cat([r[3] for r in res]), cw)
+    sub.close()
+    whole.close()

@@ -231,3 +231,25 @@ def test_varying_dynamics_env_draws_and_behaviour():
     with pytest.raises(NotImplementedError):
         from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
         BatchedMultiAgentRoundaboutEnv(dict(random_dynamics=dict(mass=(300, 3000))))
+
+
+def test_sub_batches_hold_the_same_environments_as_the_whole_batch():
+    """envs/pipeline.py: sub-batch k of S is the env range [k E/S, (k+1) E/S) of the whole batch -- same seeds, same
+    maps, same reset snapshot -- so double-buffered stepping changes the schedule, not the results."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    from metadrive_ped_amd.envs.pipeline import SubBatchedEnvs
+    E, S = 12, 3
+    user = dict(num_envs=E, num_scenarios=E, start_seed=7, env_seed_offset=24, traffic_density=0.2, mover_capacity=48)
+    whole = HostScene(make_config(user))
+    sub = SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=S)
+    hosts = sub.build_host()
+    assert [h.E for h in hosts] == [E // S] * S
+    assert sum((h.seeds for h in hosts), []) == whole.seeds
+    n = E // S * whole.cap
+    for k, h in enumerate(hosts):
+        for name in ("shape0", "dyn0", "nav0", "pid0", "param"):
+            assert h.state[name].tobytes() == whole.state[name][k * n:(k + 1) * n].tobytes(), name
+    with pytest.raises(ValueError):
+        SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=5)
