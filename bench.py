@@ -117,13 +117,17 @@ def main():
     # double-buffered leg: the same environments as S sub-batches (envs/pipeline.py); their scenes too are generated
     # before the GPU is touched
     sub = None
-    if world == 1 and args.sub_batches > 1 and args.workload in ("metadrive", "safe") and E % args.sub_batches == 0:
+    if world == 1 and args.sub_batches > 1 and args.workload in ("metadrive", "safe", "marl") and E % args.sub_batches == 0:
         from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
         from metadrive_ped_amd.envs.pipeline import SubBatchedEnvs
-        user = dict(common, map=3, horizon=1000, mover_capacity=host.cap)
-        user.update(dict(traffic_density=0.1) if args.workload == "metadrive" else BatchedSafeMetaDriveEnv.SAFE_DEFAULTS)
-        user.update(num_scenarios=common["num_scenarios"])
-        sub = SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=args.sub_batches)
+        if args.workload == "marl":
+            sub = SubBatchedEnvs(BatchedMultiAgentRoundaboutEnv,
+                                 dict(common, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50))), sub_batches=args.sub_batches)
+        else:
+            user = dict(common, map=3, horizon=1000, mover_capacity=host.cap)
+            user.update(dict(traffic_density=0.1) if args.workload == "metadrive" else BatchedSafeMetaDriveEnv.SAFE_DEFAULTS)
+            user.update(num_scenarios=common["num_scenarios"])
+            sub = SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=args.sub_batches)
         sub.build_host()
     torch.cuda.set_device(local_rank)
     tracks = None
@@ -324,7 +328,9 @@ def main():
         run_sub(args.steps, args.warmup)
         torch.cuda.synchronize()
         dt_db = time.perf_counter() - t0
-        double_buffered = dict(value=round(args.steps * E * A / dt_db, 1), unit="agent-steps/s", sub_batches=S,
+        sf_db = torch.cat([e_.engine.shape_f.view(torch.int32)[:, :A, 6] for e_ in sub.envs])
+        act_db = float((((sf_db & 0x10) != 0) & ((sf_db & 0x80) == 0)).float().mean().item()) if A > 1 else 1.0
+        double_buffered = dict(value=round(args.steps * E * A * act_db / dt_db, 1), unit="agent-steps/s", sub_batches=S,
                                envs_per_sub_batch=E // S, ms_per_step=round(dt_db / args.steps * 1e3, 4),
                                note="same %d envs, same actions; one step = one md_step launch per sub-batch, each on "
                                     "its own HIP stream; no cross-stream wait inside the timed region" % E)

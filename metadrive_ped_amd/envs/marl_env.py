@@ -69,11 +69,15 @@ class BatchedMultiAgentRoundaboutEnv:
                 self.engine.host = None
                 self.engine.cfg = self.config
                 self.engine.build()
-        if self.engine is None:
-            from metadrive_ped_amd.engine import BatchedEngine
-            self.engine = BatchedEngine(self.config)
+        self.lazy_init()
         self.engine.reset()
         return self.engine.obs, self._info()
+
+    def lazy_init(self, host=None):
+        """`host`: a HostScene already built from this env's config (e.g. before the GPU was touched)."""
+        if self.engine is None:
+            from metadrive_ped_amd.engine import BatchedEngine
+            self.engine = BatchedEngine(self.config, host=host)
 
     def step(self, actions):
         if self.engine is None:
