@@ -10,8 +10,11 @@ from collections import OrderedDict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = ["stage-in", "trigger", "idm", "integrate", "localize", "contacts", "traffic", "observe", "lidar",
-          "barrier", "write-back"]
+# stamps 2 and 5 exist only in the kernel variants that run the IDM before the integration / localisation apart from
+# the contacts (multi-agent order); where a stamp was not written the phase before it gets the whole interval
+PHASES = ["stage-in", "trigger (idm-first variants)", "idm before integrate", "integrate", "localize (own stage)",
+          "locate: localize + contacts", "traffic + next trigger", "observe || idm for the next step", "lidar",
+          "wait for the idm waves", "write-back"]
 
 
 def main():
@@ -58,6 +61,8 @@ def main():
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().reshape(E, 32)
     st = raw[:, :12].astype(np.int64)
+    for i in range(10, 0, -1):                      # a stamp that was not written takes the next one's value
+        st[:, i] = np.where(st[:, i] == 0, st[:, i + 1], st[:, i])
     fine = raw[:, 16:].astype(np.int64)
     d = np.diff(st, axis=1)
     tot = st[:, 11] - st[:, 0]
@@ -65,7 +70,7 @@ def main():
     print("kernel span (first start -> last end): %.0f cycles" % (st[:, 11].max() - st[:, 0].min()))
     for i, name in enumerate(PHASES):
         x = d[:, i]
-        print("%-11s mean %8.0f  p50 %8.0f  p99 %8.0f  max %8.0f   share %5.1f%%" %
+        print("%-34s mean %8.0f  p50 %8.0f  p99 %8.0f  max %8.0f   share %5.1f%%" %
               (name, x.mean(), np.median(x), np.percentile(x, 99), x.max(), 100.0 * x.sum() / tot.sum()))
     ok = (fine[:, 0] > 0) & (fine[:, 3] > 0)
     lf = fine[ok]
