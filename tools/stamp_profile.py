@@ -11,7 +11,7 @@ from collections import OrderedDict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # stamps 2 and 5 exist only in the kernel variants that run the IDM before the integration / localisation apart from
-# the contacts (multi-agent order); where a stamp was not written the phase before it gets the whole interval
+# the contacts (multi-agent order); where a stamp was not written its phase reads 0 and the next one gets the interval
 PHASES = ["stage-in", "trigger (idm-first variants)", "idm before integrate", "integrate", "localize (own stage)",
           "locate: localize + contacts", "traffic + next trigger", "observe || idm for the next step", "lidar",
           "wait for the idm waves", "write-back"]
@@ -61,8 +61,8 @@ def main():
     torch.cuda.synchronize()
     raw = buf.cpu().numpy().reshape(E, 32)
     st = raw[:, :12].astype(np.int64)
-    for i in range(10, 0, -1):                      # a stamp that was not written takes the next one's value
-        st[:, i] = np.where(st[:, i] == 0, st[:, i + 1], st[:, i])
+    for i in range(1, 11):                          # a stamp that was not written takes the one before it
+        st[:, i] = np.where(st[:, i] == 0, st[:, i - 1], st[:, i])
     fine = raw[:, 16:].astype(np.int64)
     d = np.diff(st, axis=1)
     tot = st[:, 11] - st[:, 0]
