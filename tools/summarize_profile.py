@@ -60,6 +60,21 @@ def main():
             traffic["env_kernel<%s>" % m.group(1)] = int((2 * f + w) * 1024)
         print("%-60s FETCH_SIZE %10.1f KiB (corrected %10.1f KiB)  WRITE_SIZE %10.1f KiB  => %.2f MB/launch" %
               (k[:60], f, 2 * f, w, (2 * f + w) * 1024 / 1e6))
+    insts = {c: pmc_avg(d, "pmc_insts", c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_WAVES")}
+    stats = {r["Name"]: float(r["AverageNs"]) for r in kernel_stats(d)}
+    if insts["SQ_INSTS_VALU"]:
+        print("== instruction mix per dispatch (wave-instructions; VALU issue = 4 cycles per wave64 instruction on one of the")
+        print("   1024 SIMDs, shader clock taken as 2.4 GHz)")
+        for k in sorted(insts["SQ_INSTS_VALU"]):
+            if "env_kernel" not in k:
+                continue
+            v = {c: insts[c].get(k, 0.0) for c in insts}
+            line = "%-60s waves %7.0f  VALU %10.0f (%5.0f/wave)  SALU %10.0f  LDS %9.0f  SMEM %9.0f" % (
+                k[:60], v["SQ_WAVES"], v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU"] / max(v["SQ_WAVES"], 1), v["SQ_INSTS_SALU"],
+                v["SQ_INSTS_LDS"], v["SQ_INSTS_SMEM"])
+            if k in stats:
+                line += "  VALU issue %.0f %% of the %.1f us" % (100.0 * v["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e3 / (stats[k] / 1e3) , stats[k] / 1e3)
+            print(line)
     if len(sys.argv) > 2:
         # machine-readable copy for bench.py's roofline.traffic (bytes per launch, corrected as above)
         with open(sys.argv[2], "w") as fh:
