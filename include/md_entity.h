@@ -81,6 +81,16 @@ MD_HD int md_drives(int flags) {
     return md_present(flags) && md_kind_of(flags) == MD_KIND_VEHICLE && !(flags & (MD_F_STATIC | MD_F_PENDING));
 }
 
+/* walks: a traffic participant (pedestrian, cyclist) that the user spawned: a kinematic body moving with the
+ * world-frame velocity the user set (Pedestrian.set_velocity -> setLinearVelocity, traffic_participants/
+ * pedestrian.py:76-103, base_object.py:310-328), seen by lidar and contacts, not driven by any policy. */
+MD_HD int md_walks(int flags) {
+    const int k = md_kind_of(flags);
+    return (flags & MD_F_ALIVE) && !(flags & MD_F_STATIC) && (k == MD_KIND_PEDESTRIAN || k == MD_KIND_CYCLIST);
+}
+/* moves: the slot's pose can change in a step (what the fused kernel has to write back) */
+MD_HD int md_moves(int flags) { return md_drives(flags) || md_walks(flags); }
+
 MD_HD float md_sanitize(float a) { /* utils/math.py:16-26 safe_clip_for_small_array(.., -1, 1) */
     if (a != a) return 0.0f;
     if (a > 3.0e38f) return 1.0f;
@@ -114,9 +124,26 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n);
 /* What the step does with slot n between "actions are known" and "poses are new": replay mode moves the
  * non-agent slots along their tracks, everything else integrates.  (Apart from md_integrate_mover so that the
  * trigger-mode kernel does not carry the replay code: it costs 4 % there.) */
+MD_HD void md_walk_mover(const MdState* s, const MdConfig* c, int n);
+
 MD_HD void md_advance_mover(const MdState* s, const MdConfig* c, int n) {
     if (c->traffic_mode == 3 && n >= c->agents_per_env) md_replay_mover(s, c, n);
-    else md_integrate_mover(s, c, n);
+    else {
+        md_walk_mover(s, c, n);
+        md_integrate_mover(s, c, n);
+    }
+}
+
+/* participant: MdDyn.steering / .throttle hold its world-frame velocity (vx, vy), m/s */
+MD_HD void md_walk_mover(const MdState* s, const MdConfig* c, int n) {
+    MdShape* sh = &s->shape[n];
+    if (!md_walks(sh->flags)) return;
+    MdDyn* d = &s->dyn[n];
+    const float step_dt = c->dt * (float)c->substeps;
+    d->last_x = sh->cx;
+    d->last_y = sh->cy;
+    sh->cx = sh->cx + d->steering * step_dt;
+    sh->cy = sh->cy + d->throttle * step_dt;
 }
 
 MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {

@@ -96,7 +96,8 @@ typedef struct MdShape {
     int32_t aux;    /* lane id (map-local) the object sits on, -1 if unknown      */
 } MdShape;
 
-/* 32-byte dynamic record. */
+/* 32-byte dynamic record.  For a walking participant (MD_KIND_PEDESTRIAN / MD_KIND_CYCLIST, not MD_F_STATIC):
+ * steering / throttle hold its world-frame velocity (vx, vy) in m/s, speed its norm. */
 typedef struct MdDyn {
     float heading;  /* psi, radians                                               */
     float speed;    /* signed forward speed, m/s                                  */

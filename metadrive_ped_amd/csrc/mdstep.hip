@@ -1222,6 +1222,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             if (RESPAWN) md_advance_mover(&s, &c, j);  // the non-trigger traffic modes' kernel (respawn / hybrid / replay)
             else md_integrate_mover(&s, &c, j);
         }
+        if (!RESPAWN)  // user-spawned pedestrians / cyclists (a loop of its own: inside the one above it costs spills)
+            for (int j = tid; j < cap; j += kBlock) md_walk_mover(&s, &c, j);
         __syncthreads();
     }
     MD_STAMP_AT(4);
@@ -1347,7 +1349,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             // respawned) or were removed this step can differ from what HBM already holds -- props, waiting and
             // dead traffic are never written by any phase.  Writing just those cuts the store traffic ~4x.
             const bool replay = c.traffic_mode == 3;  // replayed slots move without "driving"
-            auto dirty = [&](int j) { return replay || md_drives(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
+            auto dirty = [&](int j) { return replay || md_moves(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
             for (int i = tid; i < cap * 2; i += kBlock)
                 if (dirty(i >> 1)) {
                     reinterpret_cast<uint4*>(gv.shape)[i] = reinterpret_cast<const uint4*>(l_shape)[i];

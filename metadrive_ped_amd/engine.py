@@ -438,6 +438,33 @@ class BatchedEngine:
         self._check(self.lib.md_lidar(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(out.data_ptr()),
                                       stride, offset, self._stream()), "md_lidar")
 
+    # -- user-spawned traffic participants (engine.spawn_object(Pedestrian, ...) + set_velocity of the reference,
+    #    tests/test_functionality/test_pedestrian.py:38-55); see participants.py ---------------------------------
+    def _edit_participants(self, fn):
+        names = ("shape", "shape0", "dyn", "flags")
+        st = {k: self.state_dev[k].cpu().numpy().view(self.host.state[k].dtype).reshape(self.host.state[k].shape).copy()
+              for k in names}
+        out = fn(st)
+        self.upload_state({k: st[k] for k in ("shape", "dyn", "flags")})
+        return out
+
+    def spawn_object(self, kind, position, heading_theta=0.0, envs=None):
+        """-> slot handle.  The participant lives until its env resets (auto-reset included)."""
+        from metadrive_ped_amd import participants as P
+        return self._edit_participants(lambda st: P.spawn(st, self.E, self.cap, self.A, kind, position, heading_theta, envs))
+
+    def set_velocity(self, slot, direction, value=None, in_local_frame=False, envs=None):
+        from metadrive_ped_amd import participants as P
+        self._edit_participants(lambda st: P.set_velocity(st, self.E, self.cap, slot, direction, value, in_local_frame, envs))
+
+    def clear_objects(self, slots, envs=None):
+        from metadrive_ped_amd import participants as P
+        self._edit_participants(lambda st: [P.clear(st, self.E, self.cap, s, envs) for s in slots])
+
+    def object_positions(self, slot):
+        """[E, 2] tensor view of the slot's centre in every env."""
+        return self.shape_f[:, slot, 0:2]
+
     def download_state(self):
         """Device state -> dict of numpy arrays with the host dtypes (tests / checkpoints)."""
         out = {}

@@ -118,6 +118,16 @@ class BatchedMultiAgentRoundaboutEnv:
             "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
         }
 
+    # traffic participants (needs mover_capacity > num_agents: the agents' slots are never handed out)
+    def spawn_object(self, kind, position, heading_theta=0.0, envs=None):
+        return self.engine.spawn_object(kind, position, heading_theta, envs)
+
+    def set_velocity(self, handle, direction, value=None, in_local_frame=False, envs=None):
+        self.engine.set_velocity(handle, direction, value, in_local_frame, envs)
+
+    def clear_objects(self, handles, envs=None):
+        self.engine.clear_objects(list(handles), envs)
+
     def to_dicts(self, e, obs, reward, terminated, truncated, info):
         """The reference's per-agent dict view of env `e` (keys "agent{k}", plus "__all__")."""
         act = info["active"][e].cpu().numpy()

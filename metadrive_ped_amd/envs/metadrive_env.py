@@ -138,6 +138,19 @@ class BatchedMetaDriveEnv:
     def stop_recording(self):
         return self.engine.stop_recording()
 
+    # -- traffic participants spawned by the user (engine.spawn_object(Pedestrian, ...) of the reference) -------------
+    def spawn_object(self, kind, position, heading_theta=0.0, envs=None):
+        """kind "pedestrian" | "cyclist" at `position` (one [x, y] or one per chosen env) -> handle.  It is hit by
+        lidar beams, crashing into it sets crash_human, it moves with the velocity given by set_velocity and it is
+        gone when its env resets."""
+        return self.engine.spawn_object(kind, position, heading_theta, envs)
+
+    def set_velocity(self, handle, direction, value=None, in_local_frame=False, envs=None):
+        self.engine.set_velocity(handle, direction, value, in_local_frame, envs)
+
+    def clear_objects(self, handles, envs=None):
+        self.engine.clear_objects(list(handles), envs)
+
     def export_scenarios(self, tracks, envs=None):
         """BaseEnv.export_scenarios (envs/base_env.py:775-836) for a recorded batch: one scenario description (the
         reference's unified dict format, see scenario_export.py) per env of `envs` from stop_recording()'s tracks."""

@@ -217,3 +217,43 @@ def test_double_buffered_sub_batches_equal_the_whole_batch():
         assert torch.equal(torch.cat([r[3] for r in res]), cw)
     sub.close()
     whole.close()
+
+
+def test_env_spawn_object_pedestrian_known_answer_and_crash():
+    """env.spawn_object / set_velocity (the reference's engine.spawn_object(Pedestrian, ...) + set_velocity): the walking
+    schedule of the reference's test_pedestrian.py ends at x = 160 +- 1 on the device too; driving into a standing
+    pedestrian sets info['crash_human'] and terminates."""
+    import torch
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    E = 4
+    env = BatchedMetaDriveEnv(dict(num_envs=E, num_scenarios=E, traffic_density=0.0, map="X", start_seed=22,
+                                   random_lane_width=True, mover_capacity=8, horizon=5000, auto_reset=False))
+    env.reset()
+    ped = env.spawn_object("pedestrian", [30.0, 0.0], 0.0)
+    env.set_velocity(ped, [1, 0], 1, in_local_frame=True)
+    stand = torch.zeros(E, 2, device="cuda")
+    for s in range(1, 1000):
+        env.step(stand)
+        if s == 300:
+            env.set_velocity(ped, [1, 0], 0, in_local_frame=True)
+        elif s == 500:
+            env.set_velocity(ped, [1, 0], 2, in_local_frame=True)
+    x = env.engine.object_positions(ped)[:, 0].cpu().numpy()
+    assert (np.abs(x - 160.0) < 1.0).all(), "Pedestrian movement error!"
+    env.close()
+
+    env = BatchedMetaDriveEnv(dict(num_envs=E, num_scenarios=E, traffic_density=0.0, map="SS", mover_capacity=8, horizon=400))
+    env.reset()
+    sf = env.engine.shape_f[:, 0].cpu().numpy()
+    ahead = np.stack([sf[:, 0] + 18.0 * sf[:, 2], sf[:, 1] + 18.0 * sf[:, 3]], 1)
+    env.spawn_object("pedestrian", ahead, 0.0)
+    go = torch.tensor([[0.0, 1.0]], device="cuda").repeat(E, 1)
+    hit = torch.zeros(E, dtype=torch.bool, device="cuda")
+    for t in range(120):
+        _, _, term, _, info = env.step(go)
+        assert bool((term | ~info["crash_human"]).all())
+        hit |= info["crash_human"]
+    assert bool(hit.all())
+    with pytest.raises(ValueError):
+        env.spawn_object("truck", [0.0, 0.0])
+    env.close()
