@@ -225,6 +225,15 @@ MD_HD void md_lane_local(const MdLane* L, float x, float y, float* s_out, float*
     *lat_out = L->dirsign * (md_norm(dx, dy) - radius);
 }
 
+/* Sign test of ray_localization's heading filter (utils/pg/utils.py:181-184: cos(lane heading at the vehicle's
+ * longitudinal, vehicle heading) > 0): the lane's tangent at the point dotted with the vehicle's heading (c, s).
+ * Straight lane: its unit direction.  Circular lane: the tangent at the point's own phase, dirsign * (-(y - cy),
+ * x - cx), left un-normalised -- only the sign is used -- so the filter needs neither the heading angle nor a sincos. */
+MD_HD float md_lane_heading_dot(const MdLane* L, float x, float y, float c, float s) {
+    if (L->type == 0) return L->bx * c + L->by * s;
+    return L->dirsign * ((x - L->ax) * s - (y - L->ay) * c);
+}
+
 MD_HD float md_lane_heading_at(const MdLane* L, float s) {
     if (L->type == 0) return L->heading;
     float phi = L->dirsign * s / L->bx + L->by;

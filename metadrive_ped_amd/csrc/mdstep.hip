@@ -257,6 +257,7 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
     int on_lane = 0;
     int best_any = -1, best_cur = -1, best_next = -1;
     float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
+    float ls_any = 0.0f, ls_cur = 0.0f, ls_next = 0.0f;
     // Candidate lanes of the cell: each LANE fetches one cell item and tests its lane record's hull
     // AABB (records are in LDS); survivors are visited in ascending lane id through the ballot mask
     // (ties in distance resolve to the lowest lane id, like the oracle's ascending scan).
@@ -300,22 +301,18 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
         if (inside == 0ull) continue;
         on_lane = 1;
         // pass B: my lane's candidate (if contained): Frenet coordinates, heading filter, L1 distance
-        float my_dist = 3.0e38f;
+        float my_dist = 3.0e38f, my_ls = 0.0f;
         int my_road = -1;
         if ((inside >> lane_id) & 1ull) {
             const MdLane* L = &lanes[l];
-            float ls, llat;
-            md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
-            const float lh = md_lane_heading_at(L, ls);
-            float hs_, hc_;
-            md_sincos(lh, &hs_, &hc_);
-            const float cosangle = hc_ * sh.c + hs_ * sh.s;
-            if (cosangle > 0.0f) {
-                my_dist = md_lane_distance(L, ls, llat);
+            float llat;
+            md_lane_local(L, sh.cx, sh.cy, &my_ls, &llat);
+            if (md_lane_heading_dot(L, sh.cx, sh.cy, sh.c, sh.s) > 0.0f) {
+                my_dist = md_lane_distance(L, my_ls, llat);
                 my_road = L->road;
             }
         }
-        // pass C
+        // pass C (the winner's longitudinal is kept: the checkpoint update below needs it)
         while (inside) {
             const int k = __ffsll((long long)inside) - 1;
             inside &= inside - 1;
@@ -323,18 +320,20 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
             const int road = bcast_i(my_road, k);
             const int lk = bcast_i(l, k);
             if (road < 0) continue;  // failed the heading filter
-            if (dist < d_any) { d_any = dist; best_any = lk; }
-            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
-            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
+            const float lsk = bcast_f(my_ls, k);
+            if (dist < d_any) { d_any = dist; best_any = lk; ls_any = lsk; }
+            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; ls_cur = lsk; }
+            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; ls_next = lsk; }
         }
     }
     MD_FINE_STAMP(n == 0 && lane_id == 0, 3);
     if (lane_id != 0) return;  // everything below is wave-uniform; lane 0 commits
     int lane = -1;
-    if (best_cur >= 0) lane = best_cur;
-    else if (!has_next) lane = best_any;
-    else if (best_next >= 0) lane = best_next;
-    else lane = best_any;
+    float ls = 0.0f;
+    if (best_cur >= 0) { lane = best_cur; ls = ls_cur; }
+    else if (!has_next) { lane = best_any; ls = ls_any; }
+    else if (best_next >= 0) { lane = best_next; ls = ls_next; }
+    else { lane = best_any; ls = ls_any; }
     if (onlane_out) {
         onlane_out[n] = on_lane ? MD_FL_ON_LANE : 0u;
     } else {
@@ -342,12 +341,15 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
         if (on_lane) fl |= MD_FL_ON_LANE;
         s.flags[n] = fl;
     }
-    if (lane < 0) lane = nav.lane;
+    const bool kept = lane < 0;  // found nothing: the previous lane stays, its longitudinal was not evaluated above
+    if (kept) lane = nav.lane;
     s.nav[n].lane = lane;
     if (lane < 0) return;
     if (nav.ck0 == nav.ck1) return;
-    float ls, llat;
-    md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    if (kept) {
+        float llat;
+        md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    }
     if (!(ls < 5.0f)) return;
     const int start_node = roads[lanes[lane].road].start_node;
     const int k = nav.route_len;
@@ -400,6 +402,7 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
     int on_lane = 0;
     int best_any = -1, best_cur = -1, best_next = -1;
     float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
+    float ls_any = 0.0f, ls_cur = 0.0f, ls_next = 0.0f;
     const auto half_of = [&](unsigned long long b) { return (unsigned)(h ? (b >> 32) : (b & 0xFFFFFFFFull)); };
     for (int itb = it0; __ballot(itb < it1) != 0ull; itb += 32) {
         const int it = itb + hl;
@@ -436,18 +439,14 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
             if (mine && out_h == 0u && hn >= 3) inside |= 1u << k;
         }
         if (inside != 0u) on_lane = 1;
-        float my_dist = 3.0e38f;
+        float my_dist = 3.0e38f, my_ls = 0.0f;
         int my_road = -1;
         if ((inside >> hl) & 1u) {
             const MdLane* L = &lanes[l];
-            float ls, llat;
-            md_lane_local(L, sh.cx, sh.cy, &ls, &llat);
-            const float lh = md_lane_heading_at(L, ls);
-            float hs_, hc_;
-            md_sincos(lh, &hs_, &hc_);
-            const float cosangle = hc_ * sh.c + hs_ * sh.s;
-            if (cosangle > 0.0f) {
-                my_dist = md_lane_distance(L, ls, llat);
+            float llat;
+            md_lane_local(L, sh.cx, sh.cy, &my_ls, &llat);
+            if (md_lane_heading_dot(L, sh.cx, sh.cy, sh.c, sh.s) > 0.0f) {
+                my_dist = md_lane_distance(L, my_ls, llat);
                 my_road = L->road;
             }
         }
@@ -458,25 +457,30 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
             const float dist = __shfl(my_dist, hbase + k, 64);
             const int road = __shfl(my_road, hbase + k, 64);
             const int lk = __shfl(l, hbase + k, 64);
+            const float lsk = __shfl(my_ls, hbase + k, 64);
             if (!mine || road < 0) continue;
-            if (dist < d_any) { d_any = dist; best_any = lk; }
-            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; }
-            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; }
+            if (dist < d_any) { d_any = dist; best_any = lk; ls_any = lsk; }
+            if (road == cur_road && dist < d_cur) { d_cur = dist; best_cur = lk; ls_cur = lsk; }
+            if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; ls_next = lsk; }
         }
     }
     if (hl != 0 || !act) return;  // lane 0 of each half commits its vehicle
     int lane = -1;
-    if (best_cur >= 0) lane = best_cur;
-    else if (!has_next) lane = best_any;
-    else if (best_next >= 0) lane = best_next;
-    else lane = best_any;
+    float ls = 0.0f;
+    if (best_cur >= 0) { lane = best_cur; ls = ls_cur; }
+    else if (!has_next) { lane = best_any; ls = ls_any; }
+    else if (best_next >= 0) { lane = best_next; ls = ls_next; }
+    else { lane = best_any; ls = ls_any; }
     onlane_out[n] = on_lane ? MD_FL_ON_LANE : 0u;
-    if (lane < 0) lane = nav.lane;
+    const bool kept = lane < 0;  // found nothing: the previous lane stays, its longitudinal was not evaluated above
+    if (kept) lane = nav.lane;
     s.nav[n].lane = lane;
     if (lane < 0) return;
     if (nav.ck0 == nav.ck1) return;
-    float ls, llat;
-    md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    if (kept) {
+        float llat;
+        md_lane_local(&lanes[lane], sh.cx, sh.cy, &ls, &llat);
+    }
     if (!(ls < 5.0f)) return;
     const int start_node = roads[lanes[lane].road].start_node;
     const int kk = nav.route_len;

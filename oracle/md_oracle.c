@@ -155,11 +155,7 @@ static void localize_mover(const MdWorld* w, const MdState* s, const MdConfig* c
         on_lane = 1;
         float ls, llat;
         md_lane_local(L, sh->cx, sh->cy, &ls, &llat);
-        float lh = md_lane_heading_at(L, ls);
-        float hs_, hc_;
-        md_sincos(lh, &hs_, &hc_);
-        float cosangle = hc_ * sh->c + hs_ * sh->s;
-        if (!(cosangle > 0.0f)) continue;
+        if (!(md_lane_heading_dot(L, sh->cx, sh->cy, sh->c, sh->s) > 0.0f)) continue;
         float dist = md_lane_distance(L, ls, llat);
         if (dist < d_any) { d_any = dist; best_any = l; }
         if (L->road == cur_road && dist < d_cur) { d_cur = dist; best_cur = l; }
