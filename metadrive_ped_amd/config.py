@@ -104,6 +104,7 @@ BATCH_DEFAULT_CONFIG = dict(
     auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
     device="cuda:0",
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
+    initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
 )
 
 _OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False)
@@ -164,6 +165,22 @@ def make_config(user=None):
             raise KeyError("random_dynamics: unknown parameter(s) {}".format(sorted(unknown)))
     if cfg["is_multi_agent"] and abs(cfg["accident_prob"]) >= 1e-2:
         raise NotImplementedError("accident scenes in a multi-agent env are not built")
+    if cfg["num_agents"] == -1:
+        # "infinite agents" (spawn_manager.py:74-78, agent_manager.py:272-279, multi_agent_metadrive.py:86-92): every spawn
+        # point holds an agent at reset and a new agent enters whenever a spawn region is clear, whatever the number on
+        # the road.  With fixed slots: capacity = all spawn points, and as many slots again for vehicles still on the
+        # road (active or dying) -- a respawn needs a free slot too, which is the one bound the reference does not have.
+        if not cfg["is_multi_agent"] or cfg["marl_map"] is None:
+            raise ValueError("num_agents=-1 (infinite agents) is a multi-agent env option")
+        import math
+        from metadrive_ped_amd.marl import PG_SPAWN_ROADS, SPAWN_ROADS
+        roads = PG_SPAWN_ROADS if cfg["marl_map"] == "pg" else SPAWN_ROADS[cfg["marl_map"]]
+        slots = int(math.floor((cfg["map_config"]["exit_length"] - 10) / 8.0))      # max_capacity (spawn_manager.py:108-115)
+        if slots <= 0:
+            raise ValueError("The exist length {} should greater than minimal longitude interval {}.".format(
+                cfg["map_config"]["exit_length"] - 10, 18))
+        cfg["initial_agents"] = cfg["map_config"]["lane_num"] * len(roads) * slots
+        cfg["num_agents"] = min(128, 2 * cfg["initial_agents"])
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):

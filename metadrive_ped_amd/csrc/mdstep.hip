@@ -1181,7 +1181,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             for (int j = tid; j < cap; j += kBlock) gv.agent_id[j] = j;
             if (tid == 0) {
                 gv.env_steps[0] = 0;
-                gv.next_agent_id[0] = c.agents_per_env;
+                int n0 = 0;  // agents present at reset: all slots, or one per spawn point with num_agents = -1
+                for (int j = 0; j < c.agents_per_env; ++j) n0 += (gv.shape0[j].flags & MD_F_ALIVE) ? 1 : 0;
+                gv.next_agent_id[0] = n0;
             }
         }
     }

@@ -115,7 +115,7 @@ class HostScene:
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
                          random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
-                         random_dynamics=cfg["random_dynamics"])
+                         random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
@@ -206,7 +206,7 @@ class HostScene:
         if cfg["is_multi_agent"]:
             st["env_steps"] = np.zeros(E, np.int32)
             st["agent_id"] = np.tile(np.arange(cap, dtype=np.int32), E)
-            st["next_agent_id"] = np.full(E, A, np.int32)
+            st["next_agent_id"] = np.full(E, cfg["initial_agents"] or A, np.int32)   # names agent0 .. agent{n-1} are taken
         if self.num_others > 0:
             st["detected"] = np.zeros((E * A, 2), np.uint64)
         self.state = st

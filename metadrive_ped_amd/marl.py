@@ -66,9 +66,15 @@ class RoundaboutScene:
         exit_length = cfg["exit_length"] - 10   # minus FirstPGBlock.ENTRANCE_LENGTH
         num_slots = int(math.floor(exit_length / REGION_LONG))
         spots = [(road, li, j) for road in ROUNDABOUT_SPAWN_ROADS for li in range(lane_num) for j in range(num_slots)]
-        if A > len(spots):
+        if A > len(spots) and not cfg.get("initial_agents", 0):
             raise ValueError("Too many agents! We only accept {} agents, but you have {} agents!".format(len(spots), A))
-        chosen = rng.choice(len(spots), A, replace=False)
+        if cfg.get("initial_agents", 0):
+            # num_agents = -1: every spawn point in order, no draw (spawn_manager.py:77-78); slots beyond stay free
+            if cfg["initial_agents"] != len(spots):
+                raise ValueError("initial_agents {} != spawn points {}".format(cfg["initial_agents"], len(spots)))
+            chosen = np.arange(len(spots))
+        else:
+            chosen = rng.choice(len(spots), A, replace=False)
         dests = [negate_road(*r)[1] for r in ROUNDABOUT_SPAWN_ROADS]
         prm, length, width, vcfg = vehicle_param_record(cfg["agent_vehicle_model"], 0, cfg["physics_world_step_size"])
         for a, k in enumerate(chosen):
@@ -100,6 +106,8 @@ class RoundaboutScene:
         # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
         self.shape["hl"], self.shape["hw"] = length / 2, width / 2
         self.param[:] = prm
+        for a in range(len(chosen), A):
+            self.shape[a]["flags"] = abi.KIND_VEHICLE      # a free agent slot: what the lifecycle hands to the next spawn
 
     def trim(self, cap):
         pass

@@ -358,7 +358,11 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
         }
         if (c->is_multi_agent) {
             s->env_steps[e] = 0;
-            s->next_agent_id[e] = c->agents_per_env;
+            /* names agent0 .. agent{n-1} are taken by the agents present at reset (all slots, or with num_agents = -1
+             * one per spawn point: the other slots start free) */
+            int n0 = 0;
+            for (int j = 0; j < c->agents_per_env; ++j) n0 += (s->shape0[base + j].flags & MD_F_ALIVE) ? 1 : 0;
+            s->next_agent_id[e] = n0;
             for (int j = 0; j < c->cap; ++j) s->agent_id[base + j] = j;
         }
         s->need_reset[e] = 0;

@@ -399,3 +399,76 @@ def test_pg_multi_agent_rollout_parity_gpu():
             assert_state_equal(eng.download_state(), orc.state, where="pg marl step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="pg marl final")
     assert (orc.state["next_agent_id"] > A).any()
+
+
+def test_infinite_agents_fill_every_spawn_point_and_keep_coming():
+    """num_agents = -1 (tests/test_functionality/test_marl_infinite_agents.py of the reference): every spawn point holds an
+    agent at reset (no random choice), new agents enter whenever a spawn region is clear -- more bodies on the road than
+    spawn points -- and every finished agent lived at least one step."""
+    import oracle_binding as ob
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    E = 2
+    env = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=-1, delay_done=50, horizon=50,
+                                              map_config=dict(exit_length=20, lane_num=2)))
+    cfg = env.config
+    assert cfg["initial_agents"] == 2 * 4 * 1 and cfg["num_agents"] == 16       # lane_num x spawn roads x floor(10 / 8)
+    h = HostScene(cfg)
+    o = ob.OracleWorld(h)
+    o.reset()
+    A, cap = h.A, h.cap
+    sh = o.state["shape"].reshape(E, cap)
+    alive0 = ((sh["flags"][:, :A] & abi.F_ALIVE) != 0)
+    assert (alive0.sum(1) == 8).all() and alive0[:, :8].all()
+    assert (o.state["agent_id"].reshape(E, cap)[:, :8] == np.arange(8)).all() and (o.state["next_agent_id"] == 8).all()
+    max_bodies, max_active = 8, 8
+    go = np.tile(np.array([0.0, 1.0], np.float32), (E, A, 1))
+    for t in range(120):
+        o.step(go)
+        sh = o.state["shape"].reshape(E, cap)
+        alive = (sh["flags"][:, :A] & abi.F_ALIVE) != 0
+        active = alive & ((sh["flags"][:, :A] & abi.F_STATIC) == 0)
+        max_bodies, max_active = max(max_bodies, int(alive.sum(1).max())), max(max_active, int(active.sum(1).max()))
+        fl = o.state["flags"].reshape(E, cap)[:, :A]
+        done = ((fl & (abi.FL_TERMINATED | abi.FL_TRUNCATED)) != 0) & active
+        assert (o.state["nav"]["steps"].reshape(E, cap)[:, :A][done] >= 1).all()
+    assert max_bodies > 8, "no agent entered beyond the number of spawn points"
+    assert (o.state["next_agent_id"] > 8).all()
+    with pytest.raises(ValueError):
+        from metadrive_ped_amd.config import make_config
+        make_config(dict(num_agents=-1))
+
+
+@pytest.mark.gpu
+def test_infinite_agents_rollout_parity_gpu():
+    """num_agents = -1 on the device: free agent slots at reset, agents entering beyond the number of spawn points,
+    env resets in between (horizon 60) -- bit-exact with the oracle, agent names included."""
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    E = 8
+    cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=-1, delay_done=30, horizon=60,
+                                              map_config=dict(exit_length=30, lane_num=2))).config
+    A = cfg["num_agents"]
+    assert cfg["initial_agents"] == 16 and A == 32
+    eng = BatchedEngine(cfg)
+    orc = ob.OracleWorld(eng.host)
+    keys = ["shape", "dyn", "nav", "pid", "action", "flags", "obs", "reward", "cost", "step_info", "need_reset",
+            "route_nodes", "route_roads", "final_lane", "rng", "env_steps", "agent_id", "next_agent_id"]
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, keys=keys, where="infinite reset")
+    rng = np.random.RandomState(5)
+    most = 0
+    for t in range(150):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.8
+        a[..., 0] = rng.uniform(-0.2, 0.2, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 15 == 0:
+            assert_state_equal(eng.download_state(), orc.state, keys=keys, where="infinite step %d" % t)
+        most = max(most, int(((orc.state["shape"].reshape(E, -1)["flags"][:, :A] & abi.F_ALIVE) != 0).sum(1).max()))
+    assert_state_equal(eng.download_state(), orc.state, keys=keys, where="infinite final")
+    assert most > 16
