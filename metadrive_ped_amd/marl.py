@@ -75,6 +75,8 @@ class RoundaboutScene:
             chosen = np.arange(len(spots))
         else:
             chosen = rng.choice(len(spots), A, replace=False)
+            if A == 1:
+                chosen = np.array([0])   # a lone agent takes the FIRST spawn point, whatever was drawn (spawn_manager.py:85-91)
         dests = [negate_road(*r)[1] for r in ROUNDABOUT_SPAWN_ROADS]
         prm, length, width, vcfg = vehicle_param_record(cfg["agent_vehicle_model"], 0, cfg["physics_world_step_size"])
         for a, k in enumerate(chosen):

@@ -472,3 +472,34 @@ def test_infinite_agents_rollout_parity_gpu():
         most = max(most, int(((orc.state["shape"].reshape(E, -1)["flags"][:, :A] & abi.F_ALIVE) != 0).sum(1).max()))
     assert_state_equal(eng.download_state(), orc.state, keys=keys, where="infinite final")
     assert most > 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5])
+def test_small_agent_counts_rollout_parity_gpu(n):
+    """num_agents 1 / 5 (tests/test_env/test_ma_env_force_reset.py, test_change_agent_num.py): the multi-agent kernel with
+    a single slot, and the lone agent's fixed first spawn point."""
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    E = 6
+    cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=n, horizon=120)).config
+    eng = BatchedEngine(cfg)
+    assert eng.A == n and eng.cap == n
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    rng = np.random.RandomState(n)
+    for t in range(140):
+        a = np.zeros((E, n, 2), np.float32)
+        a[..., 1] = 0.9
+        a[..., 0] = rng.uniform(-0.2, 0.2, (E, n))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 20 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="n=%d step %d" % (n, t))
+    assert_state_equal(eng.download_state(), orc.state, where="n=%d final" % n)
+    if n == 1:
+        sh0 = eng.host.state["shape0"].reshape(E, -1)
+        assert np.allclose(sh0["cy"][:, 0], sh0["cy"][0, 0], atol=0.3)       # same (first) spawn lane in every scenario
