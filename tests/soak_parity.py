@@ -27,6 +27,10 @@ def main():
         respawn=dict(traffic_mode="respawn", traffic_density=0.15),
         safe=dict(accident_prob=0.8, traffic_density=0.05, crash_vehicle_done=False, crash_object_done=False),
         dense5=dict(map=5, traffic_density=0.3),
+        varying=dict(vehicle_config=dict(vehicle_model="varying_dynamics"),
+                     random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600), wheel_friction=(0.1, 2.5),
+                                          max_steering=(10, 80), mass=(300, 3000))),
+        walkers=dict(mover_capacity=40, traffic_density=0.15),   # + a pedestrian and a cyclist spawned every 400 steps
     )
     for name, extra in configs.items():
         cfg = make_config(dict(dict(num_envs=E, num_scenarios=E, horizon=1000), **extra))
@@ -37,6 +41,22 @@ def main():
         rng = np.random.RandomState(7)
         t0 = time.time()
         for t in range(steps):
+            if name == "walkers" and t % 400 == 10:
+                from metadrive_ped_amd import participants as P
+                sh = orc.state["shape"].reshape(E, -1)
+                hd = np.arctan2(sh["s"][:, 0], sh["c"][:, 0])
+                spots = [np.stack([sh["cx"][:, 0] + d * sh["c"][:, 0] + q * sh["s"][:, 0],
+                                   sh["cy"][:, 0] + d * sh["s"][:, 0] - q * sh["c"][:, 0]], 1) for d, q in ((15.0, 0.0), (30.0, 5.0))]
+                free = ((sh["flags"] & 0xF) == 0) & ((orc.state["shape0"].reshape(E, -1)["flags"] & 0xF) == 0)
+                if free[:, eng.A:].all(0).sum() >= 2:        # earlier walkers are gone wherever the env has reset since
+                    p = eng.spawn_object("pedestrian", spots[0], hd + np.pi)
+                    c = eng.spawn_object("cyclist", spots[1], hd + np.pi / 2)
+                    eng.set_velocity(p, [1, 0], 1.0, in_local_frame=True)
+                    eng.set_velocity(c, [1, 0], 3.0, in_local_frame=True)
+                    assert p == P.spawn(orc.state, E, eng.cap, eng.A, "pedestrian", spots[0], hd + np.pi)
+                    assert c == P.spawn(orc.state, E, eng.cap, eng.A, "cyclist", spots[1], hd + np.pi / 2)
+                    P.set_velocity(orc.state, E, eng.cap, p, [1, 0], 1.0, in_local_frame=True)
+                    P.set_velocity(orc.state, E, eng.cap, c, [1, 0], 3.0, in_local_frame=True)
             # a mix of random and lane-keeping actions so that both short and long episodes occur
             obs = orc.obs
             steer = np.clip(4.0 * (obs[:, 2] - 0.5) + 2.0 * (obs[:, 8] - 0.5), -1, 1)
@@ -62,8 +82,9 @@ def main_marl():
                                                  BatchedMultiAgentRoundaboutEnv)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     E = 48
-    for cls in (BatchedMultiAgentRoundaboutEnv, BatchedMultiAgentIntersectionEnv, BatchedMultiAgentBottleneckEnv):
-        cfg = cls(dict(num_envs=E, num_scenarios=E)).config
+    for cls, extra in ((BatchedMultiAgentRoundaboutEnv, {}), (BatchedMultiAgentIntersectionEnv, {}), (BatchedMultiAgentBottleneckEnv, {}),
+                       (BatchedMultiAgentRoundaboutEnv, dict(num_agents=-1, map_config=dict(exit_length=40, lane_num=2)))):
+        cfg = cls(dict(dict(num_envs=E, num_scenarios=E), **extra)).config
         eng = BatchedEngine(cfg)
         A = eng.A
         orc = ob.OracleWorld(eng.host)
@@ -84,7 +105,7 @@ def main_marl():
             if (t + 1) % 250 == 0:
                 assert_state_equal(eng.download_state(), orc.state, where="%s step %d" % (cls.__name__, t + 1))
         print("%-36s %d steps x %d envs x %d agents bit-exact (%.0f s, %d agents created per env)" %
-              (cls.__name__, steps, E, A, time.time() - t0, int(orc.state["next_agent_id"].mean())), flush=True)
+              (cls.__name__ + (" infinite" if extra else ""), steps, E, A, time.time() - t0, int(orc.state["next_agent_id"].mean())), flush=True)
 
 
 if __name__ == "__main__":
