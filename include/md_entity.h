@@ -154,6 +154,8 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     float thr = md_sanitize(s->action[2 * n + 1]);
     s->action[2 * n] = steer;
     s->action[2 * n + 1] = thr;
+    /* yaw increment per sub-step at the end of the previous step ~ its mean: sin(heading change) / substeps */
+    float yaw = (sh->s * d->last_c - sh->c * d->last_s) / (float)c->substeps;
     d->last_x = sh->cx;
     d->last_y = sh->cy;
     d->last_c = sh->c;
@@ -162,10 +164,11 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     d->throttle = thr;
     float x = sh->cx, y = sh->cy, psi = d->heading, v = d->speed;
     MdBicycle bike;
-    md_bicycle_prepare(steer, thr, &s->param[n], &bike);
-    float cp, sp;
-    md_sincos(psi + bike.beta, &sp, &cp);
-    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, &cp, &sp, thr, &bike, &s->param[n], c->dt);
+    md_bicycle_prepare(steer, thr, v, sh->hl, sh->hw, c->dt, &s->param[n], &bike);
+    float c0, s0;
+    md_sincos(psi, &s0, &c0);
+    float cp = c0 * bike.cb - s0 * bike.sb, sp = s0 * bike.cb + c0 * bike.sb; /* travel direction psi + beta */
+    for (int k = 0; k < c->substeps; ++k) md_bicycle_substep(&x, &y, &psi, &v, &cp, &sp, &yaw, thr, &bike, &s->param[n], c->dt);
     sh->cx = x;
     sh->cy = y;
     d->heading = psi;

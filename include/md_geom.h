@@ -274,16 +274,31 @@ MD_HD int md_lane_is_previous_of(const MdLane* A, const MdLane* B) {
  * bicycle_model.py:17-51:  beta = atan(lr/(lf+lr) tan(delta)), pdot = v (cos,sin)(psi+beta),
  * psidot = v sin(beta)/lr.  Longitudinal: engine accel while throttle>=0 and speed below max,
  * constant idle-brake drag, brake decel capped by tyre friction; no reverse (enable_reverse=False).
+ * Lateral grip: a raycast-vehicle wheel cannot push sideways harder than frictionSlip x its load
+ * (wheel_friction in the vehicle config, pg_space.py:226-272), i.e. the lateral acceleration v^2 sin(beta)/lr is
+ * bounded by wheel_friction * g: beyond it the slip angle is cut back (the car understeers).  Without the bound a
+ * full-lock command at 30 km/h yaws 15 degrees in one 0.1 s step -- and the reference's own PID steering
+ * (PID_controller.py, heading gains 1.7 / 0.01 / 3.5 per step) limit-cycles at the step rate on such a plant,
+ * which the Bullet vehicle it was tuned on does not do.  For the same reason the yaw RATE has inertia here: it moves
+ * towards the kinematic value with the angular acceleration that the front axle's grip can give the chassis
+ * (wheel_friction g lf / (2 k^2) ~ 2.3 rad/s^2 for the default car), starting from the rate of the previous step
+ * (recovered from last_heading_dir, no extra state).  With both, the PID settles; without, it oscillates +-0.5 of
+ * full lock at the step rate (tests/test_oracle_behaviour.py::test_traffic_steering_settles).
  * -----------------------------------------------------------------------------------------*/
 typedef struct MdBicycle {
     float acc, dec;   /* engine acceleration / opposing deceleration for this step's action */
-    float beta;       /* slip angle atan(lr/(lf+lr) tan(delta))                              */
+    float sb, cb;     /* sin / cos of the slip angle atan(lr/(lf+lr) tan(delta)), grip-limited */
     float sb_over_lr; /* sin(beta) / lr                                                      */
+    float yaw_slew;   /* largest change of the yaw increment between two sub-steps: alpha_max dt^2, alpha_max =
+                       * wheel_friction g lf / (2 k^2), k^2 = (L^2 + W^2) / 12 the box's radius of gyration squared:
+                       * the front axle cannot push harder than its grip, so the yaw rate builds up over a few steps */
+    float yaw_cap;    /* |yaw rate| <= |v| yaw_cap: sin of the full-lock slip angle / lr     */
 } MdBicycle;
 
-/* Everything that depends on the action only (constant over the decision_repeat sub-steps), except
- * the engine cut-off which looks at the current speed (base_vehicle.py:474). */
-MD_HD void md_bicycle_prepare(float steer, float throttle, const MdParam* P, MdBicycle* b) {
+/* Everything that depends on the action and the speed at the start of the step (constant over the decision_repeat
+ * sub-steps), except the engine cut-off which looks at the current speed (base_vehicle.py:474). */
+MD_HD void md_bicycle_prepare(float steer, float throttle, float speed, float hl, float hw, float dt, const MdParam* P,
+                              MdBicycle* b) {
     b->acc = (throttle > 0.0f) ? P->accel_gain * throttle : 0.0f;
     if (throttle >= 0.0f) b->dec = P->roll_decel; /* setBrake(2.0): idle drag when the engine is idle / cut */
     else b->dec = md_min(-throttle * P->brake_gain, P->fric_decel);
@@ -291,10 +306,19 @@ MD_HD void md_bicycle_prepare(float steer, float throttle, const MdParam* P, MdB
     float sd, cd;
     md_sincos(delta, &sd, &cd);
     float tan_d = sd / cd;
-    b->beta = md_atan(P->lr / (P->lf + P->lr) * tan_d);
+    float beta = md_atan(P->lr / (P->lf + P->lr) * tan_d);
     float sb, cb;
-    md_sincos(b->beta, &sb, &cb);
+    md_sincos(beta, &sb, &cb);
+    float grip = P->fric_decel * P->lr / md_max(speed * speed, 1.0e-3f); /* largest |sin(beta)| the tyres can hold */
+    if (md_fabs(sb) > grip) {
+        sb = (sb > 0.0f) ? grip : -grip;
+        cb = md_sqrt(1.0f - sb * sb);
+    }
+    b->sb = sb;
+    b->cb = cb;
     b->sb_over_lr = sb / P->lr;
+    b->yaw_slew = P->fric_decel * P->lf * 1.5f / (hl * hl + hw * hw) * dt * dt;
+    b->yaw_cap = 0.5f / P->lr;
 }
 
 /* (cp, sp) = cos / sin of the direction of travel psi + beta, carried from sub-step to sub-step: the heading turns
@@ -302,8 +326,8 @@ MD_HD void md_bicycle_prepare(float steer, float throttle, const MdParam* P, MdB
  * sin d = d (1 - d^2/6 + d^4/120), cos d = 1 - d^2/2 + d^4/24 - d^6/720 (truncation below 1e-9) instead of being
  * re-evaluated with the full sincos: one sincos per step instead of five.  psi itself accumulates exactly as
  * before, and the pose's own (cos psi, sin psi) is taken from it once at the end of the step. */
-MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float* cp_io, float* sp_io, float throttle,
-                              const MdBicycle* b, const MdParam* P, float dt) {
+MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float* cp_io, float* sp_io, float* yaw_io,
+                              float throttle, const MdBicycle* b, const MdParam* P, float dt) {
     float vv = *v;
     float speed_kmh = md_fabs(vv) * 3.6f;
     float acc = 0.0f, dec = 0.0f;
@@ -326,7 +350,12 @@ MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float* c
     float vm = 0.5f * (vv + vnew);
     *x = *x + vm * cp * dt;
     *y = *y + vm * sp * dt;
-    float d = vm * b->sb_over_lr * dt;
+    /* yaw: the kinematic rate v sin(beta) / lr is approached with the angular acceleration the front axle's grip
+     * allows (b->yaw_slew per sub-step), and never exceeds what the wheels can trace at the present speed */
+    float d = *yaw_io + md_clip(vm * b->sb_over_lr * dt - *yaw_io, -b->yaw_slew, b->yaw_slew);
+    float d_max = md_fabs(vm) * b->yaw_cap * dt;
+    d = md_clip(d, -d_max, d_max);
+    *yaw_io = d;
     *psi = md_wrap_to_pi(*psi + d);
     float d2 = d * d;
     float sd = d * (1.0f - d2 * (0.16666667f - d2 * 0.0083333333f));

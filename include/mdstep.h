@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 5
+#define MD_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -309,6 +309,9 @@ typedef struct MdConfig {
     int32_t add_others_navi;   /* vehicle_config.lidar.add_others_navi                            */
     int32_t track_len;         /* frames in MdState.track_* (traffic_mode 3); later steps hold the last frame */
     int32_t random_agent_model;/* 1: two extra leading obs dims, length / 10 and width / 2.5 (obs/state_obs.py:70-75) */
+    int32_t agent_idm;         /* 1: config agent_policy = IDMPolicy (envs/base_env.py:53, manager/agent_manager.py:37-70): the
+                                * agents are driven by the IDM / PID policy of the traffic; MdState.agent_action is not read.
+                                * Single-agent envs only. */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

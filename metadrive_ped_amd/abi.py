@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 5
+MD_ABI_VERSION = 6
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -116,6 +116,7 @@ class MdConfig(C.Structure):
         ("add_others_navi", C.c_int32),
         ("track_len", C.c_int32),
         ("random_agent_model", C.c_int32),
+        ("agent_idm", C.c_int32),
     ]
 
 

@@ -22,6 +22,7 @@ BASE_DEFAULT_CONFIG = dict(
     allow_respawn=False,
     delay_done=0,
     # ===== action =====
+    agent_policy="EnvInputPolicy",   # or "IDMPolicy" (the class of that name is accepted too): envs/base_env.py:53
     discrete_action=False,
     use_multi_discrete=False,
     discrete_steering_dim=5,
@@ -123,7 +124,7 @@ def _merge(dst, src, path=""):
                 # utils/config.py:241-250: int <-> float are interchangeable
                 ok = isinstance(v, type(old)) or (isinstance(old, float) and isinstance(v, int)) or \
                     (isinstance(old, int) and not isinstance(old, bool) and isinstance(v, float)) or \
-                    (k == "map" and isinstance(v, (int, str))) or (k == "horizon")
+                    (k == "map" and isinstance(v, (int, str))) or (k == "horizon") or (k == "agent_policy")
                 if not ok:
                     raise TypeError("Attempting to update '{}{}' with type {}, expected {}".format(
                         path, k, type(v).__name__, type(old).__name__))
@@ -165,6 +166,14 @@ def make_config(user=None):
             raise KeyError("random_dynamics: unknown parameter(s) {}".format(sorted(unknown)))
     if cfg["is_multi_agent"] and abs(cfg["accident_prob"]) >= 1e-2:
         raise NotImplementedError("accident scenes in a multi-agent env are not built")
+    # agent_policy: the reference takes a policy CLASS; here its name (or a class of that name)
+    pol = cfg["agent_policy"]
+    pol = pol if isinstance(pol, str) else getattr(pol, "__name__", repr(pol))
+    if pol not in ("EnvInputPolicy", "IDMPolicy"):
+        raise NotImplementedError("agent_policy={!r}: built are EnvInputPolicy (actions from step()) and IDMPolicy".format(pol))
+    cfg["agent_policy"] = pol
+    if pol == "IDMPolicy" and cfg["is_multi_agent"]:
+        raise NotImplementedError("agent_policy=IDMPolicy in a multi-agent env is not built")
     if cfg["num_agents"] == -1:
         # "infinite agents" (spawn_manager.py:74-78, agent_manager.py:272-279, multi_agent_metadrive.py:86-92): every spawn
         # point holds an agent at reset and a new agent enters whenever a spawn region is clear, whatever the number on

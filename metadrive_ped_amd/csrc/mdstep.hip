@@ -1211,14 +1211,19 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     // otherwise idle behind the agent's observe chain.  Multi-agent envs keep the reference order (the
     // lifecycle at the start of a step may respawn agents the IDM would have to see).
     constexpr bool kFused = (PH == PH_ALL);
-    constexpr bool plan_ahead = kFused && kWaves > 1 && !MULTI;
+    // agent_policy = IDMPolicy (single-agent envs): the agents are planned like the traffic, in the reference's order
+    // (decide, then move): the observation reports the action applied in THIS step.  Never in the lean fused variant:
+    // the launcher sends such configs to the RESPAWN one.
+    const bool agent_idm = (kFused && !RESPAWN) ? false : (!MULTI && c.agent_idm != 0);
+    constexpr bool kPlanAhead = kFused && kWaves > 1 && !MULTI;
+    const bool plan_ahead = kPlanAhead && !agent_idm;
     if ((PH & PH_IDM) && !just_reset && !plan_ahead) {
         if (wave == 0) trigger_env(lanes, s, c, lane);
         __syncthreads();
         MD_STAMP_AT(2);
-        for (int j = c.agents_per_env + wave; j < cap; j += kWaves) {
+        for (int j = (agent_idm ? 0 : c.agents_per_env) + wave; j < cap; j += kWaves) {
             const int f = s.shape[j].flags;  // wave-uniform
-            if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
+            if (md_drives(f) && (agent_idm || !(f & MD_F_AGENT))) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
         }
         __syncthreads();
     }
@@ -1437,6 +1442,10 @@ int check_common(const MdWorld* w, const MdState* s, const MdConfig* c) {
         snprintf(g_err, sizeof g_err, "n_beams=%d out of range [0,%d]", c->n_beams, MD_MAX_BEAMS);
         return MD_EINVAL;
     }
+    if (c->agent_idm && c->is_multi_agent) {
+        snprintf(g_err, sizeof g_err, "agent_idm (agent_policy = IDMPolicy) is built for single-agent envs only");
+        return MD_EINVAL;
+    }
     if (!s->shape) {
         snprintf(g_err, sizeof g_err, "MdState.shape is null");
         return MD_EINVAL;
@@ -1480,7 +1489,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     if (kCanMulti && c->is_multi_agent) {
         if (stage) MD_LAUNCH(true, false, kCanMulti);
         else MD_LAUNCH(false, false, kCanMulti);
-    } else if (kCanRespawn && (c->traffic_mode != 0 || (PH == PH_ALL && s->detected != nullptr))) {
+    } else if (kCanRespawn && (c->traffic_mode != 0 || c->agent_idm != 0 || (PH == PH_ALL && s->detected != nullptr))) {
         if (stage) MD_LAUNCH(true, kCanRespawn, false);
         else MD_LAUNCH(false, kCanRespawn, false);
     } else if (stage) {

@@ -115,7 +115,8 @@ class HostScene:
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
                          random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
-                         random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"])
+                         random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"],
+                         agent_policy=cfg["agent_policy"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
@@ -214,6 +215,7 @@ class HostScene:
         self.md_config.n_side, self.md_config.n_lane_line = self.n_side, self.n_ll
         self.md_config.num_others, self.md_config.add_others_navi = self.num_others, int(self.add_others_navi)
         self.md_config.random_agent_model = int(bool(cfg["random_agent_model"]))
+        self.md_config.agent_idm = int(cfg["agent_policy"] == "IDMPolicy")
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
@@ -411,7 +413,13 @@ class BatchedEngine:
                                               self._stream()), "md_line_detector")
 
     def step(self, actions):
-        """actions: tensor [E, A, 2] (or [E, 2] when A == 1), float32, on the engine's device."""
+        """actions: tensor [E, A, 2] (or [E, 2] when A == 1), float32, on the engine's device.  With agent_policy =
+        IDMPolicy the agents drive themselves: `actions` is ignored (None is fine), as the reference's IDMPolicy ignores
+        what env.step() is given."""
+        if self.k.agent_idm:
+            self.s.agent_action = None
+            self.step_raw()
+            return
         a = actions
         if a.dim() == 2:
             a = a.unsqueeze(1)

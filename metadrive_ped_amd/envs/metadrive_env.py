@@ -112,6 +112,10 @@ class BatchedMetaDriveEnv:
             raise RuntimeError("call reset() before step()")
         torch = self.engine.torch
         a = actions
+        if self.config["agent_policy"] == "IDMPolicy":     # the agents drive themselves; `actions` is ignored
+            self.engine.step(None)
+            fl = self.engine.flags[:, 0]
+            return self._obs(), self.engine.reward[:, 0], (fl & abi.FL_TERMINATED) != 0, (fl & abi.FL_TRUNCATED) != 0, self._info()
         if self.config["discrete_action"]:
             a = discrete_to_continuous(torch, self.config, a, (self.num_envs, ), self.engine.device)
         else:

@@ -124,9 +124,13 @@ class EnvScene:
             # classes (manager/agent_manager.py:41, component/vehicle/vehicle_type.py:269-281)
             agent_model = str(agent_mgr.np_random.choice(["s", "m", "l", "xl", "default"], p=[0.2] * 5))
         vehicle_seed = engine.generate_seed()
-        agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
+        policy_seed = agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
         self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
                             cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics)
+        if cfg.get("agent_policy") == "IDMPolicy":
+            # IDMPolicy.__init__ (policy/idm_policy.py:225-233): overtake_timer = randint(0, LANE_CHANGE_FREQ) from the
+            # policy's own stream
+            self.nav[0]["timer"] = int(get_np_random(policy_seed).randint(0, 50))
 
         # ---- traffic (trigger mode) ----
         density = cfg["traffic_density"]

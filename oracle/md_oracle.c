@@ -317,9 +317,10 @@ static void idm_env(const MdWorld* w, const MdState* s, const MdConfig* c, int e
     }
     /* Decisions use the state at the start of the step for every vehicle: actions are written to
      * s->action, poses are not touched here, so slot order does not matter. */
-    for (int j = c->agents_per_env; j < c->cap; ++j) {
+    /* agent_policy = IDMPolicy: the agents take their action from the same policy (agent_manager.py:37-70) */
+    for (int j = c->agent_idm ? 0 : c->agents_per_env; j < c->cap; ++j) {
         const MdShape* o = &s->shape[base + j];
-        if (!drives(o->flags) || (o->flags & MD_F_AGENT)) continue;
+        if (!drives(o->flags) || ((o->flags & MD_F_AGENT) && !c->agent_idm)) continue;
         MdState v = md_env_view(s, c, e);
         md_idm_vehicle(w, &v, c, e, j);
     }
@@ -336,7 +337,7 @@ EXPORT int ref_idm(const MdWorld* w, const MdState* s, const MdConfig* c) {
 static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int e) {
     int base = e * c->cap;
     int just_reset = 0;
-    if (s->agent_action) /* this step's agent actions come from the caller's own buffer */
+    if (s->agent_action && !c->agent_idm) /* this step's agent actions come from the caller's own buffer */
         for (int a = 0; a < c->agents_per_env; ++a) {
             s->action[2 * (base + a)] = s->agent_action[2 * (e * c->agents_per_env + a)];
             s->action[2 * (base + a) + 1] = s->agent_action[2 * (e * c->agents_per_env + a) + 1];
@@ -376,7 +377,9 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
      * end of step t leaves (traffic_manager.before_step runs before anything moves), so taking the decision at
      * the end of step t gives the same trajectories; the HIP kernel uses that to overlap it with the agent's
      * observation.  Multi-agent envs keep the reference order (respawns at the start of a step come first). */
-    const int plan_ahead = !c->is_multi_agent;
+    /* With IDM-driven agents the reference order is kept as well: the observation reports the action applied in THIS
+     * step, which planning ahead would overwrite with the next one before the observation is assembled. */
+    const int plan_ahead = !c->is_multi_agent && !c->agent_idm;
     if (!just_reset) {
         if (!plan_ahead) idm_env(w, s, c, e);
         MdState v = md_env_view(s, c, e);
@@ -482,12 +485,14 @@ EXPORT int ref_obb_obb(const MdShape* a, const MdShape* b) {
     return md_obb_obb(a->cx, a->cy, a->c, a->s, a->hl, a->hw, b->cx, b->cy, b->c, b->s, b->hl, b->hw);
 }
 EXPORT int ref_obb_quad(const MdShape* a, const float* q) { return md_obb_quad(a->cx, a->cy, a->c, a->s, a->hl, a->hw, q); }
+/* st5 = x, y, psi, v, yaw increment per sub-step carried in from the step before */
 EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, float dt, int n) {
     MdBicycle b;
-    md_bicycle_prepare(steer, thr, P, &b);
-    float cp, sp;
-    md_sincos(st4[2] + b.beta, &sp, &cp);
-    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], &cp, &sp, thr, &b, P, dt);
+    md_bicycle_prepare(steer, thr, st4[3], 2.2575f, 0.926f, dt, P, &b);
+    float c0, s0;
+    md_sincos(st4[2], &s0, &c0);
+    float cp = c0 * b.cb - s0 * b.sb, sp = s0 * b.cb + c0 * b.sb;
+    for (int i = 0; i < n; ++i) md_bicycle_substep(&st4[0], &st4[1], &st4[2], &st4[3], &cp, &sp, &st4[4], thr, &b, P, dt);
 }
 EXPORT void ref_probe_math(int op, const float* a, const float* b, float* out, int n) {
     for (int i = 0; i < n; ++i) out[i] = md_probe_eval(op, a[i], b[i]);

@@ -100,7 +100,7 @@ class OracleWorld:
 
     def step(self, actions=None, threads=1):
         self._held = None
-        if actions is not None:
+        if actions is not None and not self.k.agent_idm:
             # like BatchedEngine.step: hand the agents' actions over through MdState.agent_action
             self._held = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.host.E, self.host.A, 2))
             self.s.agent_action = self._held.ctypes.data

@@ -257,3 +257,21 @@ def test_env_spawn_object_pedestrian_known_answer_and_crash():
     with pytest.raises(ValueError):
         env.spawn_object("truck", [0.0, 0.0])
     env.close()
+
+
+def test_env_with_idm_agent_policy():
+    """BatchedMetaDriveEnv(agent_policy='IDMPolicy'): step() ignores its argument, the agents drive, episodes end by
+    arrival or horizon and restart."""
+    import torch
+    from metadrive_ped_amd.envs import BatchedMetaDriveEnv
+    E = 16
+    env = BatchedMetaDriveEnv(dict(num_envs=E, num_scenarios=E, map="SCS", traffic_density=0.1, agent_policy="IDMPolicy", horizon=1500))
+    obs, _ = env.reset()
+    arrived = torch.zeros(E, dtype=torch.bool, device="cuda")
+    bad = torch.zeros(E, dtype=torch.bool, device="cuda")
+    for t in range(1200):
+        obs, r, tm, tc, info = env.step(None if t % 2 else torch.ones(E, 2, device="cuda"))
+        arrived |= info["arrive_dest"]
+        bad |= info["out_of_road"] | info["crash_vehicle"]
+    assert int(arrived.sum()) >= E - 2 and int(bad.sum()) <= 2
+    env.close()

@@ -392,3 +392,31 @@ def test_spawned_participants_rollout_parity(variant):
         hits += int(((orc.state["flags"].reshape(E, -1)[:, :A] & 0x4) != 0).sum())
     assert_state_equal(eng.download_state(), orc.state, where=variant + " final")
     assert hits > 0, "no agent ever touched a participant: the scenario does not test crash_human"
+
+
+@pytest.mark.parametrize("mode", ["trigger", "hybrid"])
+def test_agent_policy_idm_rollout_parity(mode):
+    """agent_policy = IDMPolicy: the agents are planned by the traffic's policy in the reference's order (decide, move,
+    observe) -- fused step bit-exact with the oracle, with auto-resets, in trigger and hybrid traffic modes."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    E = 32
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, traffic_density=0.2, traffic_mode=mode, agent_policy="IDMPolicy",
+                           horizon=250))
+    eng = BatchedEngine(cfg)
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="idm agent reset")
+    arrived = 0
+    for t in range(400):
+        eng.step(None)
+        orc.step(None)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="idm agent %s step %d" % (mode, t))
+        arrived += int(((orc.state["flags"].reshape(E, -1)[:, 0] & 0x40) != 0).sum())
+    assert_state_equal(eng.download_state(), orc.state, where="idm agent final")
+    sp = orc.state["dyn"]["speed"].reshape(E, -1)[:, 0]
+    assert (sp > 1.0).sum() > E // 2, "the agents are not driving"

@@ -438,19 +438,28 @@ def test_sidewalk_and_line_contacts_with_hard_left():
 
 def test_bicycle_substep_rotation_matches_exact_trigonometry():
     """The integrator carries (cos, sin) of the travel direction and rotates it per sub-step with a short series
-    (include/md_geom.h: md_bicycle_substep); against float64 with exact sin / cos the pose after a 0.1 s step
-    differs by less than 1e-5 m / 1e-6 rad even at full lock and top speed."""
+    (include/md_geom.h: md_bicycle_substep); against a float64 restatement of the same model (grip-limited slip angle,
+    yaw rate with grip-limited angular acceleration) with exact sin / cos the pose after a 0.1 s step differs by less
+    than 2e-5 m / 2e-6 rad even at full lock and top speed."""
     lib = ob.load()
     P = np.zeros(1, dtype=abi.PARAM_DT)
     P["max_steer"], P["accel_gain"], P["brake_gain"], P["roll_decel"] = math.radians(40.0), 3.0, 5.0, 0.3
     P["max_speed_kmh"], P["lf"], P["lr"], P["fric_decel"] = 80.0, 1.05, 1.42, 8.8
+    hl, hw = 2.2575, 0.926                                   # ref_bicycle's box (the default car)
+    slew = 8.8 * 1.05 * 1.5 / (hl * hl + hw * hw) * 0.02 * 0.02
     rng = np.random.RandomState(0)
+    capped = slewed = 0
     for _ in range(200):
         steer, thr = float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))
-        st = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-3.1, 3.1), rng.uniform(0, 22)], np.float32)
-        x, y, psi, v = [float(t) for t in st]
+        st = np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-3.1, 3.1), rng.uniform(0, 22),
+                       rng.uniform(-0.01, 0.01)], np.float32)
+        x, y, psi, v, yaw = [float(t) for t in st]
         lib.ref_bicycle(st.ctypes.data, steer, thr, P.ctypes.data, 0.02, 5)
         beta = math.atan(1.42 / (1.05 + 1.42) * math.tan(steer * math.radians(40.0)))
+        grip = 8.8 * 1.42 / max(v * v, 1e-3)            # tyre grip bounds v^2 sin(beta) / lr by wheel_friction * g
+        capped += abs(math.sin(beta)) > grip
+        beta = math.copysign(math.asin(min(abs(math.sin(beta)), grip)), beta)
+        th = psi + beta                                 # travel direction
         for k in range(5):
             acc = 3.0 * thr if (thr > 0 and not abs(v) * 3.6 > 80.0) else 0.0
             dec = 0.0 if acc > 0 or (thr > 0 and not abs(v) * 3.6 > 80.0) else (0.3 if thr >= 0 else min(-thr * 5.0, 8.8))
@@ -458,10 +467,84 @@ def test_bicycle_substep_rotation_matches_exact_trigonometry():
             if vn > 0:
                 vn = max(vn - dec * 0.02, 0.0)
             vm = 0.5 * (v + vn)
-            x += vm * math.cos(psi + beta) * 0.02
-            y += vm * math.sin(psi + beta) * 0.02
-            psi += vm * math.sin(beta) / 1.42 * 0.02
+            x += vm * math.cos(th) * 0.02
+            y += vm * math.sin(th) * 0.02
+            want = vm * math.sin(beta) / 1.42 * 0.02
+            slewed += abs(want - yaw) > slew
+            d = yaw + min(max(want - yaw, -slew), slew)
+            d = min(max(d, -abs(vm) * 0.5 / 1.42 * 0.02), abs(vm) * 0.5 / 1.42 * 0.02)
+            yaw = d
+            psi += d
+            th += d
             v = vn
         psi = (psi + math.pi) % (2 * math.pi) - math.pi
         assert abs(st[0] - x) < 2e-5 and abs(st[1] - y) < 2e-5, (st, x, y)
         assert abs(((st[2] - psi) + math.pi) % (2 * math.pi) - math.pi) < 2e-6
+        assert abs(st[4] - yaw) < 1e-7
+    assert 40 < capped < 180 and slewed > 100       # every regime occurs: free / grip-limited slip, free / slewing yaw
+
+
+def test_traffic_steering_settles():
+    """The reference's PID steering (PID_controller.py; heading gains 1.7 / 0.01 / 3.5 per step) on this repo's vehicle
+    model: traffic at its cruise speed holds its lane with small steering commands.  On a purely kinematic bicycle
+    (instant yaw response, no tyre grip limit) the same controller limit-cycles between about +-0.5 of full lock at the
+    step rate -- more than a quarter of all steps flipped sign at |steer| > 0.5."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 8
+    h = HostScene(make_config(dict(num_envs=E, num_scenarios=E, map="SCS", traffic_density=0.2, traffic_mode="respawn",
+                                   horizon=1500, auto_reset=False)))
+    o = ob.OracleWorld(h)
+    o.reset()
+    st, sp = [], []
+    for t in range(300):
+        o.step(np.zeros((E, 1, 2), np.float32))
+        d = o.state["dyn"].reshape(E, -1)
+        st.append(d["steering"][:, 1:8].copy())
+        sp.append(d["speed"][:, 1:8].copy())
+    st, sp = np.stack(st), np.stack(sp)
+    assert (sp[-1] > 7.0).sum() >= 10                            # plenty of vehicles at cruise speed
+    flips = (np.sign(st[1:]) != np.sign(st[:-1])) & (np.abs(st[1:]) > 0.5) & (np.abs(st[:-1]) > 0.5)
+    assert flips.mean() < 0.002
+    cruising = sp[-100:] > 7.0
+    jitter = np.abs(np.diff(st[-101:], axis=0))[cruising]
+    assert np.percentile(jitter, 90) < 0.1                       # step-to-step steering change of cruising traffic
+
+
+def test_agent_policy_idm_drives_the_agent_to_its_destination():
+    """agent_policy = IDMPolicy (envs/base_env.py:53, manager/agent_manager.py:37-70; used throughout the reference's
+    export / randomness tests): the agent is planned by the traffic's IDM + PID policy.  Whatever env.step() is given
+    is ignored; the agent follows its route, keeps to the lanes, does not run into the traffic ahead and arrives."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 6
+    cfg = make_config(dict(num_envs=E, num_scenarios=E, start_seed=300, map="SCS", traffic_density=0.1, agent_policy="IDMPolicy",
+                           horizon=2000, auto_reset=False))
+    assert cfg["agent_policy"] == "IDMPolicy"
+    h = HostScene(cfg)
+    assert h.md_config.agent_idm == 1
+    o = ob.OracleWorld(h)
+    o.reset()
+    junk = np.tile(np.array([1.0, -1.0], np.float32), (E, 1, 1))      # full right lock + full brake: must be ignored
+    arrived = np.zeros(E, bool)
+    crashed = np.zeros(E, bool)
+    top = np.zeros(E, np.float32)
+    for t in range(1500):
+        o.step(junk)
+        fl = o.state["flags"].reshape(E, -1)[:, 0]
+        crashed |= ((fl & (abi.FL_CRASH_VEHICLE | abi.FL_OUT_OF_ROAD | abi.FL_CRASH_SIDEWALK)) != 0) & ~arrived
+        arrived |= ((fl & abi.FL_ARRIVE_DEST) != 0) & ~crashed     # (no auto-reset: afterwards the car just drives on)
+        top = np.maximum(top, o.state["dyn"]["speed"].reshape(E, -1)[:, 0])
+        if (arrived | crashed).all():
+            break
+    assert arrived.sum() >= E - 1 and crashed.sum() <= 1, (arrived, crashed)
+    assert (top > 6.0).all() and (top < 30.0 / 3.6 + 1.5).all()       # cruises near NORMAL_SPEED = 30 km/h, never beyond
+    # the action the observation reports is the one the policy applied in this step, not the junk
+    act = o.state["action"].reshape(E, -1, 2)[:, 0]
+    assert not np.allclose(act, junk[:, 0])
+    with pytest.raises(NotImplementedError):
+        make_config(dict(agent_policy="ReplayEgoCarPolicy"))
+
+    class IDMPolicy:            # the reference passes the class itself
+        pass
+    assert make_config(dict(agent_policy=IDMPolicy))["agent_policy"] == "IDMPolicy"
