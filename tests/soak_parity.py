@@ -31,6 +31,7 @@ def main():
                      random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600), wheel_friction=(0.1, 2.5),
                                           max_steering=(10, 80), mass=(300, 3000))),
         walkers=dict(mover_capacity=40, traffic_density=0.15),   # + a pedestrian and a cyclist spawned every 400 steps
+        idm_agent=dict(agent_policy="IDMPolicy", traffic_density=0.15),
     )
     for name, extra in configs.items():
         cfg = make_config(dict(dict(num_envs=E, num_scenarios=E, horizon=1000), **extra))
