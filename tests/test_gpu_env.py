@@ -275,3 +275,48 @@ def test_env_with_idm_agent_policy():
         bad |= info["out_of_road"] | info["crash_vehicle"]
     assert int(arrived.sum()) >= E - 2 and int(bad.sum()) <= 2
     env.close()
+
+
+def test_step_is_capturable_in_a_hip_graph():
+    """A closed rollout loop -- policy ops on the observation, then the engine's step -- captured once with
+    torch.cuda.graph and replayed gives the state of the same loop run eagerly, bit for bit: md_step allocates nothing,
+    synchronises nothing and touches only persistent buffers (tools/graph_probe.py times it)."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, K = 64, 8
+
+    def make():
+        eng = BatchedEngine(make_config(dict(num_envs=E, num_scenarios=E, traffic_density=0.2, horizon=300)))
+        eng.reset()
+        return eng, torch.zeros(E, 1, 2, device="cuda")
+
+    def drive(eng, act):
+        ob_ = eng.obs[:, 0, :]
+        act[:, 0, 0] = (4.0 * (ob_[:, 2] - 0.5) + 2.0 * (ob_[:, 8] - 0.5)).clamp_(-1.0, 1.0)
+        act[:, 0, 1] = (ob_[:, 3] < 0.35).to(torch.float32) * 0.5
+        eng.step(act)
+
+    e1, a1 = make()
+    e2, a2 = make()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            drive(e1, a1)
+            drive(e2, a2)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        for _ in range(K):
+            drive(e2, a2)
+    torch.cuda.synchronize()
+    for _ in range(30):                 # 240 steps: auto-resets included
+        for _ in range(K):
+            drive(e1, a1)
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.obs, e2.obs) and torch.equal(e1.reward, e2.reward)
+    for k in ("shape", "dyn", "nav", "flags"):
+        assert torch.equal(e1.state_dev[k], e2.state_dev[k]), k
