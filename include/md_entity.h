@@ -164,7 +164,7 @@ MD_HD void md_integrate_mover(const MdState* s, const MdConfig* c, int n) {
     d->throttle = thr;
     float x = sh->cx, y = sh->cy, psi = d->heading, v = d->speed;
     MdBicycle bike;
-    md_bicycle_prepare(steer, thr, v, sh->hl, sh->hw, c->dt, &s->param[n], &bike);
+    md_bicycle_prepare(steer, thr, v, sh->hl, sh->hw, c->dt, c->enable_reverse && (sh->flags & MD_F_AGENT), &s->param[n], &bike);
     float c0, s0;
     md_sincos(psi, &s0, &c0);
     float cp = c0 * bike.cb - s0 * bike.sb, sp = s0 * bike.cb + c0 * bike.sb; /* travel direction psi + beta */

@@ -273,7 +273,8 @@ MD_HD int md_lane_is_previous_of(const MdLane* A, const MdLane* B) {
  * reference's own (dead) stand-ins component/vehicle_model/kinematics.py:148-158 and
  * bicycle_model.py:17-51:  beta = atan(lr/(lf+lr) tan(delta)), pdot = v (cos,sin)(psi+beta),
  * psidot = v sin(beta)/lr.  Longitudinal: engine accel while throttle>=0 and speed below max,
- * constant idle-brake drag, brake decel capped by tyre friction; no reverse (enable_reverse=False).
+ * constant idle-brake drag, brake decel capped by tyre friction; with enable_reverse a negative throttle is a negative
+ * engine force instead of the brake (agents only: the traffic's vehicle config keeps it off).
  * Lateral grip: a raycast-vehicle wheel cannot push sideways harder than frictionSlip x its load
  * (wheel_friction in the vehicle config, pg_space.py:226-272), i.e. the lateral acceleration v^2 sin(beta)/lr is
  * bounded by wheel_friction * g: beyond it the slip angle is cut back (the car understeers).  Without the bound a
@@ -293,15 +294,21 @@ typedef struct MdBicycle {
                        * wheel_friction g lf / (2 k^2), k^2 = (L^2 + W^2) / 12 the box's radius of gyration squared:
                        * the front axle cannot push harder than its grip, so the yaw rate builds up over a few steps */
     float yaw_cap;    /* |yaw rate| <= |v| yaw_cap: sin of the full-lock slip angle / lr     */
+    int rev;          /* reversing: the (negative) engine force applies whatever the speed   */
 } MdBicycle;
 
 /* Everything that depends on the action and the speed at the start of the step (constant over the decision_repeat
  * sub-steps), except the engine cut-off which looks at the current speed (base_vehicle.py:474). */
-MD_HD void md_bicycle_prepare(float steer, float throttle, float speed, float hl, float hw, float dt, const MdParam* P,
-                              MdBicycle* b) {
+MD_HD void md_bicycle_prepare(float steer, float throttle, float speed, float hl, float hw, float dt, int reverse,
+                              const MdParam* P, MdBicycle* b) {
     b->acc = (throttle > 0.0f) ? P->accel_gain * throttle : 0.0f;
+    b->rev = 0;
     if (throttle >= 0.0f) b->dec = P->roll_decel; /* setBrake(2.0): idle drag when the engine is idle / cut */
-    else b->dec = md_min(-throttle * P->brake_gain, P->fric_decel);
+    else if (reverse) { /* enable_reverse: negative engine force, brake released (base_vehicle.py:479-481) */
+        b->acc = P->accel_gain * throttle;
+        b->dec = 0.0f;
+        b->rev = 1;
+    } else b->dec = md_min(-throttle * P->brake_gain, P->fric_decel);
     float delta = steer * P->max_steer;
     float sd, cd;
     md_sincos(delta, &sd, &cd);
@@ -331,7 +338,7 @@ MD_HD void md_bicycle_substep(float* x, float* y, float* psi, float* v, float* c
     float vv = *v;
     float speed_kmh = md_fabs(vv) * 3.6f;
     float acc = 0.0f, dec = 0.0f;
-    if (throttle > 0.0f && !(speed_kmh > P->max_speed_kmh)) {
+    if (b->rev || (throttle > 0.0f && !(speed_kmh > P->max_speed_kmh))) {
         acc = b->acc; /* engine force on 4 wheels; Bullet applies no brake impulse then */
     } else {
         dec = b->dec;

@@ -312,6 +312,8 @@ typedef struct MdConfig {
     int32_t agent_idm;         /* 1: config agent_policy = IDMPolicy (envs/base_env.py:53, manager/agent_manager.py:37-70): the
                                 * agents are driven by the IDM / PID policy of the traffic; MdState.agent_action is not read.
                                 * Single-agent envs only. */
+    int32_t enable_reverse;    /* vehicle_config.enable_reverse: an agent's negative throttle drives it backwards instead of
+                                * braking (base_vehicle.py:476-484) */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

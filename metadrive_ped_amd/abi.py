@@ -117,6 +117,7 @@ class MdConfig(C.Structure):
         ("track_len", C.c_int32),
         ("random_agent_model", C.c_int32),
         ("agent_idm", C.c_int32),
+        ("enable_reverse", C.c_int32),
     ]
 
 

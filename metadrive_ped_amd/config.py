@@ -108,7 +108,36 @@ BATCH_DEFAULT_CONFIG = dict(
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
 )
 
-_OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False)
+# Keys of the reference's BASE_DEFAULT_CONFIG (envs/base_env.py:32-266) that only concern rendering, cameras, the GUI,
+# debugging displays or asset handling: nothing on this path reads them, so any value is accepted and kept.
+COSMETIC_DEFAULT_CONFIG = dict(
+    controller="keyboard", norm_pixel=True, stack_size=3, use_chase_camera_follow_lane=False, camera_height=2.2, camera_dist=7.5,
+    camera_pitch=None, camera_smooth=True, camera_smooth_buffer_size=20, camera_fov=65, prefer_track_agent=None,
+    top_down_camera_initial_x=0, top_down_camera_initial_y=0, top_down_camera_initial_z=200, window_size=(1200, 900),
+    image_on_cuda=False, _render_mode="none", force_render_fps=None, force_destroy=False, num_buffering_objects=200,
+    render_pipeline=False, daytime="19:00", shadow_range=50, multi_thread_render=True, multi_thread_render_mode="Cull",
+    preload_models=True, disable_model_compression=True, cull_lanes_outside_map=False, drivable_area_extension=7,
+    height_scale=50, use_mesh_terrain=False, full_size_mesh=True, show_crosswalk=True, show_sidewalk=True, pstats=False,
+    debug=False, debug_panda3d=False, debug_physics_world=False, debug_static_world=False, show_coordinates=False,
+    show_fps=True, show_logo=True, show_mouse=True, show_skybox=True, show_terrain=True, show_interface=True,
+    show_policy_mark=False, show_interface_navi_mark=True, interface_panel=["dashboard"], force_reuse_object_name=False,
+    traffic_vehicle_config=dict(show_navi_mark=False, show_dest_mark=False, enable_reverse=False, show_lidar=False,
+                                show_lane_line_detector=False, show_side_detector=False),
+)
+COSMETIC_VEHICLE_CONFIG = dict(show_navi_mark=True, show_dest_mark=False, show_line_to_dest=False, show_line_to_navi_mark=False,
+                               use_special_color=False, image_source="rgb_camera", overtake_stat=False, random_color=False,
+                               top_down_width=None, top_down_length=None, show_lidar=False, show_side_detector=False,
+                               show_lane_line_detector=False)
+
+# Behavioural keys of subsystems that are not built: accepted at the reference's default, rejected loudly otherwise.
+_OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False, manual_control=False, agent_observation=None,
+                 sensors=None, record_episode=False, replay_episode=None, only_reset_when_replay=False, use_AI_protector=False,
+                 save_level=0.5)
+_OFF_ONLY_VEHICLE = dict(no_wheel_friction=False, navigation_module=None, spawn_position_heading=None, spawn_velocity=None,
+                         spawn_velocity_car_frame=False, width=None, length=None, height=None, mass=None, light=False)
+_OFF_HINT = dict(record_episode="use env.start_recording() / stop_recording() / export_scenarios()",
+                 replay_episode="use traffic_mode='replay' with env.load_tracks()",
+                 mass="use BatchedVaryingDynamicsEnv / random_dynamics")
 
 
 def _merge(dst, src, path=""):
@@ -120,7 +149,8 @@ def _merge(dst, src, path=""):
             _merge(dst[k], v, path + k + ".")
         else:
             old = dst[k]
-            if old is not None and v is not None and not isinstance(old, dict):
+            cosmetic = k in COSMETIC_DEFAULT_CONFIG or k in COSMETIC_VEHICLE_CONFIG
+            if old is not None and v is not None and not isinstance(old, dict) and not cosmetic:
                 # utils/config.py:241-250: int <-> float are interchangeable
                 ok = isinstance(v, type(old)) or (isinstance(old, float) and isinstance(v, int)) or \
                     (isinstance(old, int) and not isinstance(old, bool) and isinstance(v, float)) or \
@@ -135,11 +165,22 @@ def make_config(user=None):
     cfg = copy.deepcopy(BASE_DEFAULT_CONFIG)
     cfg.update(copy.deepcopy(METADRIVE_DEFAULT_CONFIG))
     cfg.update(copy.deepcopy(BATCH_DEFAULT_CONFIG))
-    _merge(cfg, dict(user or {}))
+    cfg.update(copy.deepcopy(COSMETIC_DEFAULT_CONFIG))
+    cfg["vehicle_config"].update(copy.deepcopy(COSMETIC_VEHICLE_CONFIG))
     for k, off in _OFF_ONLY.items():
-        if cfg[k] != off:
-            raise NotImplementedError("config['{}']={!r}: this option lies outside the batched step() path built so far "
-                                      "(only {!r} is accepted)".format(k, cfg[k], off))
+        cfg.setdefault(k, off)
+    for k, off in _OFF_ONLY_VEHICLE.items():
+        cfg["vehicle_config"].setdefault(k, off)
+    user = dict(user or {})
+    if isinstance(user.get("sensors"), dict) and not user["sensors"]:
+        user["sensors"] = None                                  # an empty sensor table is the default
+    _merge(cfg, user)
+    for where, table in ((cfg, _OFF_ONLY), (cfg["vehicle_config"], _OFF_ONLY_VEHICLE)):
+        for k, off in table.items():
+            if where[k] != off:
+                raise NotImplementedError("config['{}']={!r}: this option lies outside the batched step() path built so far "
+                                          "(only {!r} is accepted){}".format(k, where[k], off,
+                                                                             "; " + _OFF_HINT[k] if k in _OFF_HINT else ""))
     # parse_map_config (component/map/pg_map.py:17-36): `map` shorthand fills map_config
     m = cfg["map"]
     if isinstance(m, int):

@@ -488,7 +488,7 @@ EXPORT int ref_obb_quad(const MdShape* a, const float* q) { return md_obb_quad(a
 /* st5 = x, y, psi, v, yaw increment per sub-step carried in from the step before */
 EXPORT void ref_bicycle(float* st4, float steer, float thr, const MdParam* P, float dt, int n) {
     MdBicycle b;
-    md_bicycle_prepare(steer, thr, st4[3], 2.2575f, 0.926f, dt, P, &b);
+    md_bicycle_prepare(steer, thr, st4[3], 2.2575f, 0.926f, dt, 0, P, &b);
     float c0, s0;
     md_sincos(st4[2], &s0, &c0);
     float cp = c0 * b.cb - s0 * b.sb, sp = s0 * b.cb + c0 * b.sb;

@@ -248,6 +248,8 @@ def test_random_lanes_and_inverse_traffic_rollout_parity():
     ("beams_100_short_range", dict(num_envs=4, num_scenarios=4, vehicle_config=dict(lidar=dict(num_lasers=100, distance=12.5))), 60),
     # explicit capacity smaller than the auto choice would be; no traffic at all; long straight-only map
     ("no_traffic_tight_cap", dict(num_envs=8, num_scenarios=8, traffic_density=0.0, mover_capacity=8, map="SSS"), 150),
+    # enable_reverse: a negative throttle is a negative engine force (the scripted actions brake / reverse half the time)
+    ("reverse", dict(num_envs=16, num_scenarios=16, traffic_density=0.1, vehicle_config=dict(enable_reverse=True)), 200),
     # VaryingDynamicsEnv: extreme agent dynamics (80 deg steering, 300 kg / 3000 N, friction 0.1 ...)
     ("varying_dynamics", dict(num_envs=24, num_scenarios=24, vehicle_config=dict(vehicle_model="varying_dynamics"),
                               random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600),

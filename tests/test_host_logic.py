@@ -253,3 +253,27 @@ def test_sub_batches_hold_the_same_environments_as_the_whole_batch():
             assert h.state[name].tobytes() == whole.state[name][k * n:(k + 1) * n].tobytes(), name
     with pytest.raises(ValueError):
         SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=5)
+
+
+def test_reference_test_configs_are_accepted_verbatim():
+    """Configs copied from the reference's own tests (test_pedestrian.py:8-36, test_traffic_light.py:8-22,
+    test_marl_infinite_agents.py:5-15): rendering / debug / camera keys are inert here and accepted, behavioural keys of
+    subsystems that are not built are rejected loudly, unknown keys raise KeyError like utils/config.py."""
+    from metadrive_ped_amd.config import make_config
+    ped = {"num_scenarios": 1, "traffic_density": 0., "traffic_mode": "hybrid", "start_seed": 22, "debug": False,
+           "manual_control": False, "use_render": False, "decision_repeat": 5, "need_inverse_traffic": False, "norm_pixel": True,
+           "map": "X", "random_traffic": False, "random_lane_width": True, "driving_reward": 1.0, "force_destroy": False,
+           "window_size": (2400, 1600), "vehicle_config": {"enable_reverse": False}}
+    c = make_config(ped)
+    assert c["window_size"] == (2400, 1600) and c["traffic_mode"] == "hybrid" and c["random_lane_width"] is True
+    light = {"num_scenarios": 1, "traffic_density": 0., "traffic_mode": "hybrid", "manual_control": False, "use_render": False,
+             "debug": False, "debug_static_world": False, "map": "X", "window_size": (1200, 800),
+             "vehicle_config": {"enable_reverse": True, "show_dest_mark": True}}
+    c = make_config(light)
+    assert c["vehicle_config"]["enable_reverse"] is True and c["vehicle_config"]["show_dest_mark"] is True
+    for bad in (dict(manual_control=True), dict(record_episode=True), dict(use_render=True), dict(image_observation=True),
+                dict(vehicle_config=dict(spawn_velocity=[5, 0])), dict(vehicle_config=dict(mass=900)), dict(replay_episode="x.pkl")):
+        with pytest.raises(NotImplementedError):
+            make_config(bad)
+    with pytest.raises(KeyError):
+        make_config(dict(vehicle_config=dict(warp_drive=True)))

@@ -548,3 +548,33 @@ def test_agent_policy_idm_drives_the_agent_to_its_destination():
     class IDMPolicy:            # the reference passes the class itself
         pass
     assert make_config(dict(agent_policy=IDMPolicy))["agent_policy"] == "IDMPolicy"
+
+
+def test_enable_reverse_drives_the_agent_backwards():
+    """vehicle_config.enable_reverse (base_vehicle.py:476-484): with it a negative throttle is a negative engine force
+    (brake released), so the agent slows down and then backs up; without it the same action only brakes."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 2
+    out = {}
+    for rev in (False, True):
+        h = HostScene(make_config(dict(num_envs=E, num_scenarios=E, map="SSS", traffic_density=0.0, auto_reset=False,
+                                       horizon=1000, vehicle_config=dict(enable_reverse=rev))))
+        assert h.md_config.enable_reverse == int(rev)
+        o = ob.OracleWorld(h)
+        o.reset()
+        for _ in range(30):
+            o.step(np.tile(np.array([0.0, 1.0], np.float32), (E, 1, 1)))       # get rolling
+        v0 = o.state["dyn"]["speed"].reshape(E, -1)[:, 0].copy()
+        x0 = o.state["shape"]["cx"].reshape(E, -1)[:, 0].copy()
+        speeds = []
+        for _ in range(80):
+            o.step(np.tile(np.array([0.0, -1.0], np.float32), (E, 1, 1)))
+            speeds.append(o.state["dyn"]["speed"].reshape(E, -1)[:, 0].copy())
+        out[rev] = (v0, x0, np.stack(speeds), o.state["shape"]["cx"].reshape(E, -1)[:, 0].copy())
+    v0, x0, sp, x1 = out[False]
+    assert (v0 > 5.0).all() and (sp[-1] == 0.0).all() and (sp >= 0.0).all() and (x1 > x0).all()    # brakes to a stop
+    v0, x0, sp_r, x1_r = out[True]
+    assert (sp_r[-1] < -3.0).all()                                   # ... backs up
+    assert (sp_r[5] > sp[5]).all()                                   # and sheds speed more slowly than the brake does
+    assert (x1_r < out[False][3]).all()
