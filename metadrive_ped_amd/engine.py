@@ -111,6 +111,8 @@ class HostScene:
                          agent_vehicle_model=cfg["vehicle_config"]["vehicle_model"],
                          spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
+                         spawn_velocity=cfg["vehicle_config"]["spawn_velocity"],
+                         spawn_velocity_car_frame=cfg["vehicle_config"]["spawn_velocity_car_frame"],
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],
                          accident_prob=cfg["accident_prob"], static_traffic_object=cfg["static_traffic_object"],
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],

@@ -127,6 +127,14 @@ class EnvScene:
         policy_seed = agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
         self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
                             cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics)
+        if cfg.get("spawn_velocity") is not None:
+            # BaseVehicle.reset -> set_velocity(spawn_velocity, in_local_frame=spawn_velocity_car_frame); the vehicle model
+            # here carries a signed speed along the heading, so the component along the heading is what starts the episode
+            vx, vy = float(cfg["spawn_velocity"][0]), float(cfg["spawn_velocity"][1])
+            if cfg.get("spawn_velocity_car_frame"):
+                self.dyn[0]["speed"] = vx
+            else:
+                self.dyn[0]["speed"] = vx * float(self.shape[0]["c"]) + vy * float(self.shape[0]["s"])
         if cfg.get("agent_policy") == "IDMPolicy":
             # IDMPolicy.__init__ (policy/idm_policy.py:225-233): overtake_timer = randint(0, LANE_CHANGE_FREQ) from the
             # policy's own stream

@@ -272,8 +272,29 @@ def test_reference_test_configs_are_accepted_verbatim():
     c = make_config(light)
     assert c["vehicle_config"]["enable_reverse"] is True and c["vehicle_config"]["show_dest_mark"] is True
     for bad in (dict(manual_control=True), dict(record_episode=True), dict(use_render=True), dict(image_observation=True),
-                dict(vehicle_config=dict(spawn_velocity=[5, 0])), dict(vehicle_config=dict(mass=900)), dict(replay_episode="x.pkl")):
+                dict(vehicle_config=dict(spawn_position_heading=((0, 0), 0))), dict(vehicle_config=dict(mass=900)), dict(replay_episode="x.pkl")):
         with pytest.raises(NotImplementedError):
             make_config(bad)
     with pytest.raises(KeyError):
         make_config(dict(vehicle_config=dict(warp_drive=True)))
+
+
+def test_spawn_velocity_starts_the_episode_rolling():
+    """vehicle_config.spawn_velocity (base_vehicle.py:371-372): the agent leaves the reset with that velocity (its component
+    along the heading; world axes, or the car's own with spawn_velocity_car_frame) -- also after every auto-reset."""
+    import oracle_binding as ob
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 3
+    h = HostScene(make_config(dict(num_envs=E, num_scenarios=E, traffic_density=0.0, horizon=20,
+                                   vehicle_config=dict(spawn_velocity=[6.0, 0.0]))))
+    o = ob.OracleWorld(h)
+    o.reset()
+    x0 = o.state["shape"]["cx"].reshape(E, -1)[:, 0].copy()
+    assert np.allclose(o.state["dyn"]["speed"].reshape(E, -1)[:, 0], 6.0)
+    o.step(np.zeros((E, 1, 2), np.float32))
+    assert (o.state["shape"]["cx"].reshape(E, -1)[:, 0] - x0 > 0.5).all()          # 0.1 s at ~6 m/s
+    for _ in range(21):                                                             # horizon 20 -> truncation -> auto-reset
+        o.step(np.zeros((E, 1, 2), np.float32))
+    assert (o.state["nav"]["steps"].reshape(E, -1)[:, 0] <= 2).all()
+    assert (o.state["dyn"]["speed"].reshape(E, -1)[:, 0] > 5.0).all()
