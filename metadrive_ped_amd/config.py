@@ -40,6 +40,7 @@ BASE_DEFAULT_CONFIG = dict(
         destination=None,
         spawn_longitude=5.0,
         spawn_lateral=0.0,
+        width=None, length=None, height=None, mass=None,   # read by vehicle_model="varying_dynamics" only (vehicle_type.py:168-187)
         spawn_velocity=None,             # [vx, vy] m/s at reset (base_vehicle.py:371-372); its component along the heading is kept
         spawn_velocity_car_frame=False,  # True: [forward, left] of the vehicle instead of world axes
         lidar=dict(num_lasers=240, distance=50, num_others=0, gaussian_noise=0.0, dropout_prob=0.0,
@@ -135,11 +136,9 @@ COSMETIC_VEHICLE_CONFIG = dict(show_navi_mark=True, show_dest_mark=False, show_l
 _OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False, manual_control=False, agent_observation=None,
                  sensors=None, record_episode=False, replay_episode=None, only_reset_when_replay=False, use_AI_protector=False,
                  save_level=0.5)
-_OFF_ONLY_VEHICLE = dict(no_wheel_friction=False, navigation_module=None, spawn_position_heading=None,
-                         width=None, length=None, height=None, mass=None, light=False)
+_OFF_ONLY_VEHICLE = dict(no_wheel_friction=False, navigation_module=None, spawn_position_heading=None, light=False)
 _OFF_HINT = dict(record_episode="use env.start_recording() / stop_recording() / export_scenarios()",
-                 replay_episode="use traffic_mode='replay' with env.load_tracks()",
-                 mass="use BatchedVaryingDynamicsEnv / random_dynamics")
+                 replay_episode="use traffic_mode='replay' with env.load_tracks()")
 
 
 def _merge(dst, src, path=""):

@@ -111,6 +111,7 @@ class HostScene:
                          agent_vehicle_model=cfg["vehicle_config"]["vehicle_model"],
                          spawn_longitude=cfg["vehicle_config"]["spawn_longitude"],
                          spawn_lateral=cfg["vehicle_config"]["spawn_lateral"],
+                         agent_size_mass={k: cfg["vehicle_config"][k] for k in ("width", "length", "height", "mass")},
                          spawn_velocity=cfg["vehicle_config"]["spawn_velocity"],
                          spawn_velocity_car_frame=cfg["vehicle_config"]["spawn_velocity_car_frame"],
                          traffic_density=cfg["traffic_density"], traffic_mode=cfg["traffic_mode"],

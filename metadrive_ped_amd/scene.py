@@ -125,8 +125,18 @@ class EnvScene:
             agent_model = str(agent_mgr.np_random.choice(["s", "m", "l", "xl", "default"], p=[0.2] * 5))
         vehicle_seed = engine.generate_seed()
         policy_seed = agent_mgr.generate_seed()  # policy seed (EnvInputPolicy does not use it)
+        size = cfg.get("agent_size_mass") or {}
+        if agent_model == "varying_dynamics" and size.get("mass") is not None:
+            # VaryingDynamicsVehicle.MASS / WIDTH / LENGTH come from its config when given (vehicle_type.py:168-187)
+            dynamics = dict(dynamics or {})
+            dynamics.setdefault("mass", size["mass"])
         self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
                             cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics)
+        if agent_model == "varying_dynamics":
+            if size.get("length") is not None:
+                self.shape[0]["hl"] = float(size["length"]) / 2
+            if size.get("width") is not None:
+                self.shape[0]["hw"] = float(size["width"]) / 2
         if cfg.get("spawn_velocity") is not None:
             # BaseVehicle.reset -> set_velocity(spawn_velocity, in_local_frame=spawn_velocity_car_frame); the vehicle model
             # here carries a signed speed along the heading, so the component along the heading is what starts the episode

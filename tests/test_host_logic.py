@@ -298,3 +298,22 @@ def test_spawn_velocity_starts_the_episode_rolling():
         o.step(np.zeros((E, 1, 2), np.float32))
     assert (o.state["nav"]["steps"].reshape(E, -1)[:, 0] <= 2).all()
     assert (o.state["dyn"]["speed"].reshape(E, -1)[:, 0] > 5.0).all()
+
+
+def test_varying_dynamics_vehicle_takes_size_and_mass_from_its_config():
+    """VaryingDynamicsVehicle.WIDTH / LENGTH / MASS (vehicle_type.py:168-187; tests/test_component/
+    test_varying_dynamics_vehicle.py): given in the vehicle config they replace the default car's; any other vehicle class
+    ignores them."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    for width in (1.852, 2, 3, 4):
+        for length in (4.515, 6, 9, 13):
+            h = HostScene(make_config(dict(num_envs=1, traffic_density=0.0, vehicle_config=dict(
+                vehicle_model="varying_dynamics", width=width, length=length, mass=2200))))
+            sh = h.state["shape0"][0]
+            assert abs(2 * sh["hw"] - width) < 1e-6 and abs(2 * sh["hl"] - length) < 1e-6
+            p = h.state["param"][0]
+            cfgv = h.scenes[h.seeds[0]].vehicle_cfgs[0]
+            assert abs(p["accel_gain"] - 4.0 * cfgv["max_engine_force"] / 2200) < 1e-5
+    h = HostScene(make_config(dict(num_envs=1, traffic_density=0.0, vehicle_config=dict(width=3, length=9, mass=2200))))
+    assert abs(2 * h.state["shape0"][0]["hl"] - 4.515) < 1e-6 and abs(2 * h.state["shape0"][0]["hw"] - 1.852) < 1e-6
