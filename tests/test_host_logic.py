@@ -272,7 +272,7 @@ def test_reference_test_configs_are_accepted_verbatim():
     c = make_config(light)
     assert c["vehicle_config"]["enable_reverse"] is True and c["vehicle_config"]["show_dest_mark"] is True
     for bad in (dict(manual_control=True), dict(record_episode=True), dict(use_render=True), dict(image_observation=True),
-                dict(vehicle_config=dict(spawn_position_heading=((0, 0), 0))), dict(vehicle_config=dict(mass=900)), dict(replay_episode="x.pkl")):
+                dict(vehicle_config=dict(spawn_position_heading=((0, 0), 0))), dict(vehicle_config=dict(light=True)), dict(replay_episode="x.pkl")):
         with pytest.raises(NotImplementedError):
             make_config(bad)
     with pytest.raises(KeyError):
