@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""How much of the fused step is map-data latency?  Same 4096 envs, same kernel, but the envs share 1 / 64 / 512 / 4096
+distinct maps: with few maps the lane / grid tables are L2-resident, with 4096 every workgroup reads cold lines."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    E = 4096
+    g = torch.Generator().manual_seed(0)
+    acts = torch.rand(64, E, 1, 2, generator=g) * 2 - 1
+    acts[..., 1] = acts[..., 1].abs() * 0.9 + 0.1
+    acts[..., 0] *= 0.25
+    acts = acts.cuda()
+    for S in (1, 8, 64, 512, 4096):
+        eng = BatchedEngine(make_config(dict(num_envs=E, num_scenarios=S, horizon=1000, mover_capacity=32)))
+        eng.reset()
+        for i in range(60):
+            eng.step(acts[i % 64])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(300):
+            eng.step(acts[i % 64])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 300
+        fl = eng.shape_f.view(torch.int32)[..., 6]
+        drv = (((fl & 0x10) != 0) & ((fl & 0x40) == 0) & ((fl & 0xF) == 1) & ((fl & 0x80) == 0)).sum().item() / E
+        print("distinct maps %5d: %.1f us per step (%.2f driving vehicles per env, max lanes %d)" %
+              (S, dt * 1e6, drv, int(eng.host.world.arrays["lane_off"][1:].max() if S == 1 else 0)), flush=True)
+        del eng
+
+
+if __name__ == "__main__":
+    main()
