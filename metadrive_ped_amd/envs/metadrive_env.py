@@ -161,6 +161,16 @@ class BatchedMetaDriveEnv:
         from metadrive_ped_amd.scenario_export import tracks_to_scenarios
         return tracks_to_scenarios(tracks, self.engine.host, envs)
 
+    def load_scenarios(self, scenarios):
+        """traffic_mode='replay' from scenario descriptions written by export_scenarios() (one per env, same scenario
+        seeds): ScenarioEnv-style replay of data recorded here."""
+        from metadrive_ped_amd.scenario_export import scenarios_to_tracks
+        self.lazy_init()
+        tracks = scenarios_to_tracks(scenarios, self.engine.host)
+        torch = self.engine.torch
+        self.load_tracks(dict(shape=torch.from_numpy(tracks["shape"].view(np.uint8).reshape(tracks["shape"].shape[0], -1)),
+                              dyn=torch.from_numpy(tracks["dyn"]), seeds=tracks["seeds"], cap=tracks["cap"]))
+
     def load_tracks(self, tracks):
         """For an env built with traffic_mode='replay': the traffic follows `tracks` (from stop_recording() of an env
         with the same scenarios) instead of reacting; call before reset()."""

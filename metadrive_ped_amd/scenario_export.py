@@ -191,3 +191,50 @@ def tracks_to_scenarios(tracks, host, envs=None):
             "map_features": feats_of_map[m],
         }))
     return out
+
+
+_KIND_OF_TYPE = {"VEHICLE": abi.KIND_VEHICLE, "TRAFFIC_BARRIER": abi.KIND_BARRIER, "PEDESTRIAN": abi.KIND_PEDESTRIAN,
+                 "CYCLIST": abi.KIND_CYCLIST}
+
+
+def scenarios_to_tracks(scenarios, host):
+    """The inverse of tracks_to_scenarios for scenario descriptions exported by it: -> tracks (BatchedEngine.set_tracks /
+    env.load_tracks layout) for a replay env built with the same scenario assignment (`host`: its HostScene).  One
+    scenario per env, in env order; every scenario must carry the seed of the env it is loaded into and as many frames
+    as the others.  This is the ScenarioEnv-style path for data recorded here: record -> export_scenarios() -> store ->
+    scenarios_to_tracks() -> traffic_mode='replay'.  (TRAFFIC_CONE covers both cones and warning tripods in the
+    reference's type system; the exporter keeps the exact kind in the track metadata.)"""
+    E, cap, A = host.E, host.cap, host.A
+    if len(scenarios) != E:
+        raise ValueError("need one scenario per env: got {} for {} envs".format(len(scenarios), E))
+    T = int(scenarios[0]["length"])
+    shape = np.zeros((T, E, cap), dtype=abi.SHAPE_DT)
+    shape["aux"] = -1
+    dyn = np.zeros((T, E, cap, 2), np.float32)
+    for e, sc in enumerate(scenarios):
+        if int(sc["length"]) != T:
+            raise ValueError("scenario {} has {} frames, the first one {}".format(sc["id"], sc["length"], T))
+        if int(sc["metadata"].get("seed", -1)) != int(host.seeds[e]):
+            raise ValueError("scenario {} was recorded on scenario seed {}, env {} runs seed {}".format(
+                sc["id"], sc["metadata"].get("seed"), e, host.seeds[e]))
+        for oid, tr in sc["tracks"].items():
+            md = tr["metadata"]
+            j = int(md["slot"]) if "slot" in md else int(str(oid).split("_")[0])
+            if not 0 <= j < cap:
+                raise ValueError("track {} of scenario {} names slot {}, the env has {}".format(oid, sc["id"], j, cap))
+            st = tr["state"]
+            v = np.asarray(st["valid"], bool)
+            kind = int(md["kind_code"]) if "kind_code" in md else _KIND_OF_TYPE.get(tr["type"], abi.KIND_CONE)
+            h = np.asarray(st["heading"], np.float32)
+            rec = shape[:, e, j]
+            rec["cx"][v], rec["cy"][v] = st["position"][v, 0], st["position"][v, 1]
+            rec["c"][v], rec["s"][v] = np.cos(h[v]), np.sin(h[v])
+            rec["hl"][v], rec["hw"][v] = np.asarray(st["length"])[v] / 2.0, np.asarray(st["width"])[v] / 2.0
+            flags = kind | abi.F_ALIVE | (abi.F_AGENT if j < A else 0)
+            if kind not in (abi.KIND_VEHICLE, abi.KIND_PEDESTRIAN, abi.KIND_CYCLIST):
+                flags |= abi.F_STATIC
+            rec["flags"][v] = flags
+            shape[:, e, j] = rec
+            dyn[v, e, j, 0] = h[v]
+            dyn[v, e, j, 1] = np.hypot(st["velocity"][v, 0], st["velocity"][v, 1])
+    return dict(shape=shape.reshape(T, E * cap), dyn=dyn.reshape(T, E * cap, 2), seeds=list(host.seeds), cap=cap)

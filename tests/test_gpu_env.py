@@ -172,6 +172,14 @@ def test_record_then_replay_traffic():
         for oid in a["tracks"]:
             for k, v in a["tracks"][oid]["state"].items():
                 assert v.tobytes() == b["tracks"][oid]["state"][k].tobytes(), (oid, k)
+    # scenario descriptions -> replay tracks gives the poses of the device recording back
+    rp_sd = BatchedMetaDriveEnv(dict(base, traffic_mode="replay", mover_capacity=rec.engine.cap))
+    rp_sd.load_scenarios(rec.export_scenarios(tracks))
+    back = rp_sd.engine._tracks["shape"].cpu().numpy().view(ob.abi.SHAPE_DT).reshape(T + 1, -1)
+    orig = tracks["shape"].cpu().numpy().view(ob.abi.SHAPE_DT).reshape(T + 1, -1)
+    on = (orig["flags"] & ob.abi.F_ALIVE) != 0
+    assert np.array_equal(back["cx"][on], orig["cx"][on]) and np.array_equal(back["cy"][on], orig["cy"][on])
+    rp_sd.close()
     rp = BatchedMetaDriveEnv(dict(base, traffic_mode="replay"))
     rp.load_tracks(tracks)
     rp.reset()

@@ -12,6 +12,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 from metadrive_ped_amd import abi
 
@@ -116,3 +117,49 @@ def test_a_refilled_slot_becomes_a_new_object():
     x = np.array([0, 1, 2, 0, 0, 50, 51, 90, 91], np.float32)
     assert _segments(valid, x, np.zeros_like(x)) == [(0, 3), (5, 7), (7, 9)]
     assert _segments(np.zeros(4, bool), x[:4], x[:4]) == []
+
+
+def test_exported_scenarios_load_back_as_replay_tracks():
+    """record -> export_scenarios -> scenarios_to_tracks -> traffic_mode='replay': the traffic of the replayed episode is
+    where the scenario descriptions say, frame by frame, and the agent driven by the recorded actions sees the recorded
+    observations (the replayed bodies are kinematic: same poses, same lidar)."""
+    import oracle_binding as ob
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.scenario_export import scenarios_to_tracks, tracks_to_scenarios
+    E, T = 3, 60
+    base = dict(num_envs=E, num_scenarios=E, start_seed=20, traffic_density=0.2, horizon=1000, auto_reset=False)
+    host = HostScene(make_config(dict(base)))
+    o = ob.OracleWorld(host)
+    o.reset()
+    acts = [np.tile(np.array([0.03 * math.sin(0.07 * t), 0.6], np.float32), (E, 1, 1)) for t in range(T)]
+    obs_rec = []
+    frames = dict(shape=np.zeros((T + 1, E * host.cap), abi.SHAPE_DT), dyn=np.zeros((T + 1, E * host.cap, 2), np.float32))
+    for k in range(T + 1):
+        if k:
+            o.step(acts[k - 1])
+            obs_rec.append(o.obs.copy())
+        frames["shape"][k] = o.state["shape"]
+        frames["dyn"][k, :, 0], frames["dyn"][k, :, 1] = o.state["dyn"]["heading"], o.state["dyn"]["speed"]
+    scs = tracks_to_scenarios(dict(frames, seeds=list(host.seeds), cap=host.cap), host)
+    rp_host = HostScene(make_config(dict(base, traffic_mode="replay", mover_capacity=host.cap)))
+    tracks = scenarios_to_tracks(scs, rp_host)
+    alive = (frames["shape"]["flags"] & abi.F_ALIVE) != 0
+    for f in ("cx", "cy", "hl", "hw"):
+        assert np.array_equal(tracks["shape"][f][alive], frames["shape"][f][alive]), f
+    assert np.array_equal(tracks["shape"]["flags"][alive] & abi.KIND_MASK, frames["shape"]["flags"][alive] & abi.KIND_MASK)
+    r = ob.OracleWorld(rp_host)
+    r.set_tracks(tracks["shape"], tracks["dyn"])
+    r.reset()
+    for t in range(T):
+        r.step(acts[t])
+        sh = r.state["shape"].reshape(E, -1)
+        want = frames["shape"][t + 1].reshape(E, -1)
+        on = (want["flags"][:, 1:] & abi.F_ALIVE) != 0
+        assert np.array_equal(sh["cx"][:, 1:][on], want["cx"][:, 1:][on]) and np.array_equal(sh["cy"][:, 1:][on], want["cy"][:, 1:][on])
+        assert np.abs(r.obs - obs_rec[t]).max() < 2e-3, t          # headings pass through float32 cos / sin once more
+    with pytest.raises(ValueError):
+        scenarios_to_tracks(scs[:2], rp_host)
+    bad = [dict(s, metadata=dict(s["metadata"], seed=999)) for s in scs]
+    with pytest.raises(ValueError):
+        scenarios_to_tracks(bad, rp_host)
