@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Random combinations of the config options (not collected by pytest: run by hand on the GPU box): for each draw a
+short rollout of HIP against the oracle, every state array compared.  Usage: python tests/fuzz_parity.py [n] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def draw(rng):
+    pick = lambda *xs: xs[int(rng.randint(len(xs)))]
+    cfg = dict(num_envs=int(pick(1, 5, 16, 33)), start_seed=int(rng.randint(0, 2000)), horizon=int(pick(40, 150, 1000)),
+               map=pick(1, 2, 3, 4, "SCS", "XT", "rRO", "yY", "CrX"), traffic_density=float(pick(0.0, 0.05, 0.1, 0.3)),
+               traffic_mode=pick("trigger", "trigger", "respawn", "hybrid"), accident_prob=float(pick(0.0, 0.0, 0.5, 1.0)),
+               random_lane_width=bool(rng.randint(2)), random_lane_num=bool(rng.randint(2)),
+               need_inverse_traffic=bool(rng.randint(2)), random_agent_model=bool(rng.randint(2)),
+               auto_reset=bool(rng.randint(4) > 0), crash_vehicle_done=bool(rng.randint(2)), crash_object_done=bool(rng.randint(2)),
+               out_of_route_done=bool(rng.randint(4) == 0), on_continuous_line_done=bool(rng.randint(2)),
+               use_lateral_reward=bool(rng.randint(2)), enable_idm_lane_change=bool(rng.randint(4) > 0),
+               agent_policy=pick("EnvInputPolicy", "EnvInputPolicy", "EnvInputPolicy", "IDMPolicy"))
+    cfg["num_scenarios"] = int(pick(1, cfg["num_envs"], max(1, cfg["num_envs"] // 2)))
+    vc = dict(enable_reverse=bool(rng.randint(3) == 0))
+    beams = int(pick(0, 30, 72, 240))
+    vc["lidar"] = dict(num_lasers=beams, distance=float(pick(20, 50)) if beams else 0, num_others=int(pick(0, 0, 2, 4)) if beams else 0,
+                       add_others_navi=bool(rng.randint(2)))
+    if rng.randint(3) == 0:
+        vc["side_detector"] = dict(num_lasers=int(pick(2, 8)), distance=50)
+    if rng.randint(3) == 0:
+        vc["lane_line_detector"] = dict(num_lasers=int(pick(2, 4)), distance=20)
+    if rng.randint(4) == 0:
+        vc["vehicle_model"] = "varying_dynamics"
+        cfg["random_agent_model"] = False
+        cfg["random_dynamics"] = dict(max_engine_force=(100, 3000), max_brake_force=(20, 600), wheel_friction=(0.1, 2.5),
+                                      max_steering=(10, 80), mass=(300, 3000))
+    if rng.randint(4) == 0:
+        vc["spawn_velocity"] = [float(rng.uniform(0, 15)), 0.0]
+    cfg["vehicle_config"] = vc
+    return cfg
+
+
+def main():
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd import participants as P
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    done = skipped = 0
+    t0 = time.time()
+    for it in range(n):
+        user = draw(rng)
+        try:
+            cfg = make_config(dict(user, mover_capacity=0))
+            eng = BatchedEngine(cfg)
+        except (NotImplementedError, ValueError) as ex:      # combinations the config layer rejects (e.g. too many movers)
+            skipped += 1
+            print("skip %d: %s" % (it, str(ex)[:90]), flush=True)
+            continue
+        E, A = eng.E, eng.A
+        orc = ob.OracleWorld(eng.host)
+        eng.reset()
+        orc.reset()
+        where = "fuzz %d %r" % (it, user)
+        assert_state_equal(eng.download_state(), orc.state, where=where + " reset")
+        arng = np.random.RandomState(it)
+        for t in range(120):
+            if t == 20 and eng.cap > eng.host.state["shape0"].reshape(E, -1)["flags"].astype(bool).sum(1).max() + 1 and rng.randint(2):
+                sh = orc.state["shape"].reshape(E, -1)
+                spot = np.stack([sh["cx"][:, 0] + 14.0 * sh["c"][:, 0], sh["cy"][:, 0] + 14.0 * sh["s"][:, 0]], 1)
+                try:
+                    p = eng.spawn_object("pedestrian", spot, 0.3)
+                    assert p == P.spawn(orc.state, E, eng.cap, A, "pedestrian", spot, 0.3)
+                    eng.set_velocity(p, [0.5, 0.5], None)
+                    P.set_velocity(orc.state, E, eng.cap, p, [0.5, 0.5], None)
+                except RuntimeError:
+                    pass
+            a = arng.uniform(-1, 1, (E, A, 2)).astype(np.float32)
+            a[..., 0] *= 0.3
+            if t % 7:
+                a[..., 1] = np.abs(a[..., 1])
+            eng.step(torch.from_numpy(a).to(eng.device))
+            orc.step(a)
+            if t % 30 == 29:
+                assert_state_equal(eng.download_state(), orc.state, where=where + " step %d" % t)
+        done += 1
+        del eng
+    print("%d random configurations bit-exact over 120 steps each (%d rejected by the config layer), %.0f s" % (done, skipped, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
