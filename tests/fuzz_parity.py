@@ -43,6 +43,25 @@ def draw(rng):
     return cfg
 
 
+def draw_marl(rng):
+    pick = lambda *xs: xs[int(rng.randint(len(xs)))]
+    kind = pick("roundabout", "intersection", "bottleneck", "pg")
+    cfg = dict(num_envs=int(pick(1, 4, 9)), start_seed=int(rng.randint(0, 500)), horizon=int(pick(60, 200, 1000)),
+               num_agents=int(pick(1, 3, 8, 12, -1)), delay_done=int(pick(0, 5, 25)), allow_respawn=bool(rng.randint(4) > 0),
+               crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0),
+               map_config=dict(exit_length=int(pick(30, 50, 60)), lane_num=int(pick(2, 3))))
+    cfg["num_scenarios"] = int(pick(1, cfg["num_envs"]))
+    beams = int(pick(0, 30, 72))
+    cfg["vehicle_config"] = dict(lidar=dict(num_lasers=beams, distance=float(pick(20, 40)) if beams else 0,
+                                            num_others=int(pick(0, 0, 4)) if beams else 0, add_others_navi=bool(rng.randint(2))))
+    if kind == "pg":
+        cfg["map"] = pick(2, 3, "SCS", "XT")
+        cfg["num_agents"] = min(cfg["num_agents"], 12) if cfg["num_agents"] > 0 else -1
+    if kind == "bottleneck":
+        cfg["map_config"]["lane_num"] = int(pick(3, 4))
+    return kind, cfg
+
+
 def main():
     import torch
     import oracle_binding as ob
@@ -55,9 +74,18 @@ def main():
     done = skipped = 0
     t0 = time.time()
     for it in range(n):
-        user = draw(rng)
+        marl = rng.randint(4) == 0
         try:
-            cfg = make_config(dict(user, mover_capacity=0))
+            if marl:
+                from metadrive_ped_amd.envs import marl_env as M
+                kind, user = draw_marl(rng)
+                cls = dict(roundabout=M.BatchedMultiAgentRoundaboutEnv, intersection=M.BatchedMultiAgentIntersectionEnv,
+                           bottleneck=M.BatchedMultiAgentBottleneckEnv, pg=M.BatchedMultiAgentMetaDrive)[kind]
+                cfg = cls(user).config
+                user = dict(user, marl_map=kind)
+            else:
+                user = draw(rng)
+                cfg = make_config(dict(user, mover_capacity=0))
             eng = BatchedEngine(cfg)
         except (NotImplementedError, ValueError) as ex:      # combinations the config layer rejects (e.g. too many movers)
             skipped += 1
@@ -71,7 +99,7 @@ def main():
         assert_state_equal(eng.download_state(), orc.state, where=where + " reset")
         arng = np.random.RandomState(it)
         for t in range(120):
-            if t == 20 and eng.cap > eng.host.state["shape0"].reshape(E, -1)["flags"].astype(bool).sum(1).max() + 1 and rng.randint(2):
+            if t == 20 and not marl and eng.cap > eng.host.state["shape0"].reshape(E, -1)["flags"].astype(bool).sum(1).max() + 1 and rng.randint(2):
                 sh = orc.state["shape"].reshape(E, -1)
                 spot = np.stack([sh["cx"][:, 0] + 14.0 * sh["c"][:, 0], sh["cy"][:, 0] + 14.0 * sh["s"][:, 0]], 1)
                 try:
