@@ -141,6 +141,28 @@ class BatchedMultiAgentRoundaboutEnv:
         tc["__all__"] = all(tc.values()) if tc else True
         return o, r, tm, tc
 
+    def actions_from_dicts(self, dicts, info):
+        """The way in for the reference's per-env action dicts: `dicts[e]` = {"agent{k}": [steer, throttle], ...} for env e
+        (missing agents get [0, 0]) -> the [E, A, 2] tensor step() takes; `info` is the last info (its agent_id / active
+        say which slot holds which agent)."""
+        torch = self.engine.torch
+        ids = info["agent_id"].cpu().numpy()
+        act = info["active"].cpu().numpy()
+        out = np.zeros((self.num_envs, self.num_agents, 2), np.float32)
+        for e, d in enumerate(dicts):
+            slot_of = {"agent{}".format(int(ids[e, a])): a for a in np.nonzero(act[e])[0]}
+            for name, v in d.items():
+                if name not in slot_of:
+                    raise KeyError("env {}: no active agent named {!r}".format(e, name))
+                out[e, slot_of[name]] = v
+        return torch.from_numpy(out).to(self.engine.device)
+
+    def seed(self, seed=None):
+        """Scenario seeds are set through reset(seed=...); a no-op like the gymnasium API."""
+
+    def render(self, *args, **kwargs):
+        raise NotImplementedError("rendering lies outside this build (DESIGN.md section 1)")
+
     def close(self):
         self.engine = None
 

@@ -230,6 +230,28 @@ class BatchedMetaDriveEnv:
         info["env_seed"] = e.torch.as_tensor(np.asarray(e.host.seeds, dtype=np.int64), device=e.device)
         return info
 
+    # -- small parts of BaseEnv's surface that user loops touch (envs/base_env.py:618-700) --------------------------
+    def seed(self, seed=None):
+        """BaseEnv.seed: scenario seeds are set through reset(seed=...); kept as a no-op like the gymnasium API."""
+
+    def render(self, *args, **kwargs):
+        raise NotImplementedError("rendering lies outside this build (DESIGN.md section 1): export_scenarios() gives the "
+                                  "episode in the reference's scenario format for its own top-down renderer")
+
+    @property
+    def current_seed(self):
+        """The scenario seed of env 0 (BaseEnv.current_seed)."""
+        return self.current_seeds[0]
+
+    @property
+    def episode_step(self):
+        """[E] steps taken in the running episode of every env (BaseEnv.episode_step)."""
+        return self.engine.nav_i[:, 0, 8]
+
+    @property
+    def num_scenarios(self):
+        return self.config["num_scenarios"]
+
     @property
     def current_seeds(self):
         return list(self.engine.host.seeds)

@@ -30,7 +30,11 @@ def test_env_api_contract(cs_dist):
     with pytest.raises(ValueError):
         env.step(torch.zeros(E + 1, 2))
     obs2, _ = env.reset(seed=5)                          # re-base scenarios: maps regenerate
-    assert env.current_seeds[0] == 5
+    assert env.current_seeds[0] == 5 and env.current_seed == 5 and env.num_scenarios == E
+    assert tuple(env.episode_step.shape) == (E, ) and int(env.episode_step.max()) == 0
+    env.seed(3)
+    with pytest.raises(NotImplementedError):
+        env.render()
     env.close()
     # old gym API (envs/gym_wrapper.py of the reference): 4-tuple step, reset -> obs, attributes pass through
     from metadrive_ped_amd.envs.gym_wrapper import createGymWrapper

@@ -146,6 +146,14 @@ def test_marl_env_api_gpu():
     assert tuple(r.shape) == (E, 40) and tm.dtype == torch.bool
     assert int(info["agent_id"].max()) >= 40                            # someone respawned under a new name
     o, rr, tmd, tcd = env.to_dicts(0, obs, r, tm, tc, info)
+    # and the way in: per-env action dicts keyed by agent name
+    dicts = [{k: [0.1, 0.5] for k in env.to_dicts(e, obs, r, tm, tc, info)[0]} for e in range(E)]
+    a = env.actions_from_dicts(dicts, info)
+    assert tuple(a.shape) == (E, 40, 2) and bool(((a[..., 1] == 0.5) == info["active"]).all())
+    with pytest.raises(KeyError):
+        env.actions_from_dicts([{"agent99999": [0, 0]}] + [{}] * (E - 1), info)
+    with pytest.raises(NotImplementedError):
+        env.render()
     assert set(o.keys()) == set(rr.keys()) == (set(tmd.keys()) - {"__all__"})   # key-set consistency (test_ma_roundabout_env)
     assert all(k.startswith("agent") for k in o)
 
