@@ -18,7 +18,7 @@ import numpy as np
 
 from metadrive_ped_amd import abi
 from metadrive_ped_amd.config import make_config
-from metadrive_ped_amd.envs.spaces import Box
+from metadrive_ped_amd.envs.spaces import Box, LazyInfo
 
 MULTI_AGENT_DEFAULTS = dict(
     is_multi_agent=True, num_agents=40, crash_done=True, out_of_road_done=True, delay_done=25, allow_respawn=True,
@@ -96,27 +96,31 @@ class BatchedMultiAgentRoundaboutEnv:
         info = self._info()
         terminated = ((fl & abi.FL_TERMINATED) != 0) & info["active"]
         truncated = ((fl & abi.FL_TRUNCATED) != 0) & info["active"]
-        info["terminated_all"] = (terminated | ~info["active"]).all(dim=1)
-        info["truncated_all"] = (truncated | ~info["active"]).all(dim=1)
+        active = info["active"]
+        info._lazy["terminated_all"] = lambda: (terminated | ~active).all(dim=1)
+        info._lazy["truncated_all"] = lambda: (truncated | ~active).all(dim=1)
         return self.engine.obs, self.engine.reward, terminated, truncated, info
 
     def _info(self):
         e = self.engine
         A = self.num_agents
         sf = e.shape_f.view(e.torch.int32)[:, :A, 6]
-        alive = (sf & abi.F_ALIVE) != 0
-        active = alive & ((sf & abi.F_STATIC) == 0)
+        active = (sf & (abi.F_ALIVE | abi.F_STATIC)) == abi.F_ALIVE        # needed by step() itself: computed now
         fl = e.flags[:, :A]
-        bit = lambda m: (fl & m) != 0
-        return {
-            "active": active, "dying": alive & ~active, "agent_id": e.agent_id[:, :A],
-            "spawned": active & (e.nav_i[:, :A, 8] == 0),
+        bit = lambda m: (lambda: (fl & m) != 0)
+        eager = {
+            "active": active, "agent_id": e.agent_id[:, :A],
             "velocity": e.step_info[:, :, 1], "step_reward": e.step_info[:, :, 0], "episode_reward": e.step_info[:, :, 4],
             "episode_length": e.nav_i[:, :A, 8], "cost": e.cost,
+        }
+        lazy = {
+            "dying": lambda: (sf & (abi.F_ALIVE | abi.F_STATIC)) == (abi.F_ALIVE | abi.F_STATIC),
+            "spawned": lambda: active & (e.nav_i[:, :A, 8] == 0),
             "crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
             "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
             "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
         }
+        return LazyInfo(eager, lazy)
 
     # traffic participants (needs mover_capacity > num_agents: the agents' slots are never handed out)
     def spawn_object(self, kind, position, heading_theta=0.0, envs=None):

@@ -18,7 +18,7 @@ import numpy as np
 
 from metadrive_ped_amd import abi
 from metadrive_ped_amd.config import make_config
-from metadrive_ped_amd.envs.spaces import Box, Discrete, MultiDiscrete
+from metadrive_ped_amd.envs.spaces import Box, LazyInfo, Discrete, MultiDiscrete
 
 
 def make_action_space(cfg):
@@ -114,8 +114,8 @@ class BatchedMetaDriveEnv:
         a = actions
         if self.config["agent_policy"] == "IDMPolicy":     # the agents drive themselves; `actions` is ignored
             self.engine.step(None)
-            fl = self.engine.flags[:, 0]
-            return self._obs(), self.engine.reward[:, 0], (fl & abi.FL_TERMINATED) != 0, (fl & abi.FL_TRUNCATED) != 0, self._info()
+            terminated, truncated = self._done_flags()
+            return self._obs(), self.engine.reward[:, 0], terminated, truncated, self._info()
         if self.config["discrete_action"]:
             a = discrete_to_continuous(torch, self.config, a, (self.num_envs, ), self.engine.device)
         else:
@@ -126,10 +126,17 @@ class BatchedMetaDriveEnv:
         if tuple(a.shape) != (self.num_envs, 2):
             raise ValueError("actions must have shape [{}, 2], got {}".format(self.num_envs, tuple(a.shape)))
         self.engine.step(a)
-        fl = self.engine.flags[:, 0]
-        terminated = (fl & abi.FL_TERMINATED) != 0
-        truncated = (fl & abi.FL_TRUNCATED) != 0
+        terminated, truncated = self._done_flags()
         return self._obs(), self.engine.reward[:, 0], terminated, truncated, self._info()
+
+    def _done_flags(self):
+        """(terminated, truncated) as two views of ONE [E, 2] bool tensor: every extra device op of an eager loop costs
+        about as much as a tenth of the step itself on this GPU, so the two bits are tested in one go."""
+        e = self.engine
+        if getattr(self, "_tt_mask", None) is None or self._tt_mask.device != e.device:
+            self._tt_mask = e.torch.tensor([abi.FL_TERMINATED, abi.FL_TRUNCATED], dtype=e.flags.dtype, device=e.device)
+        tt = (e.flags[:, 0:1] & self._tt_mask) != 0
+        return tt[:, 0], tt[:, 1]
 
     def close(self):
         self.engine = None
@@ -213,22 +220,31 @@ class BatchedMetaDriveEnv:
         e = self.engine
         fl = e.flags[:, 0]
         si = e.step_info[:, 0, :]
-        bit = lambda m: (fl & m) != 0
-        info = {
+        bit = lambda m: (lambda: (fl & m) != 0)
+        eager = {
             "velocity": si[:, 1], "steering": e.dyn_f[:, 0, 2], "acceleration": e.dyn_f[:, 0, 3],
             "step_energy": si[:, 2], "episode_energy": si[:, 3], "step_reward": si[:, 0], "episode_reward": si[:, 4],
             "episode_length": e.nav_i[:, 0, 8], "cost": e.cost[:, 0], "total_cost": si[:, 5],
+            "raw_action": e.action[:, 0, :], "action": e.action[:, 0, :],
+        }
+        lazy = {
             "crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
             "crash_building": bit(abi.FL_CRASH_BUILDING), "crash_human": bit(abi.FL_CRASH_HUMAN),
             "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
             "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
             "on_lane": bit(abi.FL_ON_LANE), "on_broken_line": bit(abi.FL_ON_BROKEN),
-            "raw_action": e.action[:, 0, :], "action": e.action[:, 0, :],
+            "crash": bit(abi.FL_CRASH_VEHICLE | abi.FL_CRASH_OBJECT | abi.FL_CRASH_BUILDING | abi.FL_CRASH_SIDEWALK |
+                         abi.FL_CRASH_HUMAN),
+            "env_seed": self._env_seed_tensor,
         }
-        info["crash"] = info["crash_vehicle"] | info["crash_object"] | info["crash_building"] | \
-            info["crash_sidewalk"] | info["crash_human"]
-        info["env_seed"] = e.torch.as_tensor(np.asarray(e.host.seeds, dtype=np.int64), device=e.device)
-        return info
+        return LazyInfo(eager, lazy)
+
+    def _env_seed_tensor(self):
+        e = self.engine
+        key = tuple(e.host.seeds)
+        if getattr(self, "_seed_cache", (None, None))[0] != key:
+            self._seed_cache = (key, e.torch.as_tensor(np.asarray(e.host.seeds, dtype=np.int64), device=e.device))
+        return self._seed_cache[1]
 
     # -- small parts of BaseEnv's surface that user loops touch (envs/base_env.py:618-700) --------------------------
     def seed(self, seed=None):

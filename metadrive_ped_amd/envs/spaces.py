@@ -68,3 +68,42 @@ class MultiDiscrete:
 
     def __repr__(self):
         return "MultiDiscrete({})".format(self.nvec.tolist())
+
+
+class LazyInfo(dict):
+    """The `info` of a batched step: a dict whose derived entries (flag bits -> bool tensors ...) are computed when they
+    are first READ.  Building all of them eagerly costs some thirty small kernel launches per step -- several times the
+    step itself -- while a training loop reads two or three.  Like the entries that are plain views of the engine's
+    buffers, a derived entry reflects the state at the moment it is read: read (or clone) what you need before the next
+    step."""
+    def __init__(self, eager, lazy):
+        super().__init__(eager)
+        self._lazy = dict(lazy)
+
+    def __missing__(self, key):
+        fn = self._lazy.pop(key)            # KeyError for an unknown key, like a dict
+        value = fn()
+        self[key] = value
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def __iter__(self):
+        yield from dict.__iter__(self)
+        yield from list(self._lazy)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
+
+    def keys(self):
+        return list(iter(self))
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
