@@ -317,3 +317,19 @@ def test_varying_dynamics_vehicle_takes_size_and_mass_from_its_config():
             assert abs(p["accel_gain"] - 4.0 * cfgv["max_engine_force"] / 2200) < 1e-5
     h = HostScene(make_config(dict(num_envs=1, traffic_density=0.0, vehicle_config=dict(width=3, length=9, mass=2200))))
     assert abs(2 * h.state["shape0"][0]["hl"] - 4.515) < 1e-6 and abs(2 * h.state["shape0"][0]["hw"] - 1.852) < 1e-6
+
+
+def test_lazy_info_behaves_like_a_dict_and_computes_on_first_read():
+    from metadrive_ped_amd.envs.spaces import LazyInfo
+    calls = []
+    info = LazyInfo(dict(velocity=1.5), dict(crash=lambda: calls.append("crash") or True, out_of_road=lambda: calls.append("oor") or False))
+    assert "velocity" in info and "crash" in info and "nope" not in info and len(info) == 3
+    assert calls == []                                           # nothing derived yet
+    assert info["crash"] is True and info["crash"] is True and calls == ["crash"]     # computed once, then cached
+    assert sorted(info.keys()) == ["crash", "out_of_road", "velocity"]
+    assert dict(info.items()) == dict(velocity=1.5, crash=True, out_of_road=False) and calls == ["crash", "oor"]
+    assert info.get("nope", 7) == 7 and info.get("velocity") == 1.5
+    with pytest.raises(KeyError):
+        info["nope"]
+    info["extra"] = 3                                            # still an ordinary dict for writes
+    assert info["extra"] == 3 and len(info) == 4
