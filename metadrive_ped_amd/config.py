@@ -31,7 +31,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
-    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" (set by the multi-agent env classes)
+    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",

@@ -23,15 +23,15 @@ STATE_ARRAY_SPECS = None  # filled below
 
 def _build_marl(cfg, scene_cfg, uniq):
     """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
-    from metadrive_ped_amd.mapgen.pg import MABottleneckMap, MAIntersectionMap, MARoundaboutMap
+    from metadrive_ped_amd.mapgen.pg import MABidirectionMap, MABottleneckMap, MAIntersectionMap, MARoundaboutMap
     from metadrive_ped_amd.marl import FIXED_DESTINATION, SPAWN_ROADS, RoundaboutScene
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     mc = cfg["map_config"]
     kind = cfg["marl_map"]
     if kind not in SPAWN_ROADS:
         raise NotImplementedError("multi-agent map {!r} is not built (built: {})".format(kind, sorted(SPAWN_ROADS)))
-    if kind == "bottleneck":
-        pg = MABottleneckMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+    if kind in ("bottleneck", "bidirection"):
+        pg = (MABottleneckMap if kind == "bottleneck" else MABidirectionMap)(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                              neck_lane_num=mc["neck_lane_num"], neck_length=mc["neck_length"])
     else:
         cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]

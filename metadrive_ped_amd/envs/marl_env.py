@@ -207,6 +207,13 @@ class BatchedMultiAgentBottleneckEnv(BatchedMultiAgentRoundaboutEnv):
         super().__init__(merged)
 
 
+class BatchedMultiAgentBidirectionEnv(BatchedMultiAgentBottleneckEnv):
+    """MultiAgentBidirectionEnv (envs/marl_envs/marl_bidirection.py:11-140): the bottleneck map with a Bidirection block in
+    the neck -- ONE lane that both directions share for 40-80 m -- 20 agents from both ends.  Rewards, termination and
+    detectors are the bottleneck env's."""
+    MAP_DEFAULTS = dict(BatchedMultiAgentBottleneckEnv.MAP_DEFAULTS, marl_map="bidirection")
+
+
 class BatchedMultiAgentMetaDrive(BatchedMultiAgentRoundaboutEnv):
     """MultiAgentMetaDrive itself (envs/marl_envs/multi_agent_metadrive.py:12-128): 15 agents on an ordinary procedurally
     generated map (one per scenario seed, 3 blocks, 3 lanes), all spawning on the first block's exit road (5 slots x 3

@@ -297,8 +297,11 @@ def bend_then_straight(prev, follow_len, radius, angle, clockwise, width, line_t
 # blocks
 # ---------------------------------------------------------------------------------------------
 class Socket:
-    def __init__(self, positive, negative):
+    """`fake_positive`: the lane the next block extends instead of the positive road's own lanes (BidirectionSocket,
+    pgblock/bidirection.py:58-68: the two-way single lane ends in a socket shaped like one ordinary lane per direction)."""
+    def __init__(self, positive, negative, fake_positive=None):
         self.positive, self.negative = positive, negative
+        self.fake_positive = fake_positive
         self.index = None
 
 
@@ -319,7 +322,8 @@ class Block:
         self.config = sample_parameters(self.rng, self.SPACE)  # the draw made in BaseRunnable.__init__
         self._part, self._road = 0, 0
         if index != 0:
-            self.positive_lanes = global_net.lanes(*pre_socket.positive)
+            self.positive_lanes = [pre_socket.fake_positive] if pre_socket.fake_positive is not None else \
+                global_net.lanes(*pre_socket.positive)
             self.lane_num = len(self.positive_lanes)
             self.basic_lane = self.positive_lanes[-1]
 
@@ -958,7 +962,38 @@ class Split(Bottleneck):
         return ok
 
 
-BLOCK_CLASSES.update(Merge=Merge, Split=Split)
+class Bidirection(Block):
+    """One lane shared by both directions (pgblock/bidirection.py:71-116): the positive road is a single lane centred on
+    the incoming road's centre line, the negative road the SAME lane run backwards (create_overlap_road, :10-55);
+    whoever enters has to negotiate with the oncoming traffic.  The socket is shaped like one ordinary lane per
+    direction, so the next block (a Split in the multi-agent map) continues with normal geometry."""
+    ID = "B"
+    SPACE = BlockParameterSpace.BIDIRECTION
+
+    def plug(self):
+        length = self.config[Parameter.length]
+        basic = self.positive_lanes[0]
+        fake_positive = basic.extended(length, [LINE_BROKEN, LINE_SIDE])
+        w = basic.width
+        new_lane = StraightLane(basic.position(basic.length, -w / 2), basic.position(basic.length + length, -w / 2), w,
+                                [LINE_BROKEN, LINE_SIDE])
+        road = (self.pre_socket.positive[1], self.node())
+        ok = create_road_from(new_lane, 1, road, self.net, self.global_net)
+        # create_overlap_road: the same centre line, run the other way
+        lanes = self.net.lanes(*road)
+        ref = lanes[-1]
+        sym = StraightLane(ref.position(ref.length, 0), ref.position(0, 0), ref.width, ref.line_types)
+        sym.line_colors = [COLOR_GREY, COLOR_GREY]
+        ok = create_road_from(sym, 1, negate_road(*road), self.net, self.global_net, center_line_type=LINE_CONTINUOUS,
+                              side_lane_line_type=LINE_SIDE, inner_lane_line_type=LINE_BROKEN,
+                              center_line_color=COLOR_YELLOW) and ok
+        lanes[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
+        new_lane.line_colors = [COLOR_GREY, COLOR_GREY]
+        self.add_socket(Socket(road, negate_road(*road), fake_positive=fake_positive))
+        return ok
+
+
+BLOCK_CLASSES.update(Merge=Merge, Split=Split, Bidirection=Bidirection)
 
 
 class MABottleneckMap:
@@ -976,6 +1011,31 @@ class MABottleneckMap:
                       extra_config=dict(length=exit_length, lane_num=lane_num - neck_lane_num))
         split.construct()
         self.blocks = [first, merge, split]
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
+class MABidirectionMap:
+    """FirstPGBlock + Merge (over 3 m) + Bidirection + Split: the map of MultiAgentBidirectionEnv
+    (envs/marl_envs/marl_bidirection.py:28-73): `bottle_lane_num` lanes narrow to one, which both directions share for
+    40-80 m, and widen again."""
+    def __init__(self, lane_num=4, lane_width=3.5, exit_length=60, neck_lane_num=1, neck_length=20):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        merge = Merge(1, list(first.sockets.values())[0], self.net, 1,
+                      extra_config=dict(lane_num=lane_num - neck_lane_num, length=3))
+        merge.construct()
+        both = Bidirection(2, list(merge.sockets.values())[0], self.net, 1)
+        both.construct()
+        split = Split(3, list(both.sockets.values())[0], self.net, 1,
+                      extra_config=dict(length=exit_length, lane_num=lane_num - neck_lane_num))
+        split.construct()
+        self.blocks = [first, merge, both, split]
         for a, b, lanes in self.net.roads():
             for i, l in enumerate(lanes):
                 l.index = (a, b, i)
@@ -1114,3 +1174,4 @@ def bfs_route(net, start_node, goal):
 MARoundaboutMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MAIntersectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MABottleneckMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+MABidirectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

@@ -29,10 +29,13 @@ INTERSECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("1X0_0_", "1X0_1_"), nega
 BOTTLENECK_SPAWN_ROADS = [(">>", ">>>"), negate_road("2Y0_0_", "2Y0_1_")]
 # MultiAgentMetaDrive on PG maps: MULTI_AGENT_METADRIVE_DEFAULT_CONFIG.spawn_roads (multi_agent_metadrive.py:27)
 PG_SPAWN_ROADS = [(">>", ">>>")]
-SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS)
+# MABidirectionConfig.spawn_roads (envs/marl_envs/marl_bidirection.py:12): the Split is block 3 there
+BIDIRECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("3Y0_0_", "3Y0_1_")]
+SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS,
+                   bidirection=BIDIRECTION_SPAWN_ROADS)
 # roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
 # bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)
-FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True)
+FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 

@@ -80,6 +80,7 @@ class BlockParameterSpace:
         "solid_center_line": ConstantSpace(0),
     }
     STRAIGHT = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
+    BIDIRECTION = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
     CURVE = {
         Parameter.length: BoxSpace(min=40.0, max=80.0),
         Parameter.radius: BoxSpace(min=25.0, max=60.0),

@@ -471,6 +471,41 @@ def section_ma_bottleneck():
                                     split_config={k: float(v) for k, v in dict(split.get_config()).items()}))
 
 
+def section_ma_bidirection():
+    """Map of MultiAgentBidirectionEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 3 m) +
+    Bidirection (one lane shared by both directions, seed 1) + Split (back to 4, exit 60 m) as MABidirectionMap._generate
+    builds it (marl_bidirection.py:28-73)."""
+    from metadrive.component.pgblock.bidirection import Bidirection
+    from metadrive.component.pgblock.bottleneck import Merge, Split
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_bidirection import MABidirectionConfig
+    from metadrive.manager.spawn_manager import SpawnManager
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, 4, MagicMock(), MagicMock(), length=60)
+    merge = Merge(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok1 = merge.construct_from_config(dict(lane_num=3, length=3), MagicMock(), MagicMock())
+    both = Bidirection(2, merge.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok2 = both.construct_block(MagicMock(), MagicMock())
+    split = Split(3, both.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok3 = split.construct_from_config({"length": 60, "lane_num": 3}, MagicMock(), MagicMock())
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+    spawn_roads = [[r.start_node, r.end_node] for r in MABidirectionConfig["spawn_roads"]]
+    routes = []
+    for sr in MABidirectionConfig["spawn_roads"]:
+        for er in MABidirectionConfig["spawn_roads"]:
+            dest = (-er).end_node
+            path = net.shortest_path((sr.start_node, sr.end_node, 0), dest)
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest, path=path))
+    dump("ma_bidirection.json", dict(no_cross=bool(ok1 and ok2 and ok3), roads=roads, spawn_roads=spawn_roads, routes=routes,
+                                     max_capacity=int(SpawnManager.max_capacity(MABidirectionConfig["spawn_roads"], 60, 4)),
+                                     num_agents=int(MABidirectionConfig["num_agents"]),
+                                     bidirection_config={k: float(v) for k, v in dict(both.get_config()).items()}))
+
+
 def section_idm():
     """IDM longitudinal model, desired gap, PID steering and the front/back object search
     (SURVEY 8a-10): IDMPolicy.acceleration / desired_gap / steering_control and
@@ -650,7 +685,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -511,3 +511,83 @@ def test_small_agent_counts_rollout_parity_gpu(n):
     if n == 1:
         sh0 = eng.host.state["shape0"].reshape(E, -1)
         assert np.allclose(sh0["cy"][:, 0], sh0["cy"][0, 0], atol=0.3)       # same (first) spawn lane in every scenario
+
+
+def test_bidirection_map_equals_reference():
+    """MABidirectionMap (marl_bidirection.py:28-73): FirstPGBlock + Merge + Bidirection + Split, every lane of it, against
+    the reference's own construction (tests/golden/ma_bidirection.json)."""
+    from metadrive_ped_amd.mapgen.pg import MABidirectionMap
+    from metadrive_ped_amd.marl import BIDIRECTION_SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_bidirection.json")) as f:
+        g = json.load(f)
+    m = MABidirectionMap()
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]
+    for (a, b, lanes), ref in zip(roads, g["roads"]):
+        assert len(lanes) == len(ref["lanes"]), (a, b)
+        for l, rl in zip(lanes, ref["lanes"]):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"], (a, b)
+            np.testing.assert_allclose([l.length, *l.start, *l.end], [rl["length"], *rl["start"], *rl["end"]], atol=1e-9)
+    assert [list(r) for r in BIDIRECTION_SPAWN_ROADS] == g["spawn_roads"]
+    for r in g["routes"]:
+        assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    assert g["num_agents"] == 20
+    for k, v in g["bidirection_config"].items():
+        assert float(m.blocks[2].config[k]) == v
+    # the shared lane: the negative road is the positive road's lane run backwards
+    pos = [l for a, b, l in roads if (a, b) == ("1y0_1_", "2B0_0_")][0][0]
+    neg = [l for a, b, l in roads if (a, b) == ("-2B0_0_", "-1y0_1_")][0][0]
+    np.testing.assert_allclose([*pos.start, *pos.end], [*neg.end, *neg.start], atol=1e-9)
+
+
+def test_bidirection_env_on_oracle():
+    """MultiAgentBidirectionEnv: agents from both ends meet in the shared lane; observations stay in range, agents finish
+    (crash or arrive) and new ones enter."""
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedMultiAgentBidirectionEnv
+    E = 2
+    cfg = BatchedMultiAgentBidirectionEnv(dict(num_envs=E, num_scenarios=E)).config
+    A = cfg["num_agents"]
+    assert A == 20 and cfg["marl_map"] == "bidirection"
+    host = HostScene(cfg)
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert (_counts(o.state, E)[0] == A).all()
+    rng = np.random.RandomState(2)
+    met = 0
+    for t in range(400):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.6
+        a[..., 0] = rng.uniform(-0.1, 0.1, (E, A))
+        o.step(a)
+        obs = o.obs.reshape(E, A, -1)
+        assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+        met += int(((o.state["flags"].reshape(E, -1)[:, :A] & abi.FL_CRASH_VEHICLE) != 0).sum())
+    assert (o.state["next_agent_id"] > A).all() and met > 0        # head-on meetings in the shared lane do happen
+
+
+@pytest.mark.gpu
+def test_bidirection_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.envs import BatchedMultiAgentBidirectionEnv
+    E = 6
+    cfg = BatchedMultiAgentBidirectionEnv(dict(num_envs=E, num_scenarios=E)).config
+    A = cfg["num_agents"]
+    eng = BatchedEngine(cfg)
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="bidirection reset")
+    rng = np.random.RandomState(9)
+    for t in range(300):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.7
+        a[..., 0] = rng.uniform(-0.15, 0.15, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="bidirection step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="bidirection final")
+    assert (orc.state["next_agent_id"] > A).all()
