@@ -619,6 +619,14 @@ def section_pg_maps_v3():
     _pg_maps_cases("pg_maps_v3.json", specs)
 
 
+def section_pg_maps_v4():
+    """Block sequences with the two-way single-lane block Bidirection 'B' (zero probability in the default distribution):
+    what follows it plugs into its one-lane-per-direction socket."""
+    specs = [(410, 3, 3.5, 50, "block_sequence", "SBS"), (411, 2, 3.5, 50, "block_sequence", "BC"),
+             (412, 3, 3.5, 50, "block_sequence", "yBY"), (413, 3, 3.0, 50, "block_sequence", "BSC")]
+    _pg_maps_cases("pg_maps_v4.json", specs)
+
+
 def _pg_maps_cases(fname, specs):
     from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
     cases = []
@@ -685,7 +693,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def draw(rng):
     pick = lambda *xs: xs[int(rng.randint(len(xs)))]
     cfg = dict(num_envs=int(pick(1, 5, 16, 33)), start_seed=int(rng.randint(0, 2000)), horizon=int(pick(40, 150, 1000)),
-               map=pick(1, 2, 3, 4, "SCS", "XT", "rRO", "yY", "CrX"), traffic_density=float(pick(0.0, 0.05, 0.1, 0.3)),
+               map=pick(1, 2, 3, 4, "SCS", "XT", "rRO", "yY", "CrX", "yBY", "BS"), traffic_density=float(pick(0.0, 0.05, 0.1, 0.3)),
                traffic_mode=pick("trigger", "trigger", "respawn", "hybrid"), accident_prob=float(pick(0.0, 0.0, 0.5, 1.0)),
                random_lane_width=bool(rng.randint(2)), random_lane_num=bool(rng.randint(2)),
                need_inverse_traffic=bool(rng.randint(2)), random_agent_model=bool(rng.randint(2)),
@@ -45,7 +45,7 @@ def draw(rng):
 
 def draw_marl(rng):
     pick = lambda *xs: xs[int(rng.randint(len(xs)))]
-    kind = pick("roundabout", "intersection", "bottleneck", "pg")
+    kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg")
     cfg = dict(num_envs=int(pick(1, 4, 9)), start_seed=int(rng.randint(0, 500)), horizon=int(pick(60, 200, 1000)),
                num_agents=int(pick(1, 3, 8, 12, -1)), delay_done=int(pick(0, 5, 25)), allow_respawn=bool(rng.randint(4) > 0),
                crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0),
@@ -57,7 +57,7 @@ def draw_marl(rng):
     if kind == "pg":
         cfg["map"] = pick(2, 3, "SCS", "XT")
         cfg["num_agents"] = min(cfg["num_agents"], 12) if cfg["num_agents"] > 0 else -1
-    if kind == "bottleneck":
+    if kind in ("bottleneck", "bidirection"):
         cfg["map_config"]["lane_num"] = int(pick(3, 4))
     return kind, cfg
 
@@ -80,7 +80,8 @@ def main():
                 from metadrive_ped_amd.envs import marl_env as M
                 kind, user = draw_marl(rng)
                 cls = dict(roundabout=M.BatchedMultiAgentRoundaboutEnv, intersection=M.BatchedMultiAgentIntersectionEnv,
-                           bottleneck=M.BatchedMultiAgentBottleneckEnv, pg=M.BatchedMultiAgentMetaDrive)[kind]
+                           bottleneck=M.BatchedMultiAgentBottleneckEnv, bidirection=M.BatchedMultiAgentBidirectionEnv,
+                           pg=M.BatchedMultiAgentMetaDrive)[kind]
                 cfg = cls(user).config
                 user = dict(user, marl_map=kind)
             else:

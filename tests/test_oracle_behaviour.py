@@ -578,3 +578,22 @@ def test_enable_reverse_drives_the_agent_backwards():
     assert (sp_r[-1] < -3.0).all()                                   # ... backs up
     assert (sp_r[5] > sp[5]).all()                                   # and sheds speed more slowly than the brake does
     assert (x1_r < out[False][3]).all()
+
+
+def test_single_agent_env_on_a_map_with_a_bidirection_block():
+    """map="yBY" / "BC": the two-way single lane inside an ordinary procedurally generated map (pinned lane for lane by
+    tests/golden/pg_maps_v4.json).  The block narrows the road to ONE lane placed on the centre line -- in the reference as
+    here it is meant to follow a Merge -- so this only checks that scenes build, traffic spawns on it and a rollout runs;
+    the multi-agent env built around it is tested in test_marl.py."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    for seed, mp in ((412, "yBY"), (411, "BC")):
+        E = 3
+        h = HostScene(make_config(dict(num_envs=E, num_scenarios=E, start_seed=seed, map=mp, traffic_density=0.3, horizon=300)))
+        assert ((h.state["shape0"]["flags"] & abi.KIND_MASK) == abi.KIND_VEHICLE).sum() > 2 * E      # traffic on it too
+        o = ob.OracleWorld(h)
+        o.reset()
+        for t in range(200):
+            o.step(np.tile(np.array([0.0, 0.6], np.float32), (E, 1, 1)))
+        obs = o.obs.reshape(E, -1)
+        assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
