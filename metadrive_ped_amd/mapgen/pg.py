@@ -241,7 +241,7 @@ def create_road_from(lane, lane_num, road, block_net, global_net, ignore_check=F
 
 
 def create_adverse_road(road, block_net, global_net, ignore_check=False, center_line_type=None, side_lane_line_type=None,
-                        inner_lane_line_type=None):
+                        inner_lane_line_type=None, center_line_color=None):
     """CreateAdverseRoad (create_pg_block_utils.py:202-281)"""
     a, b = road
     lanes = block_net.lanes(a, b)
@@ -257,9 +257,26 @@ def create_adverse_road(road, block_net, global_net, ignore_check=False, center_
         sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
     ok = create_road_from(sym, num // 2, negate_road(a, b), block_net, global_net, ignore_check,
                           center_line_type=center_line_type, side_lane_line_type=side_lane_line_type,
-                          inner_lane_line_type=inner_lane_line_type)
-    lanes[0].line_colors = [COLOR_YELLOW, COLOR_GREY]
+                          inner_lane_line_type=inner_lane_line_type, center_line_color=center_line_color)
+    lanes[0].line_colors = [center_line_color or COLOR_YELLOW, COLOR_GREY]
     return ok
+
+
+def create_two_way_road(road, block_net, global_net, new_road, center_line_type=None, side_lane_line_type=None,
+                        inner_lane_line_type=None, ignore_check=False):
+    """CreateTwoWayRoad (create_pg_block_utils.py:284-348): the same lanes run the other way under a new road name."""
+    lanes = block_net.lanes(*road)
+    ref = lanes[-1]
+    num = len(lanes)
+    w = ref.width
+    if isinstance(ref, StraightLane):
+        sym = StraightLane(ref.position(ref.length, -(num - 1) * w), ref.position(0, -(num - 1) * w), w, ref.line_types)
+    else:
+        clockwise = not ref.clockwise
+        radius = ref.radius + (num - 1) * w if not clockwise else ref.radius - (num - 1) * w
+        sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
+    return create_road_from(sym, num, new_road, block_net, global_net, ignore_check, center_line_type=center_line_type,
+                            side_lane_line_type=side_lane_line_type, inner_lane_line_type=inner_lane_line_type)
 
 
 def wave_lanes(pre_lane, lateral_dist, wave_length, last_straight_length, lane_width, toward_left=True):
@@ -993,7 +1010,111 @@ class Bidirection(Block):
         return ok
 
 
-BLOCK_CLASSES.update(Merge=Merge, Split=Split, Bidirection=Bidirection)
+class ParkingLot(Block):
+    """Parking spaces at right angles on both sides of a one-lane-per-direction road (pgblock/parking_lot.py:13-330): for
+    each space an entry bend from either direction, the space itself (a two-way stub: roads x_1_ -> x_2_ in, x_5_ -> x_6_
+    out) and exit bends to either direction."""
+    ID = "P"
+    SPACE = BlockParameterSpace.PARKING_LOT
+    ANGLE = np.deg2rad(90)
+    SOCKET_LENGTH = 4
+
+    def road_node(self, part, idx):
+        return "{}{}{}_{}_".format(self.index, self.ID, part, idx)
+
+    def plug(self):
+        self.spawn_roads, self.dest_roads = [], []
+        p = self.config
+        if self.lane_num != 1:
+            raise AssertionError("Lane number of previous block must be 1 in each direction")
+        self.lane_width = self.basic_lane.width
+        self.space_len, self.space_w = p[Parameter.length], self.lane_width
+        n = int(p["one_side_vehicle_number"])
+        radius = p[Parameter.radius]
+        kw = dict(center_line_type=LINE_BROKEN, inner_lane_line_type=LINE_BROKEN)
+        main = self.positive_lanes[0].extended(2 * radius + (n - 1) * self.space_w, [LINE_BROKEN, LINE_NONE])
+        road = (self.pre_socket.positive[1], self.road_node(0, 0))
+        ok = create_road_from(main, 1, road, self.net, self.global_net, side_lane_line_type=LINE_NONE,
+                              center_line_color=COLOR_GREY, **kw)
+        ok = create_adverse_road(road, self.net, self.global_net, side_lane_line_type=LINE_NONE, center_line_color=COLOR_GREY,
+                                 **kw) and ok
+        out_lane = main.extended(self.SOCKET_LENGTH, [LINE_BROKEN, LINE_NONE])
+        out_road = (self.road_node(0, 0), self.road_node(0, 1))
+        ok = create_road_from(out_lane, 1, out_road, self.net, self.global_net, side_lane_line_type=LINE_SIDE, **kw) and ok
+        ok = create_adverse_road(out_road, self.net, self.global_net, side_lane_line_type=LINE_SIDE, **kw) and ok
+        sock = Socket(out_road, negate_road(*out_road))
+        self.add_socket(sock)
+        rev = lambda s_: Socket(s_.negative, s_.positive)
+        for i in range(n):
+            ok = self._space(rev(sock), rev(self.pre_socket), i + 1, radius, i * self.space_w, (n - i - 1) * self.space_w) and ok
+        for i in range(n, 2 * n):
+            k = i - n
+            ok = self._space(self.pre_socket, sock, i + 1, radius, k * self.space_w, (n - k - 1) * self.space_w) and ok
+        return ok
+
+    def _is_pre(self, s_):
+        a, b = self.pre_socket.positive, self.pre_socket.negative
+        return (s_.positive, s_.negative) in ((a, b), (b, a))
+
+    def _space(self, in_s, out_s, part, radius, d_in, d_out):
+        none = dict(center_line_type=LINE_NONE, inner_lane_line_type=LINE_NONE)
+        mk = lambda lane, rd, side=LINE_NONE, **k: create_road_from(lane, 1, rd, self.net, self.global_net,
+                                                                    side_lane_line_type=side, **dict(none, **k))
+        ok = True
+        net = self.global_net if self._is_pre(in_s) else self.net
+        in_lane = net.lanes(*in_s.positive)[0]
+        start = in_s.positive[1]
+        if d_in > 1e-3:
+            in_lane = in_lane.extended(d_in, [LINE_NONE, LINE_NONE])
+            mk(in_lane, (in_s.positive[1], self.road_node(part, 0)))
+            start = self.road_node(part, 0)
+        bend, straight = bend_then_straight(in_lane, self.space_len, radius, self.ANGLE, True, self.space_w, [LINE_BROKEN, LINE_BROKEN])
+        side = LINE_SIDE if d_in < 1e-3 else LINE_NONE
+        b_ok = mk(bend, (start, self.road_node(part, 1)), side)
+        if d_in < 1e-3:
+            ok = ok and b_ok
+        s_road = (self.road_node(part, 1), self.road_node(part, 2))
+        self.dest_roads.append(s_road)
+        ok = ok and mk(straight, s_road, side, center_line_type=LINE_CONTINUOUS, center_line_color=COLOR_GREY)
+        # the way in from the other direction
+        neg_road = out_s.negative
+        net = self.global_net if self._is_pre(out_s) else self.net
+        neg_lane = net.lanes(*neg_road)[0]
+        start = neg_road[1]
+        if d_out > 1e-3:
+            neg_lane = neg_lane.extended(d_out, [LINE_NONE, LINE_NONE])
+            mk(neg_lane, (neg_road[1], self.road_node(part, 3)))
+            start = self.road_node(part, 3)
+        bend, straight = bend_then_straight(neg_lane, self.lane_width, radius, self.ANGLE, False, self.space_w, [LINE_BROKEN, LINE_BROKEN])
+        mk(bend, (start, self.road_node(part, 4)))
+        mk(straight, (self.road_node(part, 4), self.road_node(part, 1)))
+        # the space as a two-way stub: (1, 2) in, (5, 6) out
+        parking_road = (self.road_node(part, 5), self.road_node(part, 6))
+        self.spawn_roads.append(parking_road)
+        create_two_way_road(s_road, self.net, self.global_net, parking_road, center_line_type=LINE_NONE,
+                            inner_lane_line_type=LINE_NONE, side_lane_line_type=LINE_SIDE if d_out < 1e-3 else LINE_NONE)
+        parking_lane = self.net.lanes(*parking_road)[0]
+        # out, towards out_s
+        bend, straight = bend_then_straight(parking_lane, 0.1 if d_out < 1e-3 else d_out, radius, self.ANGLE, True,
+                                            parking_lane.width, [LINE_BROKEN, LINE_BROKEN])
+        out_bend = (self.road_node(part, 6), self.road_node(part, 7) if d_out > 1e-3 else out_s.positive[0])
+        b_ok = mk(bend, out_bend, LINE_SIDE if d_out < 1e-3 else LINE_NONE)
+        if d_out < 1e-3:
+            ok = ok and b_ok
+        if d_out > 1e-3:
+            ok = ok and mk(straight, (self.road_node(part, 7), out_s.positive[0]))
+        # out, towards in_s' other direction
+        ext = parking_lane.extended(self.lane_width, [LINE_NONE, LINE_NONE])
+        mk(ext, (self.road_node(part, 6), self.road_node(part, 8)))
+        bend, straight = bend_then_straight(ext, 0.1 if d_in < 1e-3 else d_in, radius, self.ANGLE, False, parking_lane.width,
+                                            [LINE_BROKEN, LINE_BROKEN])
+        mk(bend, (self.road_node(part, 8), self.road_node(part, 9) if d_in > 1e-3 else in_s.negative[0]))
+        if d_in > 1e-3:
+            mk(straight, (self.road_node(part, 9), in_s.negative[0]))
+        return ok
+
+
+BLOCK_CLASSES.update(Merge=Merge, Split=Split, Bidirection=Bidirection, ParkingLot=ParkingLot)
 
 
 class MABottleneckMap:

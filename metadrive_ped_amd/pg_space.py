@@ -81,6 +81,8 @@ class BlockParameterSpace:
     }
     STRAIGHT = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
     BIDIRECTION = {Parameter.length: BoxSpace(min=40.0, max=80.0)}
+    PARKING_LOT = {"one_side_vehicle_number": DiscreteSpace(min=2, max=10), Parameter.radius: ConstantSpace(4),
+                   Parameter.length: ConstantSpace(8)}
     CURVE = {
         Parameter.length: BoxSpace(min=40.0, max=80.0),
         Parameter.radius: BoxSpace(min=25.0, max=60.0),

@@ -627,6 +627,14 @@ def section_pg_maps_v4():
     _pg_maps_cases("pg_maps_v4.json", specs)
 
 
+def section_pg_maps_v5():
+    """Block sequences with the ParkingLot block 'P' (zero probability in the default distribution; needs one lane per
+    direction before it)."""
+    specs = [(420, 1, 3.5, 50, "block_sequence", "P"), (421, 1, 3.5, 50, "block_sequence", "SP"),
+             (422, 1, 3.0, 50, "block_sequence", "PS"), (423, 1, 3.5, 50, "block_sequence", "CPC")]
+    _pg_maps_cases("pg_maps_v5.json", specs)
+
+
 def _pg_maps_cases(fname, specs):
     from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
     cases = []
@@ -693,7 +701,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -250,6 +250,9 @@ def test_random_lanes_and_inverse_traffic_rollout_parity():
     ("no_traffic_tight_cap", dict(num_envs=8, num_scenarios=8, traffic_density=0.0, mover_capacity=8, map="SSS"), 150),
     # enable_reverse: a negative throttle is a negative engine force (the scripted actions brake / reverse half the time)
     ("reverse", dict(num_envs=16, num_scenarios=16, traffic_density=0.1, vehicle_config=dict(enable_reverse=True)), 200),
+    # ParkingLot block on a one-lane-per-direction road: ~150 short roads, right-angle bends of radius 4 m; reverse allowed
+    ("parking_lot", dict(num_envs=6, num_scenarios=6, start_seed=421, map="SPS", map_config=dict(lane_num=1), traffic_density=0.2,
+                         vehicle_config=dict(enable_reverse=True)), 160),
     # VaryingDynamicsEnv: extreme agent dynamics (80 deg steering, 300 kg / 3000 N, friction 0.1 ...)
     ("varying_dynamics", dict(num_envs=24, num_scenarios=24, vehicle_config=dict(vehicle_model="varying_dynamics"),
                               random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600),

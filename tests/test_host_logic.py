@@ -25,16 +25,20 @@ def test_config_contract(cs_dist):
 
 
 def test_unbuilt_block_type_fails_loudly():
-    """Every block type of the default distribution (and Merge / Split) is built; the other zero-probability ones
-    (forks, parking lot, toll gate, bidirection) are not and say so instead of silently changing the map."""
+    """Every block type of the default distribution, Merge / Split, Bidirection and ParkingLot are built; the toll gate and
+    the forks (broken in the reference itself) are not and say so instead of silently changing the map.  A parking lot
+    after a three-lane road fails like the reference's assertion."""
     from collections import OrderedDict
     from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2, BlockDist, PGMap
     for seed in range(10):
         PGMap(seed)
     d = OrderedDict((k, 0.0) for k in BLOCK_TYPE_DISTRIBUTION_V2)
-    d["ParkingLot"] = 1.0
+    d["TollGate"] = 1.0
     with pytest.raises(NotImplementedError, match="not built yet"):
         PGMap(0, block_dist=BlockDist(d))
+    with pytest.raises(AssertionError, match="must be 1 in each direction"):
+        PGMap(0, generate_type="block_sequence", generate_config="P")            # default lane_num = 3
+    assert [b.ID for b in PGMap(0, lane_num=1, generate_type="block_sequence", generate_config="P").blocks] == ["I", "P"]
 
 
 def test_spaces_and_env_surface():

@@ -597,3 +597,27 @@ def test_single_agent_env_on_a_map_with_a_bidirection_block():
             o.step(np.tile(np.array([0.0, 0.6], np.float32), (E, 1, 1)))
         obs = o.obs.reshape(E, -1)
         assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+
+
+def test_single_agent_env_on_a_map_with_a_parking_lot():
+    """map="SPS" on a one-lane-per-direction road (ParkingLot, pgblock/parking_lot.py; pinned lane for lane by
+    tests/golden/pg_maps_v5.json): scenes build -- lane tables, grid, line / sidewalk quads of ~150 roads --, traffic spawns,
+    the IDM-driven agent passes the lot and arrives; with enable_reverse the agent can back up inside it."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 3
+    h = HostScene(make_config(dict(num_envs=E, num_scenarios=E, start_seed=421, map="SPS", traffic_density=0.1,
+                                   map_config=dict(lane_num=1), agent_policy="IDMPolicy", horizon=2000, auto_reset=False)))
+    assert max(len(t.lane_objs) for t in h.map_tables) > 100
+    o = ob.OracleWorld(h)
+    o.reset()
+    arrived = np.zeros(E, bool)
+    bad = np.zeros(E, bool)
+    for t in range(900):
+        o.step(None)
+        fl = o.state["flags"].reshape(E, -1)[:, 0]
+        bad |= ((fl & (abi.FL_OUT_OF_ROAD | abi.FL_CRASH_SIDEWALK)) != 0) & ~arrived
+        arrived |= ((fl & abi.FL_ARRIVE_DEST) != 0) & ~bad
+        if (arrived | bad).all():
+            break
+    assert arrived.sum() >= E - 1, (arrived, bad)
