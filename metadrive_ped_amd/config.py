@@ -225,13 +225,15 @@ def make_config(user=None):
             raise ValueError("num_agents=-1 (infinite agents) is a multi-agent env option")
         import math
         from metadrive_ped_amd.marl import PG_SPAWN_ROADS, SPAWN_ROADS
-        roads = PG_SPAWN_ROADS if cfg["marl_map"] == "pg" else SPAWN_ROADS[cfg["marl_map"]]
+        roads = cfg["spawn_roads"] or (PG_SPAWN_ROADS if cfg["marl_map"] == "pg" else SPAWN_ROADS[cfg["marl_map"]])
         slots = int(math.floor((cfg["map_config"]["exit_length"] - 10) / 8.0))      # max_capacity (spawn_manager.py:108-115)
         if slots <= 0:
             raise ValueError("The exist length {} should greater than minimal longitude interval {}.".format(
                 cfg["map_config"]["exit_length"] - 10, 18))
         cfg["initial_agents"] = cfg["map_config"]["lane_num"] * len(roads) * slots
         cfg["num_agents"] = min(128, 2 * cfg["initial_agents"])
+    if cfg["spawn_roads"] is not None and not cfg["is_multi_agent"]:
+        raise ValueError("spawn_roads is a multi-agent env option")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):

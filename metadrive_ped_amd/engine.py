@@ -39,8 +39,20 @@ def _build_marl(cfg, scene_cfg, uniq):
     mt = MapTables(pg)
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
     fixed = FIXED_DESTINATION[kind]
-    scenes = {s: RoundaboutScene(s, mt, sc_cfg, SPAWN_ROADS[kind], fixed) for s in uniq}
-    return mt, scenes, spawn_tables(mt, SPAWN_ROADS[kind], mc["lane_num"], fixed)
+    roads = _user_spawn_roads(cfg, mt) or SPAWN_ROADS[kind]
+    scenes = {s: RoundaboutScene(s, mt, sc_cfg, roads, fixed) for s in uniq}
+    return mt, scenes, spawn_tables(mt, roads, mc["lane_num"], fixed)
+
+
+def _user_spawn_roads(cfg, mt):
+    """config["spawn_roads"] (multi_agent_metadrive.py:27,84-92): the user's own list of (start node, end node) roads."""
+    if not cfg.get("spawn_roads"):
+        return None
+    roads = [tuple(r) for r in cfg["spawn_roads"]]
+    for r in roads:
+        if len(r) != 2 or r not in mt.road_id:
+            raise ValueError("spawn_roads: {!r} is not a road of this map".format(r))
+    return roads
 
 
 def _build_one_marl_pg(job):
@@ -52,9 +64,10 @@ def _build_one_marl_pg(job):
     pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
     mt = MapTables(pg)
-    mt.respawn = spawn_tables(mt, PG_SPAWN_ROADS, mc["lane_num"], fixed_destination=True)   # stacked per map by WorldTables
+    roads = [tuple(r) for r in scene_cfg["spawn_roads"]] if scene_cfg.get("spawn_roads") else PG_SPAWN_ROADS
+    mt.respawn = spawn_tables(mt, roads, mc["lane_num"], fixed_destination=True)   # stacked per map by WorldTables
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
-    return mt, RoundaboutScene(s, mt, sc_cfg, PG_SPAWN_ROADS, True)
+    return mt, RoundaboutScene(s, mt, sc_cfg, roads, True)
 
 
 def _build_one(job):
@@ -119,7 +132,7 @@ class HostScene:
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
                          random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
                          random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"],
-                         agent_policy=cfg["agent_policy"])
+                         agent_policy=cfg["agent_policy"], spawn_roads=cfg["spawn_roads"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)

@@ -591,3 +591,33 @@ def test_bidirection_rollout_parity_gpu():
             assert_state_equal(eng.download_state(), orc.state, where="bidirection step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="bidirection final")
     assert (orc.state["next_agent_id"] > A).all()
+
+
+def test_user_spawn_roads_are_honoured():
+    """config["spawn_roads"] (multi_agent_metadrive.py:27): the user's own spawn roads replace the env's; agents start and
+    re-enter only there, and a road that is not on the map is an error."""
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    from metadrive_ped_amd.marl import ROUNDABOUT_SPAWN_ROADS
+    E = 2
+    two = [list(ROUNDABOUT_SPAWN_ROADS[0]), list(ROUNDABOUT_SPAWN_ROADS[2])]
+    cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=10, spawn_roads=two)).config
+    host = HostScene(cfg)
+    mt = host.map_tables[0]
+    allowed = {mt.road_id[tuple(r)] for r in two}
+    lanes0 = host.state["nav0"]["lane"].reshape(E, -1)[:, :10]
+    assert set(int(mt.lanes[int(l)]["road"]) for l in lanes0.reshape(-1)) <= allowed
+    o = ob.OracleWorld(host)
+    o.reset()
+    for t in range(150):
+        o.step(np.tile(np.array([0.0, 0.8], np.float32), (E, 10, 1)))
+        sh = o.state["shape"].reshape(E, -1)
+        fresh = (sh["flags"][:, :10] & abi.F_SPAWNED) != 0
+        if fresh.any():
+            ln = o.state["nav"]["lane"].reshape(E, -1)[:, :10][fresh]
+            assert set(int(mt.lanes[int(l)]["road"]) for l in ln) <= allowed
+    assert (o.state["next_agent_id"] > 10).all()
+    with pytest.raises(ValueError):
+        HostScene(BatchedMultiAgentRoundaboutEnv(dict(num_envs=1, spawn_roads=[["nowhere", "else"]])).config)
+    inf = BatchedMultiAgentRoundaboutEnv(dict(num_envs=1, num_agents=-1, spawn_roads=two)).config
+    assert inf["initial_agents"] == 2 * 2 * 6
