@@ -132,7 +132,8 @@ class HostScene:
                          need_inverse_traffic=cfg["need_inverse_traffic"], random_lane_width=cfg["random_lane_width"],
                          random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
                          random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"],
-                         agent_policy=cfg["agent_policy"], spawn_roads=cfg["spawn_roads"])
+                         agent_policy=cfg["agent_policy"], spawn_roads=cfg["spawn_roads"],
+                         destination=cfg["vehicle_config"]["destination"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
@@ -403,26 +404,32 @@ class BatchedEngine:
         self.k.track_len = int(self._tracks["shape"].shape[0])
 
     def _lidar_noise(self):
-        """LidarStateObservation._add_noise_to_cloud_points (obs/state_obs.py:234-244): gaussian noise (clipped to
-        [0,1]) then dropout to 0 on the lidar cloud of the observation.  The reference draws from the global,
+        """LidarStateObservation._add_noise_to_cloud_points (obs/state_obs.py:234-244) and the same call on the side /
+        lane-line detector clouds (state_obs.py:82-85,134-137): gaussian noise (clipped to [0,1]) then dropout to 0,
+        each cloud with its own detector's `gaussian_noise` / `dropout_prob`.  The reference draws from the global,
         unseeded numpy stream, so no stream can be 'the' stream; this one is a device generator seeded with
         start_seed + env_seed_offset (reproducible, shard-dependent)."""
-        lc = self.cfg["vehicle_config"]["lidar"]
-        g, p = float(lc["gaussian_noise"]), float(lc["dropout_prob"])
-        if (g <= 0.0 and p <= 0.0) or self.n_beams <= 0:
-            return
+        vc = self.cfg["vehicle_config"]
+        h = self.host
+        clouds = [(vc["lidar"], self.obs_dim - self.n_beams, self.n_beams),
+                  (vc["side_detector"], h.obs_base, h.n_side),
+                  (vc["lane_line_detector"], h.obs_base + (h.n_side or 2) + 6, h.n_ll)]
         torch = self.torch
-        if self._noise_gen is None:
-            self._noise_gen = torch.Generator(device=self.device)
-            self._noise_gen.manual_seed(int(self.cfg["start_seed"]) + int(self.cfg["env_seed_offset"]))
-        cloud = self.obs[..., self.obs_dim - self.n_beams:]
-        if g > 0.0:
-            noise = torch.empty_like(cloud).normal_(0.0, g, generator=self._noise_gen)
-            cloud.copy_((cloud + noise).clamp_(0.0, 1.0))
-        if p > 0.0:
-            assert p <= 1.0
-            drop = torch.empty_like(cloud).uniform_(0.0, 1.0, generator=self._noise_gen) < p
-            cloud.masked_fill_(drop, 0.0)
+        for dc, off, n in clouds:
+            g, p = float(dc["gaussian_noise"]), float(dc["dropout_prob"])
+            if (g <= 0.0 and p <= 0.0) or n <= 0:
+                continue
+            if self._noise_gen is None:
+                self._noise_gen = torch.Generator(device=self.device)
+                self._noise_gen.manual_seed(int(self.cfg["start_seed"]) + int(self.cfg["env_seed_offset"]))
+            cloud = self.obs[..., off:off + n]
+            if g > 0.0:
+                noise = torch.empty_like(cloud).normal_(0.0, g, generator=self._noise_gen)
+                cloud.copy_((cloud + noise).clamp_(0.0, 1.0))
+            if p > 0.0:
+                assert p <= 1.0
+                drop = torch.empty_like(cloud).uniform_(0.0, 1.0, generator=self._noise_gen) < p
+                cloud.masked_fill_(drop, 0.0)
 
     def line_detector(self, beams, n, dist, mask, out, stride, offset):
         self._check(self.lib.md_line_detector(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(beams.data_ptr()),

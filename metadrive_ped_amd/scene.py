@@ -131,7 +131,8 @@ class EnvScene:
             dynamics = dict(dynamics or {})
             dynamics.setdefault("mass", size["mass"])
         self._place_vehicle(0, agent_model, vehicle_seed, spawn_lane_index, cfg["spawn_longitude"],
-                            cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics)
+                            cfg["spawn_lateral"], dt, abi.F_ALIVE | abi.F_AGENT, overrides=dynamics,
+                            destination=cfg.get("destination"))
         if agent_model == "varying_dynamics":
             if size.get("length") is not None:
                 self.shape[0]["hl"] = float(size["length"]) / 2
@@ -331,7 +332,8 @@ class EnvScene:
         self.dyn[slot]["heading"] = heading
         return slot
 
-    def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags, overrides=None):
+    def _place_vehicle(self, slot, vtype, vehicle_seed, lane_index, longitude, lateral, dt, flags, overrides=None,
+                       destination=None):
         t = self.tables
         pg_map = t.pg_map
         lane = pg_map.net.lanes(lane_index[0], lane_index[1])[lane_index[2]]
@@ -355,7 +357,12 @@ class EnvScene:
         lane_id = t.lane_id[tuple(lane_index)]
         start_node = lane_index[0]
         dest = destination_for(pg_map, self.seed, lane_index)
+        if destination is not None:      # vehicle_config.destination: the agent's own end node (node_network_navigation.py:54-56)
+            dest = destination
         ckpts = pg_map.bfs_route(start_node, dest)
+        if destination is not None and (not ckpts or ckpts[-1] != destination):
+            raise ValueError("vehicle_config.destination {!r}: no route from {!r} on the map of seed {}".format(
+                destination, start_node, self.seed))
         ck0, ck1 = 0, 1
         if len(ckpts) <= 2:
             ckpts = [lane_index[0], lane_index[1]]

@@ -144,6 +144,22 @@ def test_discrete_actions_and_lidar_noise():
     assert (cloud >= 0).all() and (cloud <= 1).all()
     assert 0.05 < (cloud == 0.0).mean() < 0.2                            # ~10 % dropped
     assert not np.array_equal(cloud, ob_[:, 19:])
+    # the side / lane-line detector clouds take their own detectors' noise settings (state_obs.py:82-85,134-137)
+    det = dict(side_detector=dict(num_lasers=8, distance=50), lane_line_detector=dict(num_lasers=4, distance=20))
+    noisy = dict(side_detector=dict(num_lasers=8, distance=50, dropout_prob=0.5),
+                 lane_line_detector=dict(num_lasers=4, distance=20, gaussian_noise=0.1))
+    c, d = BatchedMetaDriveEnv(dict(base, vehicle_config=det)), BatchedMetaDriveEnv(dict(base, vehicle_config=noisy))
+    c.reset()
+    d.reset()
+    for t in range(20):
+        oc, *_ = c.step(torch.tensor([[0.0, 0.6]] * E))
+        od, *_ = d.step(torch.tensor([[0.0, 0.6]] * E))
+    oc, od = oc.cpu().numpy(), od.cpu().numpy()
+    side, ll = slice(0, 8), slice(14, 18)                                # [side 8 | 6 state dims | lane-line 4 | navi ...]
+    assert 0.2 < (od[:, side] == 0.0).mean() < 0.8 and (oc[:, side] > 0.0).all()
+    assert not np.allclose(od[:, ll], oc[:, ll]) and np.abs(od[:, ll] - oc[:, ll]).max() < 0.6
+    rest = np.r_[8:14, 18:oc.shape[1]]
+    assert np.array_equal(od[:, rest], oc[:, rest])                      # nothing else is touched (lidar noise is off)
 
 
 def test_record_then_replay_traffic():

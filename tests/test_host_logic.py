@@ -337,3 +337,21 @@ def test_lazy_info_behaves_like_a_dict_and_computes_on_first_read():
         info["nope"]
     info["extra"] = 3                                            # still an ordinary dict for writes
     assert info["extra"] == 3 and len(info) == 4
+
+
+def test_vehicle_config_destination_is_honoured():
+    """vehicle_config.destination (node_network_navigation.py:54-56): the agent's route ends at the node the user names
+    instead of the far socket of the last block; an unreachable node is an error."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    base = dict(num_envs=1, start_seed=3, map="SSS", traffic_density=0.0)
+    h0 = HostScene(make_config(dict(base)))
+    mt = h0.map_tables[0]
+    full = [mt.node_names[i] for i in h0.state["route_nodes"].reshape(1, -1, abi.MD_ROUTE_LEN)[0, 0] if i >= 0]
+    assert len(full) >= 4
+    mid = full[-2]
+    h1 = HostScene(make_config(dict(base, vehicle_config=dict(destination=mid))))
+    short = [h1.map_tables[0].node_names[i] for i in h1.state["route_nodes"].reshape(1, -1, abi.MD_ROUTE_LEN)[0, 0] if i >= 0]
+    assert short == full[:-1] and int(h1.state["nav0"]["route_len"][0]) == len(full) - 1
+    with pytest.raises(ValueError):
+        HostScene(make_config(dict(base, vehicle_config=dict(destination="no_such_node"))))
