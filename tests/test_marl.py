@@ -621,3 +621,36 @@ def test_user_spawn_roads_are_honoured():
         HostScene(BatchedMultiAgentRoundaboutEnv(dict(num_envs=1, spawn_roads=[["nowhere", "else"]])).config)
     inf = BatchedMultiAgentRoundaboutEnv(dict(num_envs=1, num_agents=-1, spawn_roads=two)).config
     assert inf["initial_agents"] == 2 * 2 * 6
+
+
+def test_respawn_known_answers_of_the_reference_test():
+    """tests/test_functionality/test_marl_reborn.py:5-75 on the oracle: two agents at full lock and full throttle leave the
+    road; the finishing step reports out_of_road, cost = out_of_road_cost (5555) and reward = -out_of_road_penalty (2222);
+    with delay_done = 0 the slot is refilled and the new agent takes the next name (agent2, agent3, ...); the env is
+    never 'all done'."""
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    E = 1
+    cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=2, out_of_road_cost=5555.0,
+                                              out_of_road_penalty=2222.0, delay_done=0, crash_done=False, horizon=100000)).config
+    host = HostScene(cfg)
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert list(o.state["agent_id"].reshape(E, -1)[0, :2]) == [0, 1]
+    names_seen, done_count = {0, 1}, 0
+    act = np.array([[[-1.0, 1.0], [1.0, 1.0]]], np.float32)
+    for i in range(1, 600):
+        o.step(act)
+        fl = o.state["flags"].reshape(E, -1)[0, :2]
+        sh = o.state["shape"].reshape(E, -1)[0, :2]
+        for a in range(2):
+            alive = (sh["flags"][a] & abi.F_ALIVE) != 0 and (sh["flags"][a] & abi.F_STATIC) == 0
+            if alive and (fl[a] & abi.FL_TERMINATED):
+                assert fl[a] & abi.FL_OUT_OF_ROAD
+                assert float(o.state["cost"].reshape(E, -1)[0, a]) == 5555.0
+                assert float(o.state["reward"].reshape(E, -1)[0, a]) == -2222.0
+                done_count += 1
+        names_seen |= {int(x) for x in o.state["agent_id"].reshape(E, -1)[0, :2]}
+        assert (((sh["flags"] & abi.F_ALIVE) != 0).any()) or int(o.state["next_agent_id"][0]) > 2     # never all gone for good
+    assert done_count >= 4 and names_seen >= set(range(2 + done_count - 1))      # names agent2, agent3, ... handed out in order
+    assert int(o.state["next_agent_id"][0]) == 2 + done_count or int(o.state["next_agent_id"][0]) == 1 + done_count
