@@ -621,3 +621,32 @@ def test_single_agent_env_on_a_map_with_a_parking_lot():
         if (arrived | bad).all():
             break
     assert arrived.sum() >= E - 1, (arrived, bad)
+
+
+def test_reward_cost_done_known_answers():
+    """tests/test_functionality/test_reward_cost_done.py (its live case and the three it keeps commented out): the terminal
+    step of an episode reports the configured reward / cost of its cause -- success 1111 / 0, out of road -2222 / 5555,
+    crash vehicle -3333 / 6666, crash object -4444 / 7777."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    rewards = dict(success_reward=1111, out_of_road_penalty=2222, crash_vehicle_penalty=3333, crash_object_penalty=4444,
+                   out_of_road_cost=5555, crash_vehicle_cost=6666, crash_object_cost=7777)
+
+    def run(extra, action, want_flag, steps=1000):
+        h = HostScene(make_config(dict(rewards, num_envs=1, auto_reset=False, horizon=5000, **extra)))
+        o = ob.OracleWorld(h)
+        o.reset()
+        for _ in range(steps):
+            o.step(np.array([[action]], np.float32))
+            fl = int(o.state["flags"][0])
+            if fl & (abi.FL_TERMINATED | abi.FL_TRUNCATED):
+                break
+        assert fl & want_flag, hex(fl)
+        return float(o.state["reward"][0]), float(o.state["cost"][0])
+
+    assert run(dict(map="S", traffic_density=0.0), [0.0, 1.0], abi.FL_ARRIVE_DEST) == (1111.0, 0.0)
+    assert run(dict(map="S", traffic_density=0.0), [1.0, 1.0], abi.FL_OUT_OF_ROAD) == (-2222.0, 5555.0)
+    assert run(dict(map="SSS", traffic_density=1.0, start_seed=1), [0.0, 1.0], abi.FL_CRASH_VEHICLE) == (-3333.0, 6666.0)
+    r, c = run(dict(map="SSS", traffic_density=0.0, accident_prob=1.0, start_seed=5), [0.0, 1.0],
+               abi.FL_CRASH_OBJECT | abi.FL_CRASH_VEHICLE)
+    assert (r, c) in ((-4444.0, 7777.0), (-3333.0, 6666.0))      # a cone / barrier, or the broken-down car of the scene
