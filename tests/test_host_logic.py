@@ -355,3 +355,16 @@ def test_vehicle_config_destination_is_honoured():
     assert short == full[:-1] and int(h1.state["nav0"]["route_len"][0]) == len(full) - 1
     with pytest.raises(ValueError):
         HostScene(make_config(dict(base, vehicle_config=dict(destination="no_such_node"))))
+
+
+def test_examples_and_tools_compile():
+    """The runnable scripts need an MI355X; here they at least have to be valid Python."""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "examples", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")) + \
+        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) >= 12
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
