@@ -361,10 +361,11 @@ def test_examples_and_tools_compile():
     """The runnable scripts need an MI355X; here they at least have to be valid Python."""
     import glob
     import os
-    import py_compile
+    import ast
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = glob.glob(os.path.join(root, "examples", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")) + \
         [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
     assert len(files) >= 12
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        with open(f) as fh:
+            ast.parse(fh.read(), filename=f)
