@@ -12,17 +12,33 @@ For N>1 every rank owns 4096 envs of the global batch (weak scaling, no data-pat
 are independent worlds); rank 0 prints ONE JSON line.  Inputs (state, maps, actions) are resident in
 HBM when the timed region starts.
 
+Launching: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N
+rank processes ITSELF (fresh children of a parent that never touches the GPU); under torchrun
+(WORLD_SIZE set) it is one rank and WORLD_SIZE must equal --gpus.
+
+Steady state: the timed region starts after an UNTIMED pre-roll (--preroll, default 300 steps)
+whatever --warmup says, so that the batch holds its stationary mix of episode phases (traffic blocks
+triggered, envs resetting at the stationary rate), and lasts at least 50 ms (the K steps are repeated
+R times; `timed_steps` = R*K).  The per-launch kernel duration in `roofline` is taken with HIP events
+over that SAME region, and the line is refused (exit 3) if the two disagree.
+
 Extra objects in the JSON line:
   roofline     the fused step kernel: algorithmic bytes per launch / average launch duration
-               (HIP events on the launch stream) against the HBM peak
+               (HIP events on the launch stream over the timed region) against the HBM peak
   lidar        the stand-alone md_lidar kernel measured the same way (bytes = 16 + 24*M + 4*B per agent)
-  cpu_baseline the CPU oracle (oracle/md_oracle.c, "port") on the host cores, bounded sample
-  with_gather  (N>1) the same K steps followed by an RCCL all_gather of (obs, reward, flags)
+  cpu_baseline the CPU oracle (oracle/md_oracle.c, "port", rebuilt -O3 -march=native on this host) on the
+               host cores, bounded sample
+  env_api      the same steps through BatchedMetaDriveEnv.step (the Gymnasium-shaped boundary: done flags,
+               lazy info dict)
+  with_gather  (N>1) the same K steps followed by an RCCL all_gather of (obs, reward)
 """
 import argparse
-import ctypes as C
 import json
+import math
 import os
+import pickle
+import socket
+import subprocess
 import sys
 import time
 from collections import OrderedDict
@@ -32,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3   # vector FP32, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+MIN_TIMED_S = 0.05
 
 
 def parse():
@@ -39,17 +56,24 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=300)
     p.add_argument("--warmup", type=int, default=30)
+    p.add_argument("--preroll", type=int, default=300,
+                   help="untimed steps after reset() before --warmup: the batch reaches its stationary episode mix")
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--cap", type=int, default=0, help="mover slots per env (0 = smallest that fits)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-lane-follow", action="store_true", help="skip the scripted-driver operating point")
+    p.add_argument("--no-env-api", action="store_true", help="skip the BatchedMetaDriveEnv.step leg")
     p.add_argument("--sub-batches", type=int, default=2,
                    help="double-buffered leg (N=1): the same envs as S sub-batches on S HIP streams; 0 or 1 = skip")
-    p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl", "replay"],
+    p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl", "replay", "scenario"],
                    help="metadrive = BASELINE configs[1] (the headline line); safe = configs[3] per-GPU shard (8192 "
-                        "SafeMetaDriveEnv); marl = configs[2] (1024 x 40-agent roundabout, 240 beams)")
+                        "SafeMetaDriveEnv); marl = configs[2] (1024 x 40-agent roundabout, 240 beams); scenario = "
+                        "configs[4] (2048 ScenarioEnv scenes, reactive TrajectoryIDM traffic, synthetic scenario data)")
     p.add_argument("--cpu-envs", type=int, default=2048)
     p.add_argument("--cpu-steps", type=int, default=100)
+    p.add_argument("--host-cache", default="",
+                   help="pickle of the host-side scenes (written if absent, read if present): profiled runs load it "
+                        "instead of forking map-builder workers from a process whose GPU the profiler has initialised")
     return p.parse_args()
 
 
@@ -60,28 +84,105 @@ def cs_dist():
     return d
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes.  This parent has
+    not imported torch and never touches the GPU; it waits and exits with the first non-zero child code."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = env.get("MASTER_PORT") or str(_free_port())
+    env["WORLD_SIZE"] = str(args.gpus)
+    env["MD_BENCH_CHILD"] = "1"
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:   # a dead rank leaves the others in a collective: end them (exact PIDs, our own children)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def cpu_threads():
+    """Host threads this process may really use: the cgroup CPU quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(math.ceil(float(quota) / float(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def build_fast_oracle():
+    """The CPU baseline's build of the oracle: -O3 -march=native for THIS host (the parity tests keep the -O2 build;
+    -ffp-contract=off stays, so the numbers do not change).  Built at bench time: -march=native code must not travel."""
+    out = os.path.join(ROOT, "oracle", "_build", "libmdoracle_native.so")
+    subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "native"])
+    return out
+
+
+def load_or_build_hosts(path, build):
+    if path and os.path.exists(path):
+        with open(path, "rb") as fh:   # our own file, written by the branch below
+            return pickle.load(fh)
+    hosts = build()
+    if path:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "wb") as fh:
+            pickle.dump(hosts, fh, protocol=4)
+    return hosts
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d: launch with `python bench.py --gpus N` (it starts the ranks "
+                 "itself) or with torchrun --nproc-per-node N ... --gpus N" % (world, args.gpus))
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (every rank on cuda:0, gloo instead of RCCL, host tensors
     # for the two collectives): exercises rank / seed / barrier / reduction / printing logic, measures nothing.
     rehearse = os.environ.get("MD_BENCH_REHEARSE_ONE_GPU") == "1"
     if rehearse:
         local_rank = 0
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # every rank builds its own 4096 maps: share the host cores
+        os.environ.setdefault("MD_BUILD_WORKERS", str(max(1, min(32, (os.cpu_count() or 8) // world))))
     import torch
     import torch.distributed as dist
     from metadrive_ped_amd.config import make_config
-    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     E = args.envs
     common = dict(num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0,
                   mover_capacity=args.cap, auto_reset=True, device="cuda:%d" % local_rank)
+    env_cls = None
     if args.workload == "metadrive":
-        cfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=1000))
+        user = dict(common, map=3, traffic_density=0.1, horizon=1000)
+        cfg = make_config(user)
         label = ("BASELINE configs[1]: %d batched MetaDriveEnv per GPU, 3-block PG map (reference default block "
                  "distribution: curves, straights, ramps, X/T intersections, roundabouts), 240-beam lidar, "
                  "traffic_density=0.1, trigger traffic, auto-reset" % E)
@@ -90,7 +191,8 @@ def main():
             E = common["num_envs"] = 8192
             common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
         from metadrive_ped_amd.envs.metadrive_env import BatchedSafeMetaDriveEnv
-        cfg = make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, horizon=1000)))
+        user = dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, **dict(common, map=3, horizon=1000))
+        cfg = make_config(user)
         label = "BASELINE configs[3] shard: %d SafeMetaDriveEnv per GPU (accident_prob 0.8, density 0.05), 240 beams" % E
     elif args.workload == "replay":
         if args.envs == 4096:
@@ -99,6 +201,14 @@ def main():
         cfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="replay"))
         label = ("BASELINE configs[4] stand-in: %d envs replaying recorded traffic tracks (200 frames, non-reactive) on 3-block "
                  "PG maps, 240-beam lidar -- ScenarioNet data is not available here" % E)
+    elif args.workload == "scenario":
+        if args.envs == 4096:
+            E = common["num_envs"] = 2048
+            common["num_scenarios"], common["env_seed_offset"] = E * max(world, 1), rank * E
+        from metadrive_ped_amd.envs.scenario_env import scenario_bench_config
+        cfg = scenario_bench_config(common)
+        label = ("BASELINE configs[4]: %d ScenarioEnv scenes per GPU (synthetic scenario descriptions: polyline lanes, "
+                 "recorded tracks), reactive TrajectoryIDMPolicy traffic, 240-beam lidar" % E)
     else:
         if args.envs == 4096:
             E = common["num_envs"] = 1024
@@ -106,34 +216,58 @@ def main():
         from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
         cfg = BatchedMultiAgentRoundaboutEnv(dict(common, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50)))).config
         label = "BASELINE configs[2]: %d MultiAgentRoundaboutEnv x 40 agents per GPU, 240-beam lidar, respawn on" % E
-    # host-side scene generation happens BEFORE the GPU / process group are touched (fork pool inside)
+
+    # ---- host-side scene generation: ALL of it happens BEFORE the GPU / process group are touched (fork pools
+    #      inside HostScene), including the scenes of the CPU baseline and of the extra legs ----
     t0 = time.time()
-    from metadrive_ped_amd.engine import HostScene
-    host = HostScene(cfg)
-    rhost = None
-    if args.workload == "replay":   # the recording run's scenes: also built before the GPU is touched (fork pool)
-        rcfg = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="trigger"))
-        rhost = HostScene(rcfg)
-    # double-buffered leg: the same environments as S sub-batches (envs/pipeline.py); their scenes too are generated
-    # before the GPU is touched
+    want_sub = (world == 1 and args.sub_batches > 1 and args.workload in ("metadrive", "safe", "marl")
+                and E % args.sub_batches == 0)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "metadrive"
+    n_cpu = min(args.cpu_envs, E)
+    n_cpu1 = max(1, n_cpu // 16)
+
+    def build_hosts():
+        h = dict(main=HostScene(cfg))
+        if args.workload == "replay":   # the recording run's scenes
+            h["rcfg"] = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="trigger"))
+            h["record"] = HostScene(h["rcfg"])
+        if want_sub:
+            if args.workload == "marl":
+                sub_user = dict(common, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50)))
+            else:
+                sub_user = dict(common, map=3, horizon=1000, mover_capacity=h["main"].cap)
+                sub_user.update(dict(traffic_density=0.1) if args.workload == "metadrive" else BatchedSafeMetaDriveEnv.SAFE_DEFAULTS)
+                sub_user.update(num_scenarios=common["num_scenarios"])
+            h["sub_user"] = sub_user
+            from metadrive_ped_amd.envs.pipeline import SubBatchedEnvs
+            from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
+            sub_ = SubBatchedEnvs(BatchedMultiAgentRoundaboutEnv if args.workload == "marl" else BatchedMetaDriveEnv,
+                                  sub_user, sub_batches=args.sub_batches)
+            h["sub_hosts"] = sub_.build_host()
+        if want_cpu:
+            for key, n in (("cpu", n_cpu), ("cpu1", n_cpu1)):
+                c = dict(cfg)
+                c["num_envs"] = n
+                h[key] = HostScene(c)
+        return h
+
+    hosts = load_or_build_hosts(args.host_cache, build_hosts)
+    host = hosts["main"]
+    cpu_lib = build_fast_oracle() if want_cpu else None
+    build_s = time.time() - t0
+
+    torch.cuda.set_device(local_rank)
     sub = None
-    if world == 1 and args.sub_batches > 1 and args.workload in ("metadrive", "safe", "marl") and E % args.sub_batches == 0:
+    if want_sub and "sub_hosts" in hosts:
         from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
         from metadrive_ped_amd.envs.pipeline import SubBatchedEnvs
-        if args.workload == "marl":
-            sub = SubBatchedEnvs(BatchedMultiAgentRoundaboutEnv,
-                                 dict(common, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50))), sub_batches=args.sub_batches)
-        else:
-            user = dict(common, map=3, horizon=1000, mover_capacity=host.cap)
-            user.update(dict(traffic_density=0.1) if args.workload == "metadrive" else BatchedSafeMetaDriveEnv.SAFE_DEFAULTS)
-            user.update(num_scenarios=common["num_scenarios"])
-            sub = SubBatchedEnvs(BatchedMetaDriveEnv, user, sub_batches=args.sub_batches)
-        sub.build_host()
-    torch.cuda.set_device(local_rank)
+        sub = SubBatchedEnvs(BatchedMultiAgentRoundaboutEnv if args.workload == "marl" else BatchedMetaDriveEnv,
+                             hosts["sub_user"], sub_batches=args.sub_batches)
+        sub._hosts = hosts["sub_hosts"]
     tracks = None
     if args.workload == "replay":
         # record the tracks first: the same scenarios with reacting (trigger-mode IDM) traffic, 200 steps
-        reng = BatchedEngine(rcfg, host=rhost)
+        reng = BatchedEngine(hosts["rcfg"], host=hosts["record"])
         reng.reset()
         reng.start_recording(200)
         g0 = torch.Generator(device="cpu")
@@ -148,7 +282,6 @@ def main():
     eng = BatchedEngine(cfg, host=host)
     if tracks is not None:
         eng.set_tracks(tracks)
-    build_s = time.time() - t0
     if world > 1:
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -172,20 +305,41 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def run(k, base=0):
-        for i in range(k):
-            eng.step(actions[(base + i) % n_act])
+    cursor = [0]
+
+    def run(k):
+        for _ in range(k):
+            eng.step(actions[cursor[0] % n_act])
+            cursor[0] += 1
+
+    # ---- untimed pre-roll to the stationary episode mix, whatever --warmup is ----
+    tp = time.perf_counter()
+    run(max(args.preroll, 0))
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - tp) / max(args.preroll, 1) if args.preroll > 0 else 1e-4
+    repeats = max(1, int(math.ceil(MIN_TIMED_S / max(args.steps * est, 1e-9))))
+    rep_t = torch.tensor([repeats], dtype=torch.int64, device="cpu" if (rehearse or world == 1) else dev)
+    if world > 1:
+        dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)    # every rank times the same number of steps
+    repeats = int(rep_t.item())
+    timed_steps = args.steps * repeats
 
     run(args.warmup)
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup)
+    ev_a.record()
+    run(timed_steps)
+    ev_b.record()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # one event pair around the whole timed region (a pair per launch adds ~8 us of its own to each kernel): the
+    # quotient contains the ~1.5 us dependent-launch gaps; rocprofv3's per-kernel average agrees to a few per cent
+    step_ms_avg = ev_a.elapsed_time(ev_b) / timed_steps
     el = torch.tensor([elapsed], device="cpu" if rehearse else dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -193,29 +347,20 @@ def main():
     # multi-agent: only slots holding a live agent count as agent-steps (dying / free slots do not)
     sf = eng.shape_f.view(torch.int32)[:, :A, 6]
     active_frac = float((((sf & 0x10) != 0) & ((sf & 0x80) == 0)).float().mean().item()) if A > 1 else 1.0
-    total_agent_steps = args.steps * E * A * world * active_frac
+    total_agent_steps = timed_steps * E * A * world * active_frac
     value = total_agent_steps / elapsed
+    ms_per_step = elapsed / timed_steps * 1e3
+    if world == 1 and ms_per_step < step_ms_avg / 1.05:
+        sys.stderr.write("bench.py: inconsistent timing: wall %.4f ms/step < HIP-event %.4f ms/launch over the same %d "
+                         "steps; refusing to print a line\n" % (ms_per_step, step_ms_avg, timed_steps))
+        sys.exit(3)
 
-    # ---- per-launch duration of the fused step kernel with HIP events on the launch stream ----
-    # One event pair around a batch of back-to-back launches (a pair per launch adds ~8 us of its own to a 100 us
-    # kernel); the quotient contains the ~1.5 us dependent-launch gaps, which is what rocprofv3's per-kernel
-    # average agrees with to a few per cent.
-    # (Fresh actions every launch, like the timed loop: with one action repeated the envs fall into short, cheap
-    # episodes and the kernel looks 25 % faster than it is.)
-    n_ev = 50
-    torch.cuda.synchronize()
-    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev_a.record()
-    for i in range(n_ev):
-        eng.step(actions[i % n_act])
-    ev_b.record()
-    torch.cuda.synchronize()
-    step_ms_avg = ev_a.elapsed_time(ev_b) / n_ev
     # present movers per env right now (alive, kind != none)
     flags = eng.shape_f.view(torch.int32)[..., 6]
     present = ((flags & 0x10) != 0) & ((flags & 0xF) != 0)
     M = float(present.sum().item()) / E           # movers per env (agents + traffic)
     T = M - A
+    drv_now = float((((flags & 0x10) != 0) & ((flags & 0x40) == 0) & ((flags & 0xF) == 1) & ((flags & 0x80) == 0)).sum().item()) / E
     # whole step per agent ~ 2.6 KB + 136 B * T/A  (state R/W, action, navi/route, obs, flags)
     bytes_step = (2600.0 + 136.0 * T / A) * E * A
     achieved = bytes_step / (step_ms_avg * 1e-3) / 1e9
@@ -226,15 +371,18 @@ def main():
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("workload") == args.workload and E == 4096:
-            traffic, traffic_src = pmc["bytes_per_launch"].get("env_kernel<511>"), "profiles/" + pmc["source"]
+            traffic, traffic_src = (pmc["bytes_per_launch"].get("step_kernel") or pmc["bytes_per_launch"].get("env_kernel<511>")), "profiles/" + pmc["source"]
     except (OSError, ValueError, KeyError):
         pass
-    roofline = dict(bound="hbm", kernel="env_kernel<511> (fused md_step)", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
+    roofline = dict(bound="hbm", kernel="fused md_step kernel", achieved=round(achieved, 2), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic, traffic_source=traffic_src,
                     bytes_per_launch=int(bytes_step), avg_launch_us=round(step_ms_avg * 1e3, 2),
-                    movers_per_env=round(M, 2))
+                    movers_per_env=round(M, 2), driving_vehicles_per_env=round(drv_now, 2),
+                    limiter="instruction issue / dependent-chain latency, not HBM: the path moves ~15 MB per launch "
+                            "(SURVEY 8d); frac is the BASELINE metric, not a claim that HBM bounds the kernel")
 
     # ---- stand-alone lidar kernel ----
+    n_ev = 50
     out = torch.empty(E * A, B, device=dev)
     ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     eng.lidar(out, B, 0)
@@ -246,7 +394,7 @@ def main():
     torch.cuda.synchronize()
     lid_ms = ev_a.elapsed_time(ev_b) / n_ev
     bytes_lidar = (16.0 + 24.0 * (M - 1) + 4.0 * B) * E * A
-    lidar = dict(kernel="env_kernel<128> (md_lidar)", avg_launch_us=round(lid_ms * 1e3, 2),
+    lidar = dict(kernel="lidar_kernel (md_lidar)", avg_launch_us=round(lid_ms * 1e3, 2),
                  achieved=round(bytes_lidar / (lid_ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                  frac=round(bytes_lidar / (lid_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), bytes_per_launch=int(bytes_lidar),
                  flops_per_launch=int(30.0 * B * (M - 1) * E * A))
@@ -272,6 +420,30 @@ def main():
     lidar["fp32_tflops"] = round(lidar["flops_per_launch"] / (lid_ms * 1e-3) / 1e12, 2)
     lidar["fp32_peak_tflops"] = FP32_PEAK_TFLOPS
     lidar["fp32_frac"] = round(lidar["fp32_tflops"] / FP32_PEAK_TFLOPS, 4)
+
+    # ---- the Gymnasium-shaped boundary (N=1, single-agent): BatchedMetaDriveEnv.step on the same scenes and the
+    #      same actions: engine.step + the (terminated, truncated) flags + the lazy info dict, per step ----
+    env_api = None
+    if rank == 0 and world == 1 and A == 1 and args.workload in ("metadrive", "safe") and not args.no_env_api:
+        from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
+        env = BatchedMetaDriveEnv(dict(user, mover_capacity=host.cap) if args.workload == "metadrive" else
+                                  dict(user, mover_capacity=host.cap))
+        env.lazy_init(host=host)
+        env.reset()
+        acts2 = actions[:, :, 0, :].contiguous()
+        for i in range(max(args.preroll, 0)):
+            env.step(acts2[i % n_act])
+        torch.cuda.synchronize()
+        n_api = max(args.steps, int(math.ceil(MIN_TIMED_S / max(est, 1e-9))))
+        t0 = time.perf_counter()
+        for i in range(n_api):
+            o_, r_, te_, tr_, info_ = env.step(acts2[i % n_act])
+        torch.cuda.synchronize()
+        dt_api = time.perf_counter() - t0
+        env_api = dict(value=round(n_api * E / dt_api, 1), unit="agent-steps/s", ms_per_step=round(dt_api / n_api * 1e3, 4),
+                       steps=n_api, surface="BatchedMetaDriveEnv.step -> (obs, reward, terminated, truncated, LazyInfo): "
+                                            "one md_step launch + one fused flag test per step, info values on demand")
+        env.close()
 
     # ---- second operating point (N=1, single-agent workloads): a scripted lane-following driver instead of random
     #      actions.  Episodes last several hundred steps, more traffic blocks get triggered (about twice the driving
@@ -322,16 +494,16 @@ def main():
                     with sub.on(k):
                         env.engine.step(sub_acts[k][(base + i) % n_act])
 
-        run_sub(args.warmup)
+        run_sub(max(args.preroll, 0) + args.warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_sub(args.steps, args.warmup)
+        run_sub(timed_steps, args.preroll + args.warmup)
         torch.cuda.synchronize()
         dt_db = time.perf_counter() - t0
         sf_db = torch.cat([e_.engine.shape_f.view(torch.int32)[:, :A, 6] for e_ in sub.envs])
         act_db = float((((sf_db & 0x10) != 0) & ((sf_db & 0x80) == 0)).float().mean().item()) if A > 1 else 1.0
-        double_buffered = dict(value=round(args.steps * E * A * act_db / dt_db, 1), unit="agent-steps/s", sub_batches=S,
-                               envs_per_sub_batch=E // S, ms_per_step=round(dt_db / args.steps * 1e3, 4),
+        double_buffered = dict(value=round(timed_steps * E * A * act_db / dt_db, 1), unit="agent-steps/s", sub_batches=S,
+                               envs_per_sub_batch=E // S, ms_per_step=round(dt_db / timed_steps * 1e3, 4),
                                note="same %d envs, same actions; one step = one md_step launch per sub-batch, each on "
                                     "its own HIP stream; no cross-stream wait inside the timed region" % E)
         sub.close()
@@ -357,38 +529,31 @@ def main():
         barrier()
         eg = torch.tensor([time.perf_counter() - t0], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(eg, op=dist.ReduceOp.MAX)
-        with_gather = dict(value=round(total_agent_steps / float(eg.item()), 1), unit="agent-steps/s",
+        with_gather = dict(value=round(args.steps * E * A * world * active_frac / float(eg.item()), 1), unit="agent-steps/s",
                            collective="all_gather_into_tensor(obs,reward)")
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "metadrive":
+    if want_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import numpy as np
         import oracle_binding as ob
-        from metadrive_ped_amd.engine import HostScene
-        n_cpu = min(args.cpu_envs, E)
-        ccfg = dict(cfg)
-        ccfg["num_envs"] = n_cpu
-        host = HostScene(ccfg)
-        orc = ob.OracleWorld(host)
-        # the GPU box gives one GPU's job a 16-CPU share, whatever os.cpu_count() says
-        cores = min(len(os.sched_getaffinity(0)), 16)
+        cores = cpu_threads()
+        lib = ob.load(cpu_lib)
+        orc = ob.OracleWorld(hosts["cpu"], lib=lib)
         orc.reset()
         acts = actions[:, :n_cpu].cpu().numpy()
+        for i in range(20):               # untimed: first touches, and the traffic starts to wake up
+            orc.step(acts[i % n_act], threads=cores)
         t0 = time.perf_counter()
         for i in range(args.cpu_steps):
             orc.step(acts[i % n_act], threads=cores)
         dt = time.perf_counter() - t0
         # single thread, on a slice of the same envs (SURVEY 8d asks for both figures)
-        n1 = max(1, n_cpu // 16)
-        ccfg1 = dict(cfg)
-        ccfg1["num_envs"] = n1
-        orc1 = ob.OracleWorld(HostScene(ccfg1))
+        orc1 = ob.OracleWorld(hosts["cpu1"], lib=lib)
         orc1.reset()
         t1 = time.perf_counter()
         for i in range(args.cpu_steps):
-            orc1.step(acts[i % n_act][:n1], threads=1)
+            orc1.step(acts[i % n_act][:n_cpu1], threads=1)
         dt1 = time.perf_counter() - t1
         try:
             with open("/proc/cpuinfo") as fh:
@@ -396,23 +561,25 @@ def main():
         except (OSError, IndexError):
             cpu_model = "unknown"
         cpu_baseline = dict(value=round(n_cpu * A * args.cpu_steps / dt, 1), unit="agent-steps/s", cores=cores, kind="port",
-                            sample="%d envs x %d steps of the same workload, oracle/md_oracle.c ref_step_mt on %d threads"
-                                   % (n_cpu, args.cpu_steps, cores),
-                            single_thread_value=round(n1 * A * args.cpu_steps / dt1, 1),
-                            single_thread_sample="%d envs x %d steps, 1 thread" % (n1, args.cpu_steps),
+                            sample="%d envs x %d steps of the same workload, oracle/md_oracle.c (gcc -O3 -march=native) "
+                                   "ref_step_mt on %d threads" % (n_cpu, args.cpu_steps, cores),
+                            single_thread_value=round(n_cpu1 * A * args.cpu_steps / dt1, 1),
+                            single_thread_sample="%d envs x %d steps, 1 thread" % (n_cpu1, args.cpu_steps),
                             cpu_model=cpu_model, nproc=os.cpu_count())
 
     if rank == 0:
         line = OrderedDict(
             metric="agent-steps/sec at 4096 envs x 240-beam lidar" if args.workload == "metadrive" else
             "agent-steps/sec (%s workload)" % args.workload, value=round(value, 1), unit="agent-steps/s",
-            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 4),
+            n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
             higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=label,
                         envs_per_gpu=E, active_agent_fraction=round(active_frac, 3), agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
-            roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, lane_follow_policy=lane_follow, double_buffered=double_buffered, with_gather=with_gather,
-            host_build_s=round(build_s, 1))
+            preroll=args.preroll, timed_steps=timed_steps,
+            roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, env_api=env_api, lane_follow_policy=lane_follow,
+            double_buffered=double_buffered, with_gather=with_gather, host_build_s=round(build_s, 1))
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -1238,12 +1238,12 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         __syncthreads();
     }
     MD_STAMP_AT(4);
+    unsigned long long drv_lo = 0ull, drv_hi = 0ull;  // fused step: the slots that drive in this step (wave-uniform)
     if (kFused) {
         // Localisation and contacts of a vehicle are independent of each other (both only read the integrated
         // poses and the map), so they share ONE stage: work items = [localize of every driving vehicle, then
         // contacts of every driving vehicle], dealt round-robin to the waves.  With the usual 1-3 driving
         // vehicles per env everything fits one round instead of two phases behind two barriers.
-        unsigned long long drv_lo = 0ull, drv_hi = 0ull;  // driving slots (wave-uniform)
         for (int j0 = 0; j0 < cap; j0 += 64) {
             const int j = j0 + lane;
             const unsigned long long mk = __ballot(j < cap && md_drives(s.shape[j < cap ? j : 0].flags));
@@ -1304,16 +1304,23 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MD_STAMP_AT(6);
     if (PH & PH_TRAFFIC) {
         for (int j = tid; j < cap; j += kBlock) {
-            if (kFused && md_drives(s.shape[j].flags))  // traffic slots carry no contact flags (l_cfl is written for agents only)
-                s.flags[j] = l_onlane[j] | ((s.shape[j].flags & MD_F_AGENT) ? l_cfl[j] : 0u);
+            // Fused step: "drives" comes from the masks built BEFORE the localisation, never from a re-read of the slot's
+            // flags: the last wave may already be inside trigger_env below, clearing MD_F_PENDING of slots that did
+            // not drive in this step (their l_onlane / l_cfl entries were never written).  Those slots are skipped
+            // here by construction, and the read-modify-write of a driving slot's flags cannot collide with the
+            // trigger's, which only touches PENDING slots.
+            const bool drove = kFused ? ((((j < 64) ? (drv_lo >> j) : (drv_hi >> (j - 64))) & 1ull) != 0ull) : false;
+            if (kFused && !drove) continue;
             const int f = s.shape[j].flags;
+            if (kFused)  // traffic slots carry no contact flags (l_cfl is written for agents only)
+                s.flags[j] = l_onlane[j] | ((f & MD_F_AGENT) ? l_cfl[j] : 0u);
             if (md_drives(f) && !(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) {
                 s.shape[j].flags = f & ~MD_F_ALIVE;
                 if (kFused) l_cfl[j] = kRemovedMark;  // the slot's last write-back (see the dirty-slot write-back)
             }
         }
         // next step's trigger: reads the agents' final lanes and the PENDING slots, which the removal above
-        // (driving slots only) does not touch
+        // (slots that drove in this step only) does not touch
         if (plan_ahead && wave == kWaves - 1) trigger_env(lanes, s, c, lane);
         __syncthreads();
         if (RESPAWN) {  // respawn / hybrid: the removed vehicle re-enters on a respawn lane (rare; serial)

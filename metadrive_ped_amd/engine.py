@@ -136,7 +136,16 @@ class HostScene:
                          destination=cfg["vehicle_config"]["destination"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
-        workers = int(cfg.get("build_workers", 0)) or min(os.cpu_count() or 1, 32)
+        workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
+        try:
+            # a process that has initialised the GPU must not fork (the children inherit a HIP runtime they cannot use,
+            # and under rocprofv3 the profiler's handlers): build serially then.  Callers that want the pool build the
+            # HostScene first (bench.py, SubBatchedEnvs.build_host) or pass a HostScene made elsewhere.
+            import torch
+            if torch.cuda.is_initialized():
+                workers = 1
+        except ImportError:
+            pass
         shared_map = cfg["is_multi_agent"] and cfg["marl_map"] != "pg"
         build_fn = _build_one
         if cfg["is_multi_agent"] and not cfg["mover_capacity"]:
@@ -288,6 +297,17 @@ def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
     return w, s, md_config
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 class BatchedEngine:
     def __init__(self, cfg, host=None):
         import torch
@@ -297,6 +317,7 @@ class BatchedEngine:
         self._check = _lib.check
         self.cfg = cfg
         self.device = torch.device(cfg["device"])
+        self._dev_index = self.device.index if self.device.index is not None else 0
         if self.device.type != "cuda":
             raise _lib.MdStepError("BatchedEngine needs a ROCm device (config['device']={!r}); there is no CPU "
                                    "fallback".format(cfg["device"]))
@@ -304,6 +325,9 @@ class BatchedEngine:
         self._noise_gen = None
         self._rec = None
         self._tracks = None
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+            self._dev_index = self.device.index
         self.build()
 
     # -- upload helpers ---------------------------------------------------------------------------
@@ -345,6 +369,15 @@ class BatchedEngine:
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _on_device(self):
+        """Context in which HIP's current device is the engine's (config["device"]): a no-op object when it already is
+        (the usual one-process-per-GPU case), torch.cuda.device(...) otherwise -- a launch must not land on another
+        device's stream because the caller's current device differs."""
+        cuda = self.torch.cuda
+        if cuda.current_device() == self._dev_index:
+            return _NULL_CTX
+        return cuda.device(self._dev_index)
+
     def reset(self):
         """All envs back to their reset snapshot; returns after the reset observation is computed.
         (BaseEnv.reset -> engine.reset -> _get_reset_return, envs/base_env.py:502-584)"""
@@ -355,6 +388,10 @@ class BatchedEngine:
     LANE_LINE_MASK = SIDE_MASK | (1 << abi.Q_LINE_BROKEN)                         # ... | BrokenLaneLine
 
     def step_raw(self):
+        with self._on_device():
+            self._step_raw()
+
+    def _step_raw(self):
         self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
         h = self.host
         if h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
@@ -464,9 +501,14 @@ class BatchedEngine:
     def call(self, name):
         """Single-phase entry points (parity tests): md_integrate, md_localize, ..."""
         fn = getattr(self.lib, name)
-        self._check(fn(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), name)
+        with self._on_device():
+            self._check(fn(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), name)
 
     def lidar(self, out, stride, offset):
+        with self._on_device():
+            self._lidar(out, stride, offset)
+
+    def _lidar(self, out, stride, offset):
         self._check(self.lib.md_lidar(C.byref(self.w), C.byref(self.s), C.byref(self.k), C.c_void_p(out.data_ptr()),
                                       stride, offset, self._stream()), "md_lidar")
 

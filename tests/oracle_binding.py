@@ -12,20 +12,21 @@ from metadrive_ped_amd.engine import make_structs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libmdoracle.so")
-_LIB = None
+_LIBS = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
-def load():
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    if not os.path.exists(ORACLE_SO):
-        build()
-    lib = C.CDLL(ORACLE_SO)
+def load(path=None):
+    """path: another build of the same source (bench.py's -O3 -march=native one); default = the -O2 checker."""
+    path = path or ORACLE_SO
+    if path in _LIBS:
+        return _LIBS[path]
+    if path == ORACLE_SO:
+        build()     # make: a no-op when up to date, so a stale oracle never checks a newer header
+    lib = C.CDLL(path)
     W, S, K = C.POINTER(abi.MdWorld), C.POINTER(abi.MdState), C.POINTER(abi.MdConfig)
     for name in ("ref_integrate", "ref_localize", "ref_contacts", "ref_observe", "ref_idm", "ref_traffic_after_step",
                  "ref_lifecycle", "ref_step"):
@@ -73,8 +74,8 @@ def load():
     lib.ref_idm_steer.argtypes = [C.c_void_p, f, f, f, C.c_void_p]
     lib.ref_front_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, f, f, C.c_void_p, C.c_void_p]
     lib.ref_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    abi.check_abi(lib.ref_abi, ORACLE_SO)
-    _LIB = lib
+    abi.check_abi(lib.ref_abi, path)
+    _LIBS[path] = lib
     return lib
 
 
@@ -85,8 +86,8 @@ def _ptr(a):
 
 class OracleWorld:
     """The oracle running on a HostScene's tables with its own copy of the state."""
-    def __init__(self, host, state=None):
-        self.lib = load()
+    def __init__(self, host, state=None, lib=None):
+        self.lib = lib or load()
         self.host = host
         self.state = state if state is not None else host.clone_state()
         wa = dict(host.world.arrays)
