@@ -442,6 +442,23 @@ MD_HD int md_idm_is_candidate(const MdShape* o, float px, float py) {
     return md_obb_circle(o->cx, o->cy, o->c, o->s, o->hl, o->hw, px, py, 50.0f);
 }
 
+/* A pedestrian or cyclist among the surrounding objects: BaseTrafficParticipant has no `.lane`
+ * (component/traffic_participants/base_traffic_participant.py:12-32), so FrontBackObjects.get_find_front_back_objs
+ * raises AttributeError at `obj.lane is lane` (policy/idm_policy.py:110) as soon as its object loop reaches it -- and it
+ * always does, the routing target lane is never None there -- before lane_change_policy has touched target_speed or
+ * overtake_timer.  IDMPolicy.act catches everything (:254-260): front object None, distance 5, steering lane = the
+ * routing target lane, for THAT vehicle in THAT step.  (move_to_next_road has already run: its effects stay.) */
+MD_HD int md_is_participant_kind(int k) { return k == MD_KIND_PEDESTRIAN || k == MD_KIND_CYCLIST; }
+
+MD_HD int md_idm_sees_participant(const MdState* s, const MdConfig* c, int self_slot, float px, float py) {
+    for (int j = 0; j < c->cap; ++j) {
+        if (j == self_slot) continue;
+        const MdShape* o = &s->shape[j];
+        if (md_is_participant_kind(md_kind_of(o->flags)) && md_idm_is_candidate(o, px, py)) return 1;
+    }
+    return 0;
+}
+
 /* obj.lane: vehicles carry their localised lane, props the lane they were placed on */
 MD_HD int md_obj_lane_of(const MdState* s, int j) {
     const MdShape* o = &s->shape[j];
@@ -723,6 +740,7 @@ MD_HD void md_idm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c,
         fb.exist[i] = 0;
         fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
     }
+    if (!plan.fail && md_idm_sees_participant(s, c, slot, s->shape[slot].cx, s->shape[slot].cy)) plan.fail = 1;
     if (!plan.fail) md_find_front_back(s, c, lanes, slot, &plan, s->shape[slot].cx, s->shape[slot].cy, &fb);
     md_idm_decide(lanes, roads, s, slot, &plan, &fb);
 }

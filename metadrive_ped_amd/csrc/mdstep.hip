@@ -645,13 +645,19 @@ __device__ __forceinline__ void idm_vehicle_wave(const MdWorld& w, const MdLane*
         // candidate objects (get_surrounding_objects: within 50 m, present, not the vehicle itself), compacted in
         // ascending slot order into wave_list: usually a handful, whatever the slot capacity is
         int n_cand = 0;
+        bool sees_participant = false;  // a pedestrian / cyclist among them: the reference's object loop raises (md_idm_sees_participant)
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
             const int j = j0 + lane_id;
             const bool is_c = j < c.cap && j != slot && md_idm_is_candidate(&s.shape[j < c.cap ? j : 0], px, py);
             const unsigned long long mk = __ballot(is_c);
+            if (__ballot(is_c && md_is_participant_kind(md_kind_of(s.shape[j < c.cap ? j : 0].flags))) != 0ull) sees_participant = true;
             const int rank = n_cand + __popcll(mk & ((1ull << lane_id) - 1ull));
             if (is_c && rank < 21) wave_list[rank] = j;
             n_cand += __popcll(mk);
+        }
+        if (sees_participant) {  // wave-uniform: bare-except fallback, nothing is scanned
+            plan.fail = 1;
+            n_cand = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -598,6 +598,208 @@ def section_idm():
     dump("idm.json", out)
 
 
+def section_idm_policy():
+    """IDMPolicy.act (policy/idm_policy.py:235-267) end to end on fake vehicles: move_to_next_road (:269-291),
+    lane_change_policy (:330-402) over all its branches (lane-count drop on either side -> forced change / creep,
+    overtaking left / right, timer, lane follow), the single-lane search when routing fails or lane change is off,
+    and the bare-except fallback (:254-260) -- in particular with a traffic participant (an object WITHOUT `.lane`,
+    traffic_participants/base_traffic_participant.py:12-32) among the surrounding objects.
+    World: roads P (-60..0) -> A (0..60) -> B (60..140) along +x, 3 lanes each except the B variants with 2 lanes
+    (aligned with A's lanes 0-1 or 1-2); Q is a road that nothing connects to.  The ego's current road is A."""
+    from types import SimpleNamespace
+    from metadrive.policy.idm_policy import IDMPolicy, FrontBackObjects
+    from metadrive.component.vehicle.PID_controller import PIDController
+    from metadrive.component.lane.straight_lane import StraightLane
+    rng = np.random.RandomState(4242)
+    W = 3.5
+
+    def road(name0, name1, x0, x1, lane_ids):
+        ls = []
+        for k, i in enumerate(lane_ids):          # i = lateral slot (y = -W * i), k = index inside the road
+            l = StraightLane([x0, -W * i], [x1, -W * i], W)
+            l.index = (name0, name1, k)
+            ls.append(l)
+        return ls
+
+    class Net:          # has_connection only reads .graph (road_network/base_road_network.py:106-113)
+        def __init__(self, graph):
+            self.graph = graph
+    from metadrive.component.road_network.base_road_network import BaseRoadNetwork
+    has_connection = BaseRoadNetwork.has_connection
+
+    raised = []
+    orig_lcp = IDMPolicy.lane_change_policy
+    orig_find = FrontBackObjects.get_find_front_back_objs.__func__
+
+    ret_line = []
+
+    def lcp(self, objs):
+        # which `return` of lane_change_policy was taken: the line number of the frame's return event
+        def tracer(frame, event, arg):
+            if frame.f_code is orig_lcp.__code__:
+                def local(fr, ev, a):
+                    if ev == "return":
+                        ret_line.append(fr.f_lineno)
+                    return local
+                return local
+            return None
+        old_trace = sys.gettrace()
+        sys.settrace(tracer)
+        try:
+            return orig_lcp(self, objs)
+        except BaseException as e:
+            raised.append(type(e).__name__)
+            raise
+        finally:
+            sys.settrace(old_trace)
+
+    def find(cls, *a, **k):
+        try:
+            return orig_find(cls, *a, **k)
+        except BaseException as e:
+            raised.append(type(e).__name__)
+            raise
+
+    IDMPolicy.lane_change_policy = lcp
+    FrontBackObjects.get_find_front_back_objs = classmethod(find)
+    cases = []
+    try:
+        for n in range(520):
+            variant = int(rng.randint(4))      # 0: B has 3 lanes, 1: B = A's lanes 0-1, 2: B = A's lanes 1-2, 3: A is the last road
+            P = road("n0", "n1", -60, 0, [0, 1, 2])
+            A = road("n1", "n2", 0, 60, [0, 1, 2])
+            B = road("n2", "n3", 60, 140, {0: [0, 1, 2], 1: [0, 1], 2: [1, 2], 3: [0, 1, 2]}[variant])
+            Q = road("n4", "n5", 0, 60, [5, 6, 7])
+            graph = {"n0": {"n1": P}, "n1": {"n2": A}, "n2": {"n3": B}, "n4": {"n5": Q}}
+            net = SimpleNamespace(graph=graph)
+            net.has_connection = lambda a, b, _n=net: has_connection(_n, a, b)
+            all_lanes = dict(P=P, A=A, B=B, Q=Q)
+
+            e_lane_road = "A" if rng.rand() < 0.85 else ("B" if rng.rand() < 0.5 else "P")
+            e_lanes = all_lanes[e_lane_road]
+            e_lane = e_lanes[int(rng.randint(len(e_lanes)))]
+            on_lane = A[min(e_lane.index[2], 2)] if e_lane_road != "A" else e_lane
+            es = float(rng.uniform(5, 55))
+            elat = float(rng.uniform(-0.6, 0.6))
+            epos = on_lane.position(es, elat)
+            if e_lane_road == "B":
+                epos = B[e_lane.index[2]].position(float(rng.uniform(1, 8)), elat)
+            elif e_lane_road == "P":
+                epos = P[e_lane.index[2]].position(float(rng.uniform(52, 59)), elat)
+            eh = float(rng.uniform(-0.25, 0.25))
+            ev = float(rng.choice([rng.uniform(0, 3), rng.uniform(7.5, 9.2), rng.uniform(10, 16)]))   # m/s; 30 km/h = 8.33
+            kind = rng.rand()
+            forced = variant in (1, 2) and rng.rand() < 0.6
+            if forced:       # the routing target lane does not continue into B: forced lane change / creep branches
+                e_lane_road, e_lane = "A", A[2 if variant == 1 else 0]
+                epos = e_lane.position(es, elat)
+                kind = 0.3
+            if kind < 0.2:
+                tgt = None
+            elif kind < 0.55:
+                tgt = e_lane
+            elif kind < 0.75:
+                tgt = A[int(rng.randint(3))]
+            elif kind < 0.92:
+                tgt = P[int(rng.randint(3))]
+            else:
+                tgt = Q[int(rng.randint(3))]
+            timer0 = int(rng.randint(0, 90))
+            enable_lc = bool(rng.rand() < 0.88)
+            target_speed0 = float(rng.choice([30.0, 5.0]))
+
+            nav = SimpleNamespace(current_ref_lanes=A, next_ref_lanes=None if variant == 3 else B,
+                                  map=SimpleNamespace(road_network=net))
+            ego = SimpleNamespace(lane=e_lane, navigation=nav, position=(float(epos[0]), float(epos[1])), heading_theta=eh,
+                                  speed_km_h=ev * 3.6, velocity_km_h=np.array([math.cos(eh), math.sin(eh)]) * ev * 3.6,
+                                  heading=np.array([math.cos(eh), math.sin(eh)]))
+            objs, recs = [], []
+            with_participant = rng.rand() < 0.12
+            for j in range(int(rng.randint(0, 9))):
+                rname = ["P", "A", "A", "A", "B", "B"][int(rng.randint(6))]
+                lanes_r = all_lanes[rname]
+                ol = lanes_r[int(rng.randint(len(lanes_r)))]
+                x = float(np.clip(epos[0] + rng.uniform(-44, 44), ol.start[0] + 0.5, ol.end[0] - 0.5))
+                op = ol.position(x - ol.start[0], float(rng.uniform(-0.4, 0.4)))
+                is_cone = rng.rand() < 0.15
+                ov = 0.0 if is_cone else float(rng.choice([rng.uniform(0, 3), rng.uniform(7.5, 9.2), rng.uniform(10, 16)]))
+                o = SimpleNamespace(lane=ol, position=np.array([float(op[0]), float(op[1])]), speed_km_h=ov * 3.6,
+                                    velocity_km_h=np.array([ov * 3.6, 0.0]), slot=j + 1)
+                objs.append(o)
+                recs.append(dict(kind="cone" if is_cone else "vehicle", road=rname, lane=ol.index[2],
+                                 pos=[float(op[0]), float(op[1])], speed=ov))
+            setup = rng.rand()
+            if setup < 0.3 and e_lane_road == "A":
+                # an object close by on a neighbouring lane (unsafe lane change -> creep) ...
+                nb = A[int(np.clip(e_lane.index[2] + (1 if rng.rand() < 0.5 else -1), 0, 2))]
+                x = float(np.clip(epos[0] + rng.uniform(-12, 6), 0.5, 59.5))
+                ov = float(rng.uniform(0, 14))
+                objs.append(SimpleNamespace(lane=nb, position=np.array([x, float(nb.start[1])]), speed_km_h=ov * 3.6,
+                                            velocity_km_h=np.array([ov * 3.6, 0.0]), slot=len(objs) + 1))
+                recs.append(dict(kind="vehicle", road="A", lane=nb.index[2], pos=[x, float(nb.start[1])], speed=ov))
+            elif setup < 0.55 and e_lane_road == "A":
+                # ... or an overtaking set-up: slow lead vehicle on the ego lane, timer past LANE_CHANGE_FREQ
+                timer0 = int(rng.randint(51, 95))
+                x = float(np.clip(epos[0] + rng.uniform(4, 25), 0.5, 59.5))
+                ov = float(rng.uniform(0, 6))
+                objs.append(SimpleNamespace(lane=e_lane, position=np.array([x, float(e_lane.start[1])]), speed_km_h=ov * 3.6,
+                                            velocity_km_h=np.array([ov * 3.6, 0.0]), slot=len(objs) + 1))
+                recs.append(dict(kind="vehicle", road="A", lane=e_lane.index[2], pos=[x, float(e_lane.start[1])], speed=ov))
+            if with_participant:
+                pp = [float(epos[0] + rng.uniform(-40, 40)), float(rng.uniform(-12, 5))]
+                pos_at = int(rng.randint(0, len(objs) + 1))
+                o = SimpleNamespace(position=np.array(pp), speed_km_h=3.0, velocity_km_h=np.array([0.0, 3.0]), slot=None)   # no .lane
+                objs.insert(pos_at, o)
+                recs.insert(pos_at, dict(kind="pedestrian" if rng.rand() < 0.6 else "cyclist", pos=pp, speed=0.0))
+                for k, oo in enumerate(objs):
+                    oo.slot = k + 1
+            ego.lidar = SimpleNamespace(get_surrounding_objects=lambda v, _o=objs: list(_o))
+
+            p = object.__new__(IDMPolicy)
+            p.control_object = ego
+            p.target_speed = target_speed0
+            p.routing_target_lane = tgt
+            p.available_routing_index_range = None
+            p.overtake_timer = timer0
+            p.enable_lane_change = enable_lc
+            p.disable_idm_deceleration = False
+            p.heading_pid = PIDController(1.7, 0.01, 3.5)
+            p.lateral_pid = PIDController(0.3, .002, 0.05)
+            p.action_info = {}
+            p.np_random = SimpleNamespace(randint=lambda lo, hi: 7)
+            del raised[:]
+            del ret_line[:]
+            action = IDMPolicy.act(p)
+
+            def lane_name(l):
+                if l is None:
+                    return None
+                for rn, ls in all_lanes.items():
+                    for q in ls:
+                        if q is l:
+                            return [rn, q.index[2]]
+                raise AssertionError("unknown lane")
+
+            cases.append(dict(variant=variant, ego=dict(lane=lane_name(e_lane), pos=list(ego.position), heading=eh, speed=ev),
+                              target0=lane_name(tgt), timer0=timer0, enable_lane_change=enable_lc, target_speed0=target_speed0,
+                              objs=recs, action=[float(action[0]), float(action[1])], target1=lane_name(p.routing_target_lane),
+                              timer1=int(p.overtake_timer), target_speed1=float(p.target_speed), fallback=bool(raised),
+                              exc=(raised[0] if raised else None),
+                              lcp_return_line=(ret_line[-1] if ret_line and not raised else None)))
+    finally:
+        IDMPolicy.lane_change_policy = orig_lcp
+        FrontBackObjects.get_find_front_back_objs = classmethod(orig_find)
+    n_fb = sum(c["fallback"] for c in cases)
+    n_part = sum(any(o["kind"] in ("pedestrian", "cyclist") for o in c["objs"]) for c in cases)
+    assert all(c["fallback"] and c["exc"] == "AttributeError" for c in cases
+               if any(o["kind"] in ("pedestrian", "cyclist") for o in c["objs"])), "a lane-less object must raise"
+    from collections import Counter
+    print("lane_change_policy return lines:", sorted(Counter(c["lcp_return_line"] for c in cases).items(), key=lambda kv: str(kv[0])))
+    print("idm_policy: %d cases, %d fallbacks, %d with a participant, creep %d, timer kept %d" % (
+        len(cases), n_fb, n_part, sum(c["target_speed1"] == 5.0 for c in cases), sum(c["timer1"] == c["timer0"] for c in cases)))
+    dump("idm_policy.json", dict(lane_width=W, rand_value=7, cases=cases))
+
+
 def section_pg_maps_v2():
     """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
     straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
@@ -700,7 +902,7 @@ def section_scenario_export():
     dump("scenario_export.json", dict(accepted_by_reference_sanity_check=True, scenarios=out))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":

@@ -527,6 +527,27 @@ EXPORT void ref_front_back(const MdLane* lanes, MdShape* shapes, MdNav* navs, in
         dist6[i] = fb.front_d[i]; dist6[3 + i] = fb.back_d[i];
     }
 }
+/* IDMPolicy.act (policy/idm_policy.py:235-267) of ONE vehicle on a hand-made scene: one map, one env of `cap` slots.
+ * node_adj_off / node_adj: the road graph (MdWorld layout, n_nodes + 1 offsets).  In / out: navs (target lane, timer,
+ * rand cursor), pids (target speed, PID state), actions[2 * slot ..] = (steering, acceleration). */
+EXPORT void ref_idm_vehicle(const MdLane* lanes, int n_lanes, const MdRoad* roads, int n_roads, const int32_t* node_adj_off,
+                            const int32_t* node_adj, MdShape* shapes, MdDyn* dyns, MdNav* navs, MdPid* pids, float* actions,
+                            int32_t* route_roads, const int32_t* idm_rand, int cap, int slot, int enable_lane_change) {
+    int32_t env_map = 0, lane_off[2] = {0, n_lanes}, road_off[2] = {0, n_roads}, node_off[2] = {0, 0};
+    MdWorld w;
+    memset(&w, 0, sizeof w);
+    w.n_maps = 1; w.n_envs = 1;
+    w.env_map = &env_map; w.lane_off = lane_off; w.lanes = lanes; w.road_off = road_off; w.roads = roads;
+    w.node_off = node_off; w.node_adj_off = node_adj_off; w.node_adj = node_adj;
+    MdState s;
+    memset(&s, 0, sizeof s);
+    s.shape = shapes; s.dyn = dyns; s.nav = navs; s.pid = pids; s.action = actions; s.route_roads = route_roads;
+    s.idm_rand = idm_rand;
+    MdConfig c;
+    memset(&c, 0, sizeof c);
+    c.n_envs = 1; c.cap = cap; c.agents_per_env = 1; c.enable_idm_lane_change = enable_lane_change;
+    md_idm_vehicle(&w, &s, &c, 0, slot);
+}
 EXPORT int ref_abi(int32_t* sizes, int n) {
     int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),
                      sizeof(MdRoad), sizeof(MdGrid), sizeof(MdWorld), sizeof(MdState), sizeof(MdConfig)};

@@ -73,6 +73,9 @@ def load(path=None):
     lib.ref_idm_steer.restype = f
     lib.ref_idm_steer.argtypes = [C.c_void_p, f, f, f, C.c_void_p]
     lib.ref_front_back.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, f, f, C.c_void_p, C.c_void_p]
+    lib.ref_idm_vehicle.restype = None
+    lib.ref_idm_vehicle.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.ref_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     abi.check_abi(lib.ref_abi, path)
     _LIBS[path] = lib

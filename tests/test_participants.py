@@ -105,3 +105,47 @@ def test_cyclist_velocity_frames_slots_and_errors():
         P.spawn(o.state, E, cap, h.A, "pedestrian", [100.0, 100.0])
     with pytest.raises(RuntimeError):
         P.spawn(o.state, E, cap, h.A, "pedestrian", [100.0, 100.0])
+
+
+def test_traffic_near_a_pedestrian_takes_the_bare_except_fallback(cs_dist):
+    """IDMPolicy.act with a pedestrian inside the 50 m ghost cylinder (policy/idm_policy.py:110,254-260; golden cases in
+    tests/golden/idm_policy.json): no lead object, distance 5 -- so a traffic vehicle queueing behind another one stops
+    braking for it -- while vehicles farther than 50 m from the pedestrian keep following their lead."""
+    from helpers import make_cfg
+    cfg = make_cfg(cs_dist, num_envs=6, num_scenarios=6, start_seed=40, traffic_density=0.3, auto_reset=False, horizon=5000)
+    h = HostScene(cfg)
+    a, b = ob.OracleWorld(h), ob.OracleWorld(h)
+    a.reset(), b.reset()
+    E, cap = h.E, h.cap
+    go = np.tile(np.array([0.0, 0.6], np.float32), (E, 1, 1))
+    for _ in range(40):            # let the first traffic block wake up
+        a.step(go), b.step(go)
+    sh = a.state["shape"].reshape(E, cap)
+    fl = sh["flags"]
+    drives = ((fl & abi.KIND_MASK) == abi.KIND_VEHICLE) & ((fl & abi.F_ALIVE) != 0) & ((fl & (abi.F_PENDING | abi.F_STATIC | abi.F_AGENT)) == 0)
+    assert drives.any()
+    # the pedestrian stands 20 m off to the side of the first driving traffic vehicle of every env that has one
+    pos = np.zeros((E, 2), np.float32) + 1.0e4
+    first = np.full(E, -1)
+    for e in range(E):
+        js = np.nonzero(drives[e])[0]
+        if len(js):
+            first[e] = js[0]
+            pos[e] = [sh["cx"][e, js[0]] - 20.0 * sh["s"][e, js[0]], sh["cy"][e, js[0]] + 20.0 * sh["c"][e, js[0]]]
+    P.spawn(b.state, E, cap, h.A, "pedestrian", pos, 0.0)
+    a.step(go), b.step(go)
+    act_a, act_b = a.state["action"].reshape(E, cap, 2), b.state["action"].reshape(E, cap, 2)
+    shb = b.state["shape"].reshape(E, cap)
+    near = far = changed = 0
+    for e in range(E):
+        for j in np.nonzero(drives[e])[0]:
+            d = np.hypot(shb["cx"][e, j] - pos[e, 0], shb["cy"][e, j] - pos[e, 1])
+            if d < 45.0:
+                near += 1
+                # fallback: the IDM term uses "no front object" -> acceleration 1 - (v/v0)^10 >= what car following gives
+                assert act_b[e, j, 1] >= act_a[e, j, 1] - 1e-6
+                changed += act_b[e, j, 1] != act_a[e, j, 1]
+            elif d > 56.0:
+                far += 1
+                assert act_b[e, j].tobytes() == act_a[e, j].tobytes()
+    assert near >= 3, (near, far)
