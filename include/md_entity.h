@@ -196,10 +196,9 @@ MD_HD void md_observe_ctx(const MdLane* lanes, const MdRoad* roads, const MdStat
     k->lane = k->ref0 = k->ref_last = k->next0 = k->fin = k->rl = lanes;
     k->cur_w = k->cur_n = k->positive_road = 0.0f;
     if (!k->valid) return;
-    const int32_t* rroads = s->route_roads + (size_t)n * MD_ROUTE_LEN;
-    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    const MdRoad* cur_road = &roads[nav->road0];
     int has_next = nav->ck1 != nav->ck0;
-    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : cur_road;
+    const MdRoad* next_road = has_next ? &roads[nav->road1] : cur_road;
     k->lane = &lanes[nav->lane];
     k->ref0 = &lanes[cur_road->first_lane];
     k->ref_last = &lanes[cur_road->first_lane + cur_road->n_lanes - 1];
@@ -209,7 +208,7 @@ MD_HD void md_observe_ctx(const MdLane* lanes, const MdRoad* roads, const MdStat
     k->cur_n = (float)cur_road->n_lanes;
     /* reward lane (metadrive_env.py:248-254) */
     k->positive_road = 1.0f;
-    if (k->lane->road == rroads[nav->ck0]) k->rl = k->lane;
+    if (k->lane->road == nav->road0) k->rl = k->lane;
     else {
         k->rl = k->ref0;
         k->positive_road = cur_road->negative ? -1.0f : 1.0f;
@@ -495,15 +494,14 @@ MD_HD int md_fb_neighbour(const MdLane* L, const MdLane* OL, float cur_long, flo
 MD_HD void md_idm_plan(const MdWorld* w, const MdLane* lanes, const MdRoad* roads, const MdState* s, const MdConfig* c,
                         int m, int slot, MdIdmPlan* p) {
     MdNav* nav = &s->nav[slot];
-    const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
-    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    const MdRoad* cur_road = &roads[nav->road0];
     int success;
     int veh_lane = nav->lane;
-    int in_cur = (veh_lane >= 0) && (lanes[veh_lane].road == rroads[nav->ck0]);
+    int in_cur = (veh_lane >= 0) && (lanes[veh_lane].road == nav->road0);
     if (nav->target_lane < 0) {
         nav->target_lane = veh_lane;
         success = in_cur;
-    } else if (lanes[nav->target_lane].road != rroads[nav->ck0]) {
+    } else if (lanes[nav->target_lane].road != nav->road0) {
         success = 0;
         const MdLane* T = &lanes[nav->target_lane];
         int t_end = roads[T->road].end_node;
@@ -599,10 +597,9 @@ MD_HD void md_idm_decide(const MdLane* lanes, const MdRoad* roads, const MdState
     MdNav* nav = &s->nav[slot];
     MdPid* pid = &s->pid[slot];
     MdDyn* d = &s->dyn[slot];
-    const int32_t* rroads = s->route_roads + (size_t)slot * MD_ROUTE_LEN;
-    const MdRoad* cur_road = &roads[rroads[nav->ck0]];
+    const MdRoad* cur_road = &roads[nav->road0];
     int has_next = nav->ck1 != nav->ck0;
-    const MdRoad* next_road = has_next ? &roads[rroads[nav->ck1]] : 0;
+    const MdRoad* next_road = has_next ? &roads[nav->road1] : 0;
     float px = sh->cx, py = sh->cy;
     float speed_kmh = md_fabs(d->speed) * 3.6f;
     FrontBack fb = *fbp;
@@ -784,9 +781,8 @@ MD_HD void md_others_project(float dx, float dy, float hc, float hs, float scale
 MD_HD void md_others_ckpt(const MdLane* lanes, const MdRoad* roads, const MdState* s, int j, float* c1x, float* c1y,
                           float* c2x, float* c2y) {
     const MdNav* nav = &s->nav[j];
-    const int32_t* rroads = s->route_roads + (size_t)j * MD_ROUTE_LEN;
-    const MdRoad* r1 = &roads[rroads[nav->ck0]];
-    const MdRoad* r2 = (nav->ck1 != nav->ck0) ? &roads[rroads[nav->ck1]] : r1;
+    const MdRoad* r1 = &roads[nav->road0];
+    const MdRoad* r2 = (nav->ck1 != nav->ck0) ? &roads[nav->road1] : r1;
     /* later_middle uses the CURRENT lane's width and the current road's lane count (base_navigation.py:147) */
     float wdt = (nav->lane >= 0) ? lanes[nav->lane].width : lanes[r1->first_lane].width;
     float lm = ((float)r1->n_lanes / 2.0f - 0.5f) * wdt;
@@ -836,7 +832,7 @@ MD_HD void md_others_block(const MdLane* lanes, const MdRoad* roads, const MdSta
         md_others_project(ov * v->c - ego_v * me->c, ov * v->s - ego_v * me->s, me->c, me->s, vmax, &o[2], &o[3]);
         if (c->add_others_navi) {
             float c1x = me->cx, c1y = me->cy, c2x = me->cx, c2y = me->cy;
-            if (s->nav[best].route_len >= 2 && s->route_roads[(size_t)best * MD_ROUTE_LEN + s->nav[best].ck0] >= 0)
+            if (s->nav[best].route_len >= 2 && s->nav[best].road0 >= 0)
                 md_others_ckpt(lanes, roads, s, best, &c1x, &c1y, &c2x, &c2y);
             float pts[4] = {c1x, c1y, c2x, c2y};
             for (int q = 0; q < 2; ++q) {
@@ -912,6 +908,8 @@ MD_HD void md_traffic_respawn_env(const MdWorld* w, const MdLane* lanes, const M
             s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];
             s->route_roads[(size_t)slot * MD_ROUTE_LEN + k] = rt[MD_ROUTE_LEN + k];
         }
+        nav->road0 = rt[MD_ROUTE_LEN + nav->ck0];
+        nav->road1 = rt[MD_ROUTE_LEN + nav->ck1];
         MdPid* pid = &s->pid[slot];
         pid->hp = pid->hi = pid->hd = 0.0f;
         pid->lp = pid->li = pid->ld = 0.0f;
@@ -1019,6 +1017,8 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
                 s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];
                 s->route_roads[(size_t)slot * MD_ROUTE_LEN + k] = rt[MD_ROUTE_LEN + k];
             }
+            nav->road0 = rt[MD_ROUTE_LEN + nav->ck0];
+            nav->road1 = rt[MD_ROUTE_LEN + nav->ck1];
             s->pid[slot].energy = 0.0f;
             s->flags[slot] = 0;
             s->action[2 * slot] = 0.0f;

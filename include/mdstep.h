@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 6
+#define MD_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -130,7 +130,11 @@ typedef struct MdNav {
     int32_t steps;       /* episode_lengths[agent]                                              */
     int32_t rand_cursor; /* next entry of MdState.idm_rand to consume                           */
     int32_t done;        /* sticky BaseEnv.dones[agent] (envs/base_env.py:600)                  */
-    int32_t spare[5];
+    int32_t road0, road1;/* route_roads[ck0] / route_roads[ck1]: the roads of navigation.current_ref_lanes / next_ref_lanes
+                          * (node_network_navigation.py:130-168), kept beside the cursors so that the per-step logic never
+                          * indexes the 48-entry route arrays; rewritten whenever ck0 / ck1 change (checkpoint advance,
+                          * respawn, reset snapshot)                                              */
+    int32_t spare[3];
 } MdNav;
 
 /* 32-byte IDM controller state (PID_controller.py:1-22, idm_policy.py:226-233). */

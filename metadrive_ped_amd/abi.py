@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 6
+MD_ABI_VERSION = 7
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -50,7 +50,7 @@ PARAM_DT = np.dtype([("max_steer", f4), ("accel_gain", f4), ("brake_gain", f4), 
                      ("max_speed_kmh", f4), ("lf", f4), ("lr", f4), ("fric_decel", f4)])
 NAV_DT = np.dtype([("lane", i4), ("ck0", i4), ("ck1", i4), ("route_len", i4), ("target_lane", i4), ("timer", i4),
                    ("trigger_road", i4), ("trigger_order", i4), ("steps", i4), ("rand_cursor", i4), ("done", i4),
-                   ("spare", i4, (5, ))])
+                   ("road0", i4), ("road1", i4), ("spare", i4, (3, ))])
 PID_DT = np.dtype([("hp", f4), ("hi", f4), ("hd", f4), ("lp", f4), ("li", f4), ("ld", f4), ("target_speed", f4),
                    ("energy", f4)])
 LANE_DT = np.dtype([("type", i4), ("road", i4), ("idx", i4), ("n_in_road", i4), ("ax", f4), ("ay", f4), ("bx", f4),

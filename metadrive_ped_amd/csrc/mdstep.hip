@@ -237,11 +237,11 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
     if (!md_drives(sh.flags)) return;
     MdNav nav = s.nav[n];
     const int m = w.env_map[e];
-    const int32_t* rroads = s.route_roads + (size_t)n * MD_ROUTE_LEN;
+    const int32_t* rroads = s.route_roads + (size_t)n * MD_ROUTE_LEN;   // global: read only when the cursors advance
     const int32_t* rnodes = s.route_nodes + (size_t)n * MD_ROUTE_LEN;
-    const int cur_road = rroads[nav.ck0];
+    const int cur_road = nav.road0;
     const bool has_next = nav.ck1 != nav.ck0;
-    const int next_road = has_next ? rroads[nav.ck1] : -1;
+    const int next_road = has_next ? nav.road1 : -1;
 
     MD_FINE_STAMP(n == 0 && lane_id == 0, 0);
     const MdGrid g = w.grid[m];
@@ -358,8 +358,11 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
         if (rnodes[j] == start_node) { idx = j; break; }
     }
     if (idx < 0) return;
+    const int nck1 = (idx + 1 == k - 1) ? idx : idx + 1;
     s.nav[n].ck0 = idx;
-    s.nav[n].ck1 = (idx + 1 == k - 1) ? idx : idx + 1;
+    s.nav[n].ck1 = nck1;
+    s.nav[n].road0 = rroads[idx];
+    s.nav[n].road1 = rroads[nck1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,11 +388,11 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
     nav.ck1 = s.nav[nn].ck1;
     nav.route_len = s.nav[nn].route_len;
     const int m = w.env_map[e];
-    const int32_t* rroads = s.route_roads + (size_t)nn * MD_ROUTE_LEN;
+    const int32_t* rroads = s.route_roads + (size_t)nn * MD_ROUTE_LEN;   // global: read only when the cursors advance
     const int32_t* rnodes = s.route_nodes + (size_t)nn * MD_ROUTE_LEN;
-    const int cur_road = rroads[nav.ck0];
+    const int cur_road = s.nav[nn].road0;
     const bool has_next = nav.ck1 != nav.ck0;
-    const int next_road = has_next ? rroads[nav.ck1] : -1;
+    const int next_road = has_next ? s.nav[nn].road1 : -1;
     const MdGrid g = w.grid[m];
     const int gx = (int)md_floor((sh.cx - g.x0) * g.inv_cell);
     const int gy = (int)md_floor((sh.cy - g.y0) * g.inv_cell);
@@ -489,8 +492,11 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
         if (rnodes[j] == start_node) { idx = j; break; }
     }
     if (idx < 0) return;
+    const int nck1 = (idx + 1 == kk - 1) ? idx : idx + 1;
     s.nav[n].ck0 = idx;
-    s.nav[n].ck1 = (idx + 1 == kk - 1) ? idx : idx + 1;
+    s.nav[n].ck1 = nck1;
+    s.nav[n].road0 = rroads[idx];
+    s.nav[n].road1 = rroads[nck1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -978,6 +984,8 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                         s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
                         s.route_roads[(size_t)slot * MD_ROUTE_LEN + q] = rt[MD_ROUTE_LEN + q];
                     }
+                    nav->road0 = rt[MD_ROUTE_LEN + nav->ck0];
+                    nav->road1 = rt[MD_ROUTE_LEN + nav->ck1];
                     s.pid[slot].energy = 0.0f;
                     s.flags[slot] = 0;
                     s.action[2 * slot] = 0.0f;
@@ -1048,11 +1056,11 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MdPid* l_pid = reinterpret_cast<MdPid*>(l_nav + cap);
     float* l_action = reinterpret_cast<float*>(l_pid + cap);
     uint32_t* l_flags = reinterpret_cast<uint32_t*>(l_action + 2 * cap);
-    // static tables of this env's map + the movers' routes: read many times by the serial per-vehicle
-    // logic, so they sit in LDS too (a dependent chain of HBM/L2 round trips otherwise)
-    int32_t* l_rroads = reinterpret_cast<int32_t*>(l_flags + ((cap + 3) & ~3));
+    // static tables of this env's map: read many times by the serial per-vehicle logic, so (small maps) they sit in
+    // LDS too (a dependent chain of HBM/L2 round trips otherwise).  The movers' routes stay in global memory: the two
+    // road ids the step needs are cached in MdNav (road0 / road1), the arrays are touched only when a cursor advances.
     const int n_stage_lanes = STAGE_MAP ? w.max_lanes : 0, n_stage_roads = STAGE_MAP ? w.max_roads : 0;
-    MdLane* l_lanes = reinterpret_cast<MdLane*>(l_rroads + cap * MD_ROUTE_LEN);
+    MdLane* l_lanes = reinterpret_cast<MdLane*>(l_flags + ((cap + 3) & ~3));
     MdRoad* l_roads = reinterpret_cast<MdRoad*>(l_lanes + n_stage_lanes);
     constexpr int kScratch = MULTI ? kObsScratch : 48;  // floats per wave (launch<> sizes the LDS image the same way)
     float* l_scratch = reinterpret_cast<float*>(l_roads + n_stage_roads) + wave * kScratch;  // per-wave observe results
@@ -1089,14 +1097,13 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         // arrives in one memory round trip (a chain of copy loops waits for each loop's loads in turn: 7 trips,
         // ~9 k cycles per env).  16-B units per array at cap <= 128: shape/dyn/pid/param <= 256 (one per thread),
         // nav <= 512, routes <= 1536: the first 256 / 512 units go through registers, the rest (cap > 64 / > 42) in tail loops.
-        const int n32 = cap * 2, n64 = cap * 4, nrr = cap * (MD_ROUTE_LEN / 4);
+        const int n32 = cap * 2, n64 = cap * 4;
         const uint4* g_shape = reinterpret_cast<const uint4*>(gv.shape);
         const uint4* g_dyn = reinterpret_cast<const uint4*>(gv.dyn);
         const uint4* g_pid = reinterpret_cast<const uint4*>(gv.pid);
         const uint4* g_param = reinterpret_cast<const uint4*>(gv.param);
         const uint4* g_nav = reinterpret_cast<const uint4*>(gv.nav);
-        const uint4* g_rr = reinterpret_cast<const uint4*>(gv.route_roads);
-        uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_rr0, r_rr1;
+        uint4 r_shape, r_dyn, r_pid, r_param, r_nav0;
         float2 r_act;
         uint32_t r_fl;
         int r_fin;
@@ -1108,8 +1115,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             r_param = g_param[tid];
         }
         if (tid < n64) r_nav0 = g_nav[tid];
-        if (tid < nrr) r_rr0 = g_rr[tid];
-        if (tid + kBlock < nrr) r_rr1 = g_rr[tid + kBlock];
         if (pc) {
             r_act = (kFusedAct && tid < c.agents_per_env) ? reinterpret_cast<const float2*>(gv.agent_action)[tid]
                                                           : reinterpret_cast<const float2*>(gv.action)[tid];
@@ -1129,10 +1134,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             reinterpret_cast<uint4*>(l_param)[tid] = r_param;
         }
         if (tid < n64) reinterpret_cast<uint4*>(l_nav)[tid] = r_nav0;
-        if (tid < nrr) reinterpret_cast<uint4*>(l_rroads)[tid] = r_rr0;
-        if (tid + kBlock < nrr) reinterpret_cast<uint4*>(l_rroads)[tid + kBlock] = r_rr1;
         for (int i = tid + kBlock; i < n64; i += kBlock) reinterpret_cast<uint4*>(l_nav)[i] = g_nav[i];
-        for (int i = tid + 2 * kBlock; i < nrr; i += kBlock) reinterpret_cast<uint4*>(l_rroads)[i] = g_rr[i];
         if (pc) {
             reinterpret_cast<float2*>(l_action)[tid] = r_act;
             l_flags[tid] = r_fl;
@@ -1148,7 +1150,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             copy16(l_lanes, w.lanes + lo, (w.lane_off[m + 1] - lo) * (int)sizeof(MdLane), tid, kBlock);
             copy16(l_roads, w.roads + ro, (w.road_off[m + 1] - ro) * (int)sizeof(MdRoad), tid, kBlock);
         }
-        copy16(l_rroads, gv.route_roads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
         copy16(l_dyn, gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         copy16(l_nav, gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
         copy16(l_pid, gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
@@ -1179,7 +1180,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         if (MULTI || (RESPAWN && (c.traffic_mode == 1 || c.traffic_mode == 2))) {  // respawns rewrote the routes: restore them too
             for (int i = tid; i < cap * MD_ROUTE_LEN; i += kBlock) {
                 gv.route_nodes[i] = gv.route_nodes0[i];
-                l_rroads[i] = gv.route_roads0[i];
+                gv.route_roads[i] = gv.route_roads0[i];
             }
             for (int j = tid; j < cap; j += kBlock) l_final[j] = gv.final_lane0[j];
         }
@@ -1203,7 +1204,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         s.flags = l_flags;
         s.param = l_param;
         s.final_lane = l_final;
-        s.route_roads = l_rroads;
     }
     __syncthreads();
     MD_STAMP_AT(1);
@@ -1382,11 +1382,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                 }
             for (int i = tid; i < cap * 4; i += kBlock)
                 if (dirty(i >> 2)) reinterpret_cast<uint4*>(gv.nav)[i] = reinterpret_cast<const uint4*>(l_nav)[i];
-            if (RESPAWN) {
-                for (int i = tid; i < cap * (MD_ROUTE_LEN / 4); i += kBlock)
-                    if (md_drives(l_shape[i / (MD_ROUTE_LEN / 4)].flags))
-                        reinterpret_cast<uint4*>(gv.route_roads)[i] = reinterpret_cast<const uint4*>(l_rroads)[i];
-            }
             for (int j = tid; j < cap; j += kBlock)
                 if (dirty(j)) {
                     reinterpret_cast<float2*>(gv.action)[j] = reinterpret_cast<const float2*>(l_action)[j];
@@ -1403,7 +1398,6 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         if ((PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
         if ((PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
         if (((PH & (PH_RESET | PH_LIFECYCLE)) && MULTI) || ((PH & (PH_RESET | PH_TRAFFIC)) && RESPAWN)) {
-            copy16(gv.route_roads, l_rroads, cap * MD_ROUTE_LEN * 4, tid, kBlock);
             for (int j = tid; j < cap; j += kBlock) gv.final_lane[j] = l_final[j];
         }
         for (int j = tid; j < cap; j += kBlock) {
@@ -1484,7 +1478,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     // the lidar-only kernel stages nothing but the shapes: asking for the full image would cost it occupancy
     const size_t lds = (PH == PH_LIDAR) ? (size_t)c->cap * sizeof(MdShape) + 16 :
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
-                       (size_t)((c->cap + 3) & ~3) * 4 + (size_t)c->cap * MD_ROUTE_LEN * 4 +
+                       (size_t)((c->cap + 3) & ~3) * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
                        (MD_ENV_BLOCK / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
                        (size_t)c->cap * 8;

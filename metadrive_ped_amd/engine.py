@@ -211,6 +211,12 @@ class HostScene:
         st["route_roads"] = stack("route_roads")
         st["final_lane"] = stack("final_lane")
         st["idm_rand"] = stack("idm_rand")
+        # MdNav.road0 / road1: the road ids under the two route cursors, kept beside them (ABI v7) so that the per-step
+        # logic never indexes the route arrays
+        rows = np.arange(N)
+        rr = st["route_roads"].reshape(N, abi.MD_ROUTE_LEN)
+        st["nav0"]["road0"] = rr[rows, np.clip(st["nav0"]["ck0"], 0, abi.MD_ROUTE_LEN - 1)]
+        st["nav0"]["road1"] = rr[rows, np.clip(st["nav0"]["ck1"], 0, abi.MD_ROUTE_LEN - 1)]
         st["shape"] = st["shape0"].copy()
         st["dyn"] = st["dyn0"].copy()
         st["nav"] = st["nav0"].copy()

@@ -186,6 +186,8 @@ static void localize_mover(const MdWorld* w, const MdState* s, const MdConfig* c
     if (idx < 0) return;
     nav->ck0 = idx;
     nav->ck1 = (idx + 1 == k - 1) ? idx : idx + 1;
+    nav->road0 = rroads[nav->ck0]; /* the cached ids of current_ref_lanes / next_ref_lanes' roads follow the cursors */
+    nav->road1 = rroads[nav->ck1];
 }
 
 EXPORT int ref_localize(const MdWorld* w, const MdState* s, const MdConfig* c) {

@@ -650,3 +650,27 @@ def test_reward_cost_done_known_answers():
     r, c = run(dict(map="SSS", traffic_density=0.0, accident_prob=1.0, start_seed=5), [0.0, 1.0],
                abi.FL_CRASH_OBJECT | abi.FL_CRASH_VEHICLE)
     assert (r, c) in ((-4444.0, 7777.0), (-3333.0, 6666.0))      # a cone / barrier, or the broken-down car of the scene
+
+
+def test_nav_road_cache_follows_the_route_cursors(cs_dist):
+    """MdNav.road0 / road1 (ABI v7) are route_roads[ck0] / route_roads[ck1] at all times: after checkpoint advances,
+    traffic respawns (hybrid mode) and auto-resets.  The step logic reads only the cached ids."""
+    from helpers import make_cfg, scripted_actions
+    from metadrive_ped_amd.engine import HostScene
+    for mode in ("trigger", "hybrid"):
+        cfg = make_cfg(cs_dist, num_envs=12, num_scenarios=12, start_seed=70, traffic_density=0.2, traffic_mode=mode,
+                       horizon=150, auto_reset=True)
+        h = HostScene(cfg)
+        o = ob.OracleWorld(h)
+        o.reset()
+        advanced = 0
+        for t in range(260):
+            o.step(scripted_actions(h.E, 1, t))
+            if t % 20 == 19:
+                nav, rr = o.state["nav"], o.state["route_roads"].reshape(-1, abi.MD_ROUTE_LEN)
+                rows = np.arange(len(nav))
+                live = nav["route_len"] >= 2
+                assert (nav["road0"][live] == rr[rows, nav["ck0"]][live]).all()
+                assert (nav["road1"][live] == rr[rows, nav["ck1"]][live]).all()
+                advanced += int((nav["ck0"][live] > 0).sum())
+        assert advanced > 0
