@@ -318,6 +318,8 @@ typedef struct MdConfig {
                                 * Single-agent envs only. */
     int32_t enable_reverse;    /* vehicle_config.enable_reverse: an agent's negative throttle drives it backwards instead of
                                 * braking (base_vehicle.py:476-484) */
+    int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env.
+                                * Same results bit for bit; a machine-mapping choice, no reference counterpart. */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

@@ -118,6 +118,7 @@ class MdConfig(C.Structure):
         ("random_agent_model", C.c_int32),
         ("agent_idm", C.c_int32),
         ("enable_reverse", C.c_int32),
+        ("step_kernel", C.c_int32),
     ]
 
 

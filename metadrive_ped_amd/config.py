@@ -109,6 +109,7 @@ BATCH_DEFAULT_CONFIG = dict(
     device="cuda:0",
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
+    step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same results)
 )
 
 # Keys of the reference's BASE_DEFAULT_CONFIG (envs/base_env.py:32-266) that only concern rendering, cameras, the GUI,
@@ -236,6 +237,8 @@ def make_config(user=None):
         raise ValueError("spawn_roads is a multi-agent env option")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
+    if cfg["step_kernel"] not in ("wg", "wave"):
+        raise ValueError("step_kernel must be 'wg' or 'wave', got {!r}".format(cfg["step_kernel"]))
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
         raise ValueError("mover_capacity must be 0 (auto) or in [num_agents, 128]")
     return cfg

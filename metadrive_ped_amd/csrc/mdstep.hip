@@ -371,10 +371,14 @@ __device__ __forceinline__ void localize_vehicle(const MdWorld& w, const MdLane*
 // tie-breaks as localize_vehicle; the per-vehicle data are per-lane values here (uniform within a half), cross-lane
 // reads go through __shfl, votes through the matching half of a 64-bit ballot.  Results go to onlane_out.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
-                              int slot_a, int slot_b, int lane_id, uint32_t* onlane_out) {
-    const int h = lane_id >> 5, hl = lane_id & 31, hbase = h << 5;
-    const int n = h ? slot_b : slot_a;
+// GW = lanes per vehicle: 32 (two vehicles per wave) or 16 (four; the one-wave-per-env kernel's form when three or more
+// vehicles drive).  slot_c / slot_d are only read with GW == 16.
+template <int GW>
+__device__ __forceinline__ void localize_group(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
+                              int slot_a, int slot_b, int slot_c, int slot_d, int lane_id, uint32_t* onlane_out) {
+    constexpr unsigned kGroupMask = (GW == 32) ? 0xFFFFFFFFu : 0xFFFFu;
+    const int h = lane_id / GW, hl = lane_id & (GW - 1), hbase = h * GW;
+    const int n = (h == 0) ? slot_a : ((h == 1) ? slot_b : ((h == 2) ? slot_c : slot_d));
     const bool act = n >= 0;  // (slots handed in always drive)
     const int nn = act ? n : 0;
     struct { float cx, cy, c, s; } sh;   // only what the search needs, per lane
@@ -406,8 +410,8 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
     int best_any = -1, best_cur = -1, best_next = -1;
     float d_any = 3.0e38f, d_cur = 3.0e38f, d_next = 3.0e38f;
     float ls_any = 0.0f, ls_cur = 0.0f, ls_next = 0.0f;
-    const auto half_of = [&](unsigned long long b) { return (unsigned)(h ? (b >> 32) : (b & 0xFFFFFFFFull)); };
-    for (int itb = it0; __ballot(itb < it1) != 0ull; itb += 32) {
+    const auto part_of = [&](unsigned long long b) { return (unsigned)(b >> hbase) & kGroupMask; };
+    for (int itb = it0; __ballot(itb < it1) != 0ull; itb += GW) {
         const int it = itb + hl;
         int l = -1;
         bool pass = false;
@@ -418,8 +422,8 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
                 pass = !(sh.cx < L->x0 || sh.cx > L->x1 || sh.cy < L->y0 || sh.cy > L->y1);
             }
         }
-        unsigned mask = half_of(__ballot(pass));
-        unsigned inside = 0u;  // bit k: candidate held by lane k of MY half contains the point
+        unsigned mask = part_of(__ballot(pass));
+        unsigned inside = 0u;  // bit k: candidate held by lane k of MY group contains the point
         while (__ballot(mask != 0u) != 0ull) {
             const bool mine = mask != 0u;
             const int k = mine ? (__ffs((int)mask) - 1) : 0;
@@ -431,14 +435,14 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
                 const MdLane* L = &lanes[lk];
                 hn = L->hull_n;
                 const float* xy = md_lane_hull(L, w.hull_xy);
-                for (int i = hl; i < hn; i += 32) {
+                for (int i = hl; i < hn; i += GW) {
                     const int j = (i + 1 == hn) ? 0 : i + 1;
                     const float ex = xy[2 * j] - xy[2 * i], ey = xy[2 * j + 1] - xy[2 * i + 1];
                     const float cr = ex * (sh.cy - xy[2 * i + 1]) - ey * (sh.cx - xy[2 * i]);
                     if (cr < 0.0f) outside = true;
                 }
             }
-            const unsigned out_h = half_of(__ballot(outside));
+            const unsigned out_h = part_of(__ballot(outside));
             if (mine && out_h == 0u && hn >= 3) inside |= 1u << k;
         }
         if (inside != 0u) on_lane = 1;
@@ -467,7 +471,7 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
             if (has_next && road == next_road && dist < d_next) { d_next = dist; best_next = lk; ls_next = lsk; }
         }
     }
-    if (hl != 0 || !act) return;  // lane 0 of each half commits its vehicle
+    if (hl != 0 || !act) return;  // lane 0 of each group commits its vehicle
     int lane = -1;
     float ls = 0.0f;
     if (best_cur >= 0) { lane = best_cur; ls = ls_cur; }
@@ -497,6 +501,11 @@ __device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* la
     s.nav[n].ck1 = nck1;
     s.nav[n].road0 = rroads[idx];
     s.nav[n].road1 = rroads[nck1];
+}
+
+__device__ __forceinline__ void localize_pair(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s, int e,
+                              int slot_a, int slot_b, int lane_id, uint32_t* onlane_out) {
+    localize_group<32>(w, lanes, roads, s, e, slot_a, slot_b, -1, -1, lane_id, onlane_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -606,25 +615,12 @@ __device__ __forceinline__ void wave_argmin(float& key, int& slot) {
     slot = bs;
 }
 
+// The object scan of one vehicle by the whole wave.  `plan` is wave-uniform (may come back with fail = 1: a traffic
+// participant among the candidates), `fb` is the wave-uniform result.
 // wave_list: >= 24 ints of LDS private to this wave (the compacted candidate list)
-__device__ __forceinline__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
-                                 const MdConfig& c, int m, int slot, int lane_id, int* wave_list) {
+__device__ __forceinline__ void idm_scan_wave(const MdLane* lanes, const MdState& s, const MdConfig& c, int slot, int lane_id,
+                              int* wave_list, MdIdmPlan& plan, FrontBack& fb) {
     constexpr float kInf = 3.0e38f;
-    MdIdmPlan plan;
-    plan.success = plan.use_ref = plan.fail = 0;
-    plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
-    const bool st_ = (slot == c.agents_per_env) && lane_id == 0;
-    (void)st_;
-    MD_FINE_STAMP(st_, 4);
-    if (lane_id == 0) md_idm_plan(&w, lanes, roads, &s, &c, m, slot, &plan);
-    plan.success = bcast_i(plan.success, 0);
-    plan.use_ref = bcast_i(plan.use_ref, 0);
-    plan.fail = bcast_i(plan.fail, 0);
-    plan.ids[0] = bcast_i(plan.ids[0], 0);
-    plan.ids[1] = bcast_i(plan.ids[1], 0);
-    plan.ids[2] = bcast_i(plan.ids[2], 0);
-    MD_FINE_STAMP(st_, 5);
-    FrontBack fb;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         fb.front[i] = fb.back[i] = -1;
@@ -778,9 +774,74 @@ __device__ __forceinline__ void idm_vehicle_wave(const MdWorld& w, const MdLane*
             }
         }
     }
+}
+
+// One vehicle at a time: plan on lane 0, scan by the wave, decide on lane 0 (the workgroup-per-env kernels' form).
+__device__ __forceinline__ void idm_vehicle_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
+                                 const MdConfig& c, int m, int slot, int lane_id, int* wave_list) {
+    MdIdmPlan plan;
+    plan.success = plan.use_ref = plan.fail = 0;
+    plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
+    const bool st_ = (slot == c.agents_per_env) && lane_id == 0;
+    (void)st_;
+    MD_FINE_STAMP(st_, 4);
+    if (lane_id == 0) md_idm_plan(&w, lanes, roads, &s, &c, m, slot, &plan);
+    plan.success = bcast_i(plan.success, 0);
+    plan.use_ref = bcast_i(plan.use_ref, 0);
+    plan.fail = bcast_i(plan.fail, 0);
+    plan.ids[0] = bcast_i(plan.ids[0], 0);
+    plan.ids[1] = bcast_i(plan.ids[1], 0);
+    plan.ids[2] = bcast_i(plan.ids[2], 0);
+    MD_FINE_STAMP(st_, 5);
+    FrontBack fb;
+    idm_scan_wave(lanes, s, c, slot, lane_id, wave_list, plan, fb);
     MD_FINE_STAMP(st_, 6);
     if (lane_id == 0) md_idm_decide(lanes, roads, &s, slot, &plan, &fb);
     MD_FINE_STAMP(st_, 7);
+}
+
+// All vehicles of `mask` (bit j = slot j0 + j; <= 64 of them): stage A (route bookkeeping) and stage C (lane-change
+// policy, PID steering, IDM acceleration) are per-vehicle scalar code, so every vehicle runs them on ITS OWN lane, all
+// at once; only the object scans in between go vehicle by vehicle, each by the whole wave.  Same arithmetic per
+// vehicle; the decisions do not depend on each other (a decision reads poses / speeds / lanes, and writes only its
+// own action, PID and lane-change state).  The one-wave-per-env kernel's form.
+__device__ __forceinline__ void idm_group_wave(const MdWorld& w, const MdLane* lanes, const MdRoad* roads, const MdState& s,
+                               const MdConfig& c, int m, int j0, unsigned long long mask, int lane_id, int* wave_list) {
+    const int my_slot = j0 + lane_id;
+    const bool mine = (mask >> lane_id) & 1ull;
+    MdIdmPlan plan;
+    plan.success = plan.use_ref = plan.fail = 0;
+    plan.ids[0] = plan.ids[1] = plan.ids[2] = -1;
+    if (mine) md_idm_plan(&w, lanes, roads, &s, &c, m, my_slot, &plan);
+    FrontBack fb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fb.front[i] = fb.back[i] = -1;
+        fb.exist[i] = 0;
+        fb.front_d[i] = fb.back_d[i] = IDM_MAX_LONG_DIST;
+    }
+    unsigned long long todo = mask;
+    while (todo) {
+        const int v = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        MdIdmPlan up;   // vehicle v's plan, wave-uniform
+        up.success = bcast_i(plan.success, v);
+        up.use_ref = bcast_i(plan.use_ref, v);
+        up.fail = bcast_i(plan.fail, v);
+        up.ids[0] = bcast_i(plan.ids[0], v);
+        up.ids[1] = bcast_i(plan.ids[1], v);
+        up.ids[2] = bcast_i(plan.ids[2], v);
+        FrontBack ufb;
+        idm_scan_wave(lanes, s, c, j0 + v, lane_id, wave_list, up, ufb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next scan reuses wave_list
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane_id == v) {
+            plan.fail = up.fail;
+            fb = ufb;
+        }
+    }
+    if (mine) md_idm_decide(lanes, roads, &s, my_slot, &plan, &fb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1414,6 +1475,325 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     MD_STAMP_AT(11);
 }
 
+// ------------------------------------------------------------------------------------------------
+// wave_step_kernel: the fused step of the SINGLE-AGENT envs with ONE WAVE PER ENVIRONMENT.
+//
+// env_kernel above gives an env a 4-wave workgroup and orders its phases with workgroup barriers; with one agent and two
+// or three driving vehicles per env most of those waves spend most of the step parked at the next barrier (PMC:
+// SQ_WAIT_ANY 79 % of the wave-cycles) while holding a wave slot and a share of the LDS, and everything wave-uniform
+// (stage-in addressing, masks, flag merges) is executed four times.  Here one wave64 walks through ALL phases of its
+// env: the work items that env_kernel deals to waves (localise a vehicle, the agent's contacts, one IDM scan, one
+// 64-beam lidar sector) are taken one after the other by the same wave, with the SAME wave-level device functions --
+// identical arithmetic, candidate order and tie-breaks, so the results stay bit-identical to the oracle.  What changes
+// is the machine mapping:
+//   * no workgroup barrier anywhere: phases are ordered by program order inside the wave (LDS operations of one wave
+//     execute in order; a compiler fence + wave barrier keeps the compiler from reordering across the lanes' roles);
+//   * every resident wave issues useful instructions: 4096 envs = 4096 waves = 4 per SIMD, all of them busy, instead
+//     of 1 792 resident workgroups x 4 waves of which ~1.3 per SIMD issue;
+//   * a workgroup is kWaveEnvs independent envs (they share nothing but the launch), the LDS image of an env is
+//     ~5.4 KB at 24 slots (no routes, no map tables), so LDS never limits the residency.
+// Multi-agent envs (40 agents per env) keep env_kernel: there the parallelism inside one env pays.
+// ------------------------------------------------------------------------------------------------
+#ifndef MD_WAVE_ENVS
+#define MD_WAVE_ENVS 4
+#endif
+constexpr int kWaveEnvs = MD_WAVE_ENVS;   // envs (= waves) per workgroup
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__host__ __device__ inline int wave_env_lds_bytes(int cap, int agents) {
+    // shape dyn pid param (32 B) + nav (64 B) per slot, then action (8) flags final onlane cfl (4 each), the wave's
+    // scratch (48 floats) and the detected sets (16 B per agent); rounded to 16 B
+    const int b = cap * (4 * 32 + 64) + cap * (8 + 4 * 4) + 48 * 4 + 16 * agents;
+    return (b + 15) & ~15;
+}
+
+// k-th set bit of (hi:lo), -1 if there is none
+__device__ __forceinline__ int kth_bit(unsigned long long lo, unsigned long long hi, int k) {
+    int slot = -1;
+    while (k >= 0) {
+        if (lo) {
+            slot = __ffsll((long long)lo) - 1;
+            lo &= lo - 1;
+        } else if (hi) {
+            slot = 64 + __ffsll((long long)hi) - 1;
+            hi &= hi - 1;
+        } else {
+            return -1;
+        }
+        --k;
+    }
+    return slot;
+}
+
+template <bool RESPAWN>
+__global__ __launch_bounds__(64 * kWaveEnvs) void wave_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
+                                                                  int lidar_stride, int lidar_offset) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // blockDim.x / 64 envs per workgroup (<= kWaveEnvs)
+    if (e >= c.n_envs) return;   // whole wave
+    const int cap = c.cap;
+    const int A = c.agents_per_env;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* base = smem + (size_t)(threadIdx.x >> 6) * wave_env_lds_bytes(cap, A);
+    MdShape* l_shape = reinterpret_cast<MdShape*>(base);
+    MdDyn* l_dyn = reinterpret_cast<MdDyn*>(l_shape + cap);
+    MdPid* l_pid = reinterpret_cast<MdPid*>(l_dyn + cap);
+    MdParam* l_param = reinterpret_cast<MdParam*>(l_pid + cap);
+    MdNav* l_nav = reinterpret_cast<MdNav*>(l_param + cap);
+    float* l_action = reinterpret_cast<float*>(l_nav + cap);
+    uint32_t* l_flags = reinterpret_cast<uint32_t*>(l_action + 2 * cap);
+    int32_t* l_final = reinterpret_cast<int32_t*>(l_flags + cap);
+    uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_final + cap);
+    uint32_t* l_cfl = l_onlane + cap;
+    float* l_scratch = reinterpret_cast<float*>(l_cfl + cap);
+    unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_scratch + 48);
+    const bool track_det = RESPAWN && g.detected != nullptr;
+
+    const MdState gv = md_env_view(&g, &c, e);
+    const int reset_flag = gv.need_reset[0];
+    MD_STAMP_AT(0);
+    const int m = w.env_map[e];
+    const MdLane* lanes = w.lanes + w.lane_off[m];
+    const MdRoad* roads = w.roads + w.road_off[m];
+    const bool fused_act = gv.agent_action != nullptr;
+
+    // ---- stage-in: every global load is issued before the first LDS store (one memory round trip) ----
+    {
+        const int n32 = cap * 2, n64 = cap * 4;   // 16-byte units
+        const uint4* g_shape = reinterpret_cast<const uint4*>(gv.shape);
+        const uint4* g_dyn = reinterpret_cast<const uint4*>(gv.dyn);
+        const uint4* g_pid = reinterpret_cast<const uint4*>(gv.pid);
+        const uint4* g_param = reinterpret_cast<const uint4*>(gv.param);
+        const uint4* g_nav = reinterpret_cast<const uint4*>(gv.nav);
+        uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_nav1;
+        float2 r_act;
+        uint32_t r_fl;
+        int r_fin;
+        const bool p32 = lane < n32, pc = lane < cap;
+        if (p32) {
+            r_shape = g_shape[lane];
+            r_dyn = g_dyn[lane];
+            r_pid = g_pid[lane];
+            r_param = g_param[lane];
+        }
+        if (lane < n64) r_nav0 = g_nav[lane];
+        if (lane + 64 < n64) r_nav1 = g_nav[lane + 64];
+        if (pc) {
+            r_act = (fused_act && lane < A) ? reinterpret_cast<const float2*>(gv.agent_action)[lane]
+                                            : reinterpret_cast<const float2*>(gv.action)[lane];
+            r_fl = gv.flags[lane];
+            r_fin = gv.final_lane ? gv.final_lane[lane] : 0;
+        }
+        if (p32) {
+            reinterpret_cast<uint4*>(l_shape)[lane] = r_shape;
+            reinterpret_cast<uint4*>(l_dyn)[lane] = r_dyn;
+            reinterpret_cast<uint4*>(l_pid)[lane] = r_pid;
+            reinterpret_cast<uint4*>(l_param)[lane] = r_param;
+        }
+        if (lane < n64) reinterpret_cast<uint4*>(l_nav)[lane] = r_nav0;
+        if (lane + 64 < n64) reinterpret_cast<uint4*>(l_nav)[lane + 64] = r_nav1;
+        if (pc) {
+            reinterpret_cast<float2*>(l_action)[lane] = r_act;
+            l_flags[lane] = r_fl;
+            l_final[lane] = r_fin;
+        }
+        // capacities beyond 32 slots (accident scenes with many props): the tails, in plain loops
+        for (int i = lane + 64; i < n32; i += 64) {
+            reinterpret_cast<uint4*>(l_shape)[i] = g_shape[i];
+            reinterpret_cast<uint4*>(l_dyn)[i] = g_dyn[i];
+            reinterpret_cast<uint4*>(l_pid)[i] = g_pid[i];
+            reinterpret_cast<uint4*>(l_param)[i] = g_param[i];
+        }
+        for (int i = lane + 128; i < n64; i += 64) reinterpret_cast<uint4*>(l_nav)[i] = g_nav[i];
+        for (int j = lane + 64; j < cap; j += 64) {
+            const float* src = (fused_act && j < A) ? gv.agent_action : gv.action;
+            l_action[2 * j] = src[2 * j];
+            l_action[2 * j + 1] = src[2 * j + 1];
+            l_flags[j] = gv.flags[j];
+            l_final[j] = gv.final_lane ? gv.final_lane[j] : 0;
+        }
+        if (track_det)
+            for (int j = lane; j < 2 * A; j += 64) l_det[j] = 0ull;
+    }
+    const bool do_reset = reset_flag != 0;   // wave-uniform
+    const int just_reset = do_reset ? 1 : 0;
+    if (do_reset) {
+        wave_sync();
+        const uint4* s0 = reinterpret_cast<const uint4*>(gv.shape0);
+        const uint4* d0 = reinterpret_cast<const uint4*>(gv.dyn0);
+        const uint4* p0 = reinterpret_cast<const uint4*>(gv.pid0);
+        const uint4* n0 = reinterpret_cast<const uint4*>(gv.nav0);
+        for (int i = lane; i < cap * 2; i += 64) {
+            reinterpret_cast<uint4*>(l_shape)[i] = s0[i];
+            reinterpret_cast<uint4*>(l_dyn)[i] = d0[i];
+            reinterpret_cast<uint4*>(l_pid)[i] = p0[i];
+        }
+        for (int i = lane; i < cap * 4; i += 64) reinterpret_cast<uint4*>(l_nav)[i] = n0[i];
+        for (int j = lane; j < cap; j += 64) {
+            l_action[2 * j] = 0.0f;
+            l_action[2 * j + 1] = 0.0f;
+            l_flags[j] = 0u;
+        }
+        if (RESPAWN && (c.traffic_mode == 1 || c.traffic_mode == 2)) {   // respawns rewrote the routes: restore them too
+            for (int i = lane; i < cap * MD_ROUTE_LEN; i += 64) {
+                gv.route_nodes[i] = gv.route_nodes0[i];
+                gv.route_roads[i] = gv.route_roads0[i];
+            }
+            for (int j = lane; j < cap; j += 64) l_final[j] = gv.final_lane0[j];
+        }
+    }
+    MdState s = gv;   // env-local view whose hot arrays live in this wave's LDS image
+    s.shape = l_shape;
+    s.dyn = l_dyn;
+    s.nav = l_nav;
+    s.pid = l_pid;
+    s.action = l_action;
+    s.flags = l_flags;
+    s.param = l_param;
+    s.final_lane = l_final;
+    wave_sync();
+    MD_STAMP_AT(1);
+
+    // agent_policy = IDMPolicy: the agents are planned like the traffic, in the reference's order (decide, then move);
+    // otherwise the traffic is planned one step AHEAD, at the end of the step (see env_kernel)
+    const bool agent_idm = RESPAWN && c.agent_idm != 0;
+    const bool plan_ahead = !agent_idm;
+    if (!just_reset && !plan_ahead) {
+        trigger_env(lanes, s, c, lane);
+        wave_sync();
+        for (int j0 = 0; j0 < cap; j0 += 64) {
+            const int jj = j0 + lane;
+            const unsigned long long mk = __ballot(jj < cap && md_drives(s.shape[jj < cap ? jj : 0].flags));
+            if (mk) idm_group_wave(w, lanes, roads, s, c, m, j0, mk, lane, reinterpret_cast<int*>(l_scratch));
+        }
+        wave_sync();
+    }
+    MD_STAMP_AT(3);
+    // the slots that drive in this step (the integration does not change any slot's flags)
+    unsigned long long drv_lo = 0ull, drv_hi = 0ull;
+    for (int j0 = 0; j0 < cap; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long mk = __ballot(j < cap && md_drives(s.shape[j < cap ? j : 0].flags));
+        if (j0 == 0) drv_lo = mk;
+        else drv_hi = mk;
+    }
+    if (!just_reset) {
+        for (int j = lane; j < cap; j += 64) {
+            if (RESPAWN) md_advance_mover(&s, &c, j);
+            else md_integrate_mover(&s, &c, j);
+        }
+        if (!RESPAWN)
+            for (int j = lane; j < cap; j += 64) md_walk_mover(&s, &c, j);
+        wave_sync();
+    }
+    MD_STAMP_AT(4);
+    // ---- localisation of every driving vehicle, contacts of every driving agent ----
+    {
+        const unsigned long long a_lo = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
+        const unsigned long long a_hi = A <= 64 ? 0ull : (A >= 128 ? ~0ull : ((1ull << (A - 64)) - 1ull));
+        const unsigned long long adrv_lo = drv_lo & a_lo, adrv_hi = drv_hi & a_hi;
+        const int nd = __popcll(drv_lo) + __popcll(drv_hi);
+        const int na = __popcll(adrv_lo) + __popcll(adrv_hi);
+        // one vehicle: the whole wave, its data in scalar registers; two: 32 lanes each; more: 16 lanes each, four per pass
+        if (nd == 1) localize_vehicle(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, 0), lane, l_onlane);
+        else if (nd == 2) localize_pair(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, 0), kth_bit(drv_lo, drv_hi, 1), lane, l_onlane);
+        else
+            for (int item = 0; item < nd; item += 4)
+                localize_group<16>(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, item), kth_bit(drv_lo, drv_hi, item + 1),
+                                   kth_bit(drv_lo, drv_hi, item + 2), kth_bit(drv_lo, drv_hi, item + 3), lane, l_onlane);
+        for (int k = 0; k < na; ++k) contacts_vehicle(w, s, c, e, kth_bit(adrv_lo, adrv_hi, k), lane, l_cfl);
+    }
+    wave_sync();
+    MD_STAMP_AT(6);
+    // ---- flags of the slots that drove; traffic that left every lane is removed ----
+    for (int j = lane; j < cap; j += 64) {
+        const bool drove = (((j < 64) ? (drv_lo >> j) : (drv_hi >> (j - 64))) & 1ull) != 0ull;
+        if (!drove) continue;
+        const int f = s.shape[j].flags;
+        s.flags[j] = l_onlane[j] | ((f & MD_F_AGENT) ? l_cfl[j] : 0u);
+        if (!(f & MD_F_AGENT) && !(s.flags[j] & MD_FL_ON_LANE)) {
+            s.shape[j].flags = f & ~MD_F_ALIVE;
+            l_cfl[j] = kRemovedMark;
+        }
+    }
+    wave_sync();
+    if (plan_ahead) {   // next step's trigger: the agents' final lanes, the PENDING slots
+        trigger_env(lanes, s, c, lane);
+        wave_sync();
+    }
+    if (RESPAWN) {   // respawn / hybrid: the removed vehicle re-enters on a respawn lane (rare; serial)
+        if (lane == 0) md_traffic_respawn_env(&w, lanes, &s, &c, m);
+        wave_sync();
+    }
+    MD_STAMP_AT(7);
+    // ---- next step's traffic decisions, then the agents' observations (disjoint data: either order gives the same) ----
+    if (plan_ahead) {
+        for (int j0 = 0; j0 < cap; j0 += 64) {
+            const int jj = j0 + lane;
+            const unsigned long long mk = __ballot(jj < cap && jj >= A && md_drives(s.shape[jj < cap ? jj : 0].flags) &&
+                                                   !(s.shape[jj < cap ? jj : 0].flags & MD_F_AGENT));
+            if (mk) idm_group_wave(w, lanes, roads, s, c, m, j0, mk, lane, reinterpret_cast<int*>(l_scratch));
+            wave_sync();
+        }
+    }
+    MD_STAMP_AT(8);
+    for (int a = 0; a < A; ++a) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+    MD_STAMP_AT(9);
+    // ---- lidar: the sectors of every agent, one after the other ----
+    if (c.n_beams > 0) {
+        const int nsec = (c.n_beams + 63) >> 6;
+        for (int a = 0; a < A; ++a) {
+            float* row = lidar_out + (size_t)(e * A + a) * lidar_stride + lidar_offset;
+            for (int sec = 0; sec < nsec; ++sec) lidar_item(w, s, c, a, sec, lane, row, track_det ? l_det + 2 * a : nullptr);
+        }
+    }
+    wave_sync();
+    MD_STAMP_AT(10);
+    // ---- write-back (16-byte stores) ----
+    if (!do_reset) {
+        // only slots that move now (agents, traffic incl. the just triggered / respawned, walking participants) or were
+        // removed in this step can differ from what HBM already holds
+        const bool replay = RESPAWN && c.traffic_mode == 3;   // replayed slots move without "driving"
+        auto dirty = [&](int j) { return replay || md_moves(l_shape[j].flags) || l_cfl[j] == kRemovedMark; };
+        for (int i = lane; i < cap * 2; i += 64)
+            if (dirty(i >> 1)) {
+                reinterpret_cast<uint4*>(gv.shape)[i] = reinterpret_cast<const uint4*>(l_shape)[i];
+                reinterpret_cast<uint4*>(gv.dyn)[i] = reinterpret_cast<const uint4*>(l_dyn)[i];
+                reinterpret_cast<uint4*>(gv.pid)[i] = reinterpret_cast<const uint4*>(l_pid)[i];
+            }
+        for (int i = lane; i < cap * 4; i += 64)
+            if (dirty(i >> 2)) reinterpret_cast<uint4*>(gv.nav)[i] = reinterpret_cast<const uint4*>(l_nav)[i];
+        for (int j = lane; j < cap; j += 64)
+            if (dirty(j)) {
+                reinterpret_cast<float2*>(gv.action)[j] = reinterpret_cast<const float2*>(l_action)[j];
+                gv.flags[j] = l_flags[j];
+                if (RESPAWN) gv.final_lane[j] = l_final[j];
+            }
+    } else {
+        for (int i = lane; i < cap * 2; i += 64) {
+            reinterpret_cast<uint4*>(gv.shape)[i] = reinterpret_cast<const uint4*>(l_shape)[i];
+            reinterpret_cast<uint4*>(gv.dyn)[i] = reinterpret_cast<const uint4*>(l_dyn)[i];
+            reinterpret_cast<uint4*>(gv.pid)[i] = reinterpret_cast<const uint4*>(l_pid)[i];
+        }
+        for (int i = lane; i < cap * 4; i += 64) reinterpret_cast<uint4*>(gv.nav)[i] = reinterpret_cast<const uint4*>(l_nav)[i];
+        for (int j = lane; j < cap; j += 64) {
+            reinterpret_cast<float2*>(gv.action)[j] = reinterpret_cast<const float2*>(l_action)[j];
+            gv.flags[j] = l_flags[j];
+            if (RESPAWN && gv.final_lane) gv.final_lane[j] = l_final[j];
+        }
+        if (lane == 0) gv.need_reset[0] = 0;
+    }
+    if (track_det)
+        for (int j = lane; j < 2 * A; j += 64) gv.detected[j] = l_det[j];
+    MD_STAMP_AT(11);
+}
+
 // "Others" block of the observation (Lidar.get_surrounding_vehicles_info): one thread per agent, after the
 // step kernel has written the detected sets and the new state back.  Off in the headline configs.
 __global__ __launch_bounds__(64) void others_kernel(MdWorld w, MdState g, MdConfig c) {
@@ -1470,9 +1850,47 @@ int need(const void* p, const char* name) {
     return MD_EINVAL;
 }
 
+// md_step of the single-agent envs has two kernels: env_kernel (one 4-wave workgroup per env, the default) and
+// wave_step_kernel (one wave per env), chosen by MdConfig.step_kernel; MD_STEP_KERNEL=wave / wg in the environment
+// overrides the config (A/B measurements).
+bool use_wave_kernel(const MdConfig* c) {
+    static const int forced = [] {
+        const char* v = getenv("MD_STEP_KERNEL");
+        if (!v) return 0;
+        return (v[0] == 'w' && v[1] == 'a') ? 1 : ((v[0] == 'w' && v[1] == 'g') ? 2 : 0);
+    }();
+    if (c->is_multi_agent) return false;
+    if (forced) return forced == 1;
+    return c->step_kernel == 1;
+}
+
+int launch_wave_step(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
+                     void* stream) {
+    const size_t per_env = (size_t)wave_env_lds_bytes(c->cap, c->agents_per_env);
+    int per_wg = kWaveEnvs;   // envs per workgroup: as many as fit 64 KB of LDS (capacity-128 accident scenes: 2)
+    while (per_wg > 1 && per_wg * per_env > 64 * 1024) per_wg >>= 1;
+    const size_t lds = per_wg * per_env;
+    if (lds > 64 * 1024) {
+        snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d); limit 65536", lds, c->cap);
+        return MD_EINVAL;
+    }
+    const dim3 grid((c->n_envs + per_wg - 1) / per_wg);
+    const hipStream_t st = (hipStream_t)stream;
+    const bool general = c->traffic_mode != 0 || c->agent_idm != 0 || s->detected != nullptr;
+    if (general) hipLaunchKernelGGL((wave_step_kernel<true>), grid, dim3(64 * per_wg), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    else hipLaunchKernelGGL((wave_step_kernel<false>), grid, dim3(64 * per_wg), lds, st, *w, *s, *c, lidar_out, stride, offset);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
+
 template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
+    if (PH == PH_ALL && use_wave_kernel(c)) return launch_wave_step(w, s, c, lidar_out, stride, offset, stream);
     const bool stage = w->max_lanes <= kStageMaxLanes;
     constexpr bool kCanMultiLds = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;  // same rule as the MULTI kernel variant below
     // the lidar-only kernel stages nothing but the shapes: asking for the full image would cost it occupancy

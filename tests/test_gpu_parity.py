@@ -8,6 +8,15 @@ from helpers import assert_state_equal, make_cfg, scripted_actions
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["wg", "wave"])
+def step_kernel(request, monkeypatch):
+    """Every parity case runs with both md_step kernels of the single-agent envs (MdConfig.step_kernel): one 4-wave
+    workgroup per env, and one wave per env.  (Multi-agent configs always take the workgroup kernel.)"""
+    from metadrive_ped_amd import config
+    monkeypatch.setitem(config.BATCH_DEFAULT_CONFIG, "step_kernel", request.param)
+    return request.param
+
+
 def _engine_and_oracle(cs_dist, **kw):
     import torch
     from metadrive_ped_amd.engine import BatchedEngine

@@ -10,17 +10,20 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    import torch
     from metadrive_ped_amd.config import make_config
-    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
     E = 4096
+    sizes = [int(x) for x in os.environ.get("MAPS", "1,8,64,512,4096").split(",")]
+    cfgs = {S: make_config(dict(num_envs=E, num_scenarios=S, horizon=1000, mover_capacity=32)) for S in sizes}
+    hosts = {S: HostScene(cfgs[S]) for S in sizes}     # host-side generation (fork pool) before the GPU is touched
+    import torch
     g = torch.Generator().manual_seed(0)
     acts = torch.rand(64, E, 1, 2, generator=g) * 2 - 1
     acts[..., 1] = acts[..., 1].abs() * 0.9 + 0.1
     acts[..., 0] *= 0.25
     acts = acts.cuda()
-    for S in (1, 8, 64, 512, 4096):
-        eng = BatchedEngine(make_config(dict(num_envs=E, num_scenarios=S, horizon=1000, mover_capacity=32)))
+    for S in sizes:
+        eng = BatchedEngine(cfgs[S], host=hosts[S])
         eng.reset()
         for i in range(60):
             eng.step(acts[i % 64])

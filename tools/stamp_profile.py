@@ -17,8 +17,15 @@ PHASES = ["stage-in", "trigger (idm-first variants)", "idm before integrate", "i
           "wait for the idm waves", "write-back"]
 
 
+WAVE_PHASES = ["stage-in", "trigger + idm (idm-first variants)", "-", "integrate", "-", "locate: localize + contacts",
+               "traffic + next trigger", "idm for the next step", "observe", "lidar", "write-back"]
+
+
 def main():
     import numpy as np
+    global PHASES
+    if os.environ.get("MD_STEP_KERNEL", "") != "wg":
+        PHASES = WAVE_PHASES     # wave_step_kernel (build with MD_EXTRA_FLAGS=-DMD_WAVE_ENVS=1: one env per workgroup)
     out = os.path.join(ROOT, "gpurun_out", "libmdstep_stamp.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
