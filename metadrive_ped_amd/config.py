@@ -109,7 +109,8 @@ BATCH_DEFAULT_CONFIG = dict(
     device="cuda:0",
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
-    step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same results)
+    step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same
+                            # results bit for bit; a machine-mapping choice)
 )
 
 # Keys of the reference's BASE_DEFAULT_CONFIG (envs/base_env.py:32-266) that only concern rendering, cameras, the GUI,

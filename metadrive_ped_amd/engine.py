@@ -249,7 +249,7 @@ class HostScene:
         self.md_config.random_agent_model = int(bool(cfg["random_agent_model"]))
         self.md_config.agent_idm = int(cfg["agent_policy"] == "IDMPolicy")
         self.md_config.enable_reverse = int(bool(cfg["vehicle_config"]["enable_reverse"]))
-        self.md_config.step_kernel = 1 if cfg.get("step_kernel", "wg") == "wave" else 0
+        self.md_config.step_kernel = {"wg": 0, "wave": 1}[cfg.get("step_kernel", "wg")]
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
