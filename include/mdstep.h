@@ -189,6 +189,29 @@ typedef struct MdGrid {
     int32_t spare[2];
 } MdGrid;
 
+/* 48-byte polyline segment (utils/interpolating_line.py:96-140 `segment_property`): what PointLane --
+ * the SDC's reference trajectory and every TrajectoryIDMPolicy route -- is made of.  Scenario mode only. */
+typedef struct MdSeg {
+    float sx, sy;        /* start_point                                                          */
+    float ex, ey;        /* end_point                                                            */
+    float dx, dy;        /* direction (unit)                                                     */
+    float len;           /* length                                                               */
+    float heading;       /* atan2(end - start)                                                   */
+    float cum;           /* sum of the lengths of the segments before this one                   */
+    float spare[3];
+} MdSeg;
+
+/* MdWorld.track_meta[n][4] (scenario mode): first valid run [t0, t1) of the track in slot n and MD_TM_* bits */
+#define MD_TM_MOVING 1      /* not a "static car": max std of its valid positions > STATIC_THRESHOLD (scenario_traffic_manager.py:176-181) */
+#define MD_TM_LENGTH_OK 2   /* start -> end of the run farther than IDM_CREATE_MIN_LENGTH (:226-228)   */
+#define MD_TM_NEVER 4       /* never spawned: noise object (:286-291), unsupported type, empty track    */
+
+/* Scenario-mode slot state lives in MdNav: ck0 = MD_SC_* mode, timer = TrajectoryIDMPolicy.policy_index */
+#define MD_SC_ABSENT 0      /* not in the world (not yet valid, removed, filtered): a spawn is tried every step */
+#define MD_SC_REPLAY 1      /* ReplayTrafficParticipantPolicy: pose from the track                        */
+#define MD_SC_IDM 2         /* TrajectoryIDMPolicy: drives along its own recorded path                    */
+#define MD_SC_ARRIVED 3     /* IDM vehicle inside its destination region: removed at the end of this step */
+
 /* Static world: everything fixed between resets. */
 typedef struct MdWorld {
     int32_t n_maps;
@@ -220,6 +243,17 @@ typedef struct MdWorld {
     const int32_t* spawn_route_meta; /* [n_places][n_dest][2]: route_len, final_lane              */
     int32_t n_dest;            /* destinations per spawn place                                   */
     int32_t pad0;
+    /* scenario mode (traffic_mode 4; NULL otherwise): polylines per mover slot, the SDC route's checkpoints */
+    const int32_t* poly_off;   /* [n_envs * cap + 1] CSR into segs: slot 0 = the SDC's reference trajectory
+                                  (ScenarioMapManager.current_sdc_route, manager/scenario_map_manager.py:49-63), slot j = the
+                                  path of track j over its first valid run (get_idm_route, scenario/parse_object_state.py:19-21) */
+    const MdSeg* segs;
+    const int32_t* polyv_off;  /* [n_envs * cap + 1] CSR into polyv: outline of that path at width 2 (PointLane.auto_generate_polygon,
+                                  component/lane/point_lane.py:60-106): what lane.point_on_lane tests                              */
+    const float* polyv;        /* [n_vertices][2]                                                */
+    const int32_t* ckpt_off;   /* [n_envs + 1] CSR into ckpt_xy: TrajectoryNavigation.checkpoints (trajectory_navigation.py:96-103) */
+    const float* ckpt_xy;      /* [n_ckpt][2]                                                    */
+    const int32_t* track_meta; /* [n_envs * cap][4]: t0, t1, MD_TM_* bits, 0                       */
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */
@@ -293,7 +327,8 @@ typedef struct MdConfig {
     int32_t out_of_route_done, on_continuous_line_done;
     int32_t crash_vehicle_done, crash_object_done, crash_human_done;
     int32_t truncate_as_terminate;
-    int32_t traffic_mode;      /* 0 trigger, 1 respawn, 2 hybrid (manager/traffic_manager.py:20-29), 3 replay of recorded tracks */
+    int32_t traffic_mode;      /* 0 trigger, 1 respawn, 2 hybrid (manager/traffic_manager.py:20-29), 3 replay of recorded tracks,
+                                * 4 scenario (ScenarioEnv: envs/scenario_env.py, manager/scenario_traffic_manager.py)              */
     int32_t enable_idm_lane_change;
     int32_t auto_reset;        /* 1: md_step restores envs whose need_reset flag is set          */
     float max_lane_width;      /* BaseMap.MAX_LANE_WIDTH 4.5                                     */
@@ -318,6 +353,13 @@ typedef struct MdConfig {
                                 * Single-agent envs only. */
     int32_t enable_reverse;    /* vehicle_config.enable_reverse: an agent's negative throttle drives it backwards instead of
                                 * braking (base_vehicle.py:476-484) */
+    /* scenario mode (traffic_mode 4): ScenarioEnv reward / cost / termination scheme (envs/scenario_env.py:21-95) */
+    float on_lane_line_penalty, crash_human_penalty, steering_range_penalty, heading_penalty, lateral_penalty;
+    float max_lateral_dist, crash_human_cost;
+    int32_t no_negative_reward, relax_out_of_road_done;
+    int32_t reactive_traffic, filter_overlapping_car, no_static_vehicles;
+    int32_t allowed_more_steps;/* 0 = None                                                       */
+    int32_t scenario_length;   /* frames of the scenarios (data_manager.current_scenario_length)  */
     int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env.
                                 * Same results bit for bit; a machine-mapping choice, no reference counterpart. */
 } MdConfig;

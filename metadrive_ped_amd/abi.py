@@ -60,12 +60,16 @@ LANE_DT = np.dtype([("type", i4), ("road", i4), ("idx", i4), ("n_in_road", i4), 
                     ("elx", f4), ("ely", f4), ("spare", f4, (4, )), ("hull4", f4, (8, ))])
 ROAD_DT = np.dtype([("first_lane", i4), ("n_lanes", i4), ("start_node", i4), ("end_node", i4), ("negative", i4),
                     ("block", i4), ("spare", i4, (2, ))])
+SEG_DT = np.dtype([("sx", f4), ("sy", f4), ("ex", f4), ("ey", f4), ("dx", f4), ("dy", f4), ("len", f4), ("heading", f4),
+                   ("cum", f4), ("spare", f4, (3, ))])
+TM_MOVING, TM_LENGTH_OK, TM_NEVER = 1, 2, 4
+SC_ABSENT, SC_REPLAY, SC_IDM, SC_ARRIVED = 0, 1, 2, 3
 GRID_DT = np.dtype([("x0", f4), ("y0", f4), ("inv_cell", f4), ("nx", i4), ("ny", i4), ("cell_base", i4),
                     ("spare", i4, (2, ))])
 
 assert SHAPE_DT.itemsize == 32 and DYN_DT.itemsize == 32 and PARAM_DT.itemsize == 32
 assert NAV_DT.itemsize == 64 and PID_DT.itemsize == 32 and LANE_DT.itemsize == 160
-assert ROAD_DT.itemsize == 32 and GRID_DT.itemsize == 32
+assert ROAD_DT.itemsize == 32 and GRID_DT.itemsize == 32 and SEG_DT.itemsize == 48
 
 P = C.c_void_p
 
@@ -79,6 +83,7 @@ class MdWorld(C.Structure):
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
         ("n_dest", C.c_int32), ("pad0", C.c_int32),
+        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P),
     ]
 
 
@@ -118,6 +123,12 @@ class MdConfig(C.Structure):
         ("random_agent_model", C.c_int32),
         ("agent_idm", C.c_int32),
         ("enable_reverse", C.c_int32),
+        ("on_lane_line_penalty", C.c_float), ("crash_human_penalty", C.c_float), ("steering_range_penalty", C.c_float),
+        ("heading_penalty", C.c_float), ("lateral_penalty", C.c_float), ("max_lateral_dist", C.c_float),
+        ("crash_human_cost", C.c_float),
+        ("no_negative_reward", C.c_int32), ("relax_out_of_road_done", C.c_int32), ("reactive_traffic", C.c_int32),
+        ("filter_overlapping_car", C.c_int32), ("no_static_vehicles", C.c_int32), ("allowed_more_steps", C.c_int32),
+        ("scenario_length", C.c_int32),
         ("step_kernel", C.c_int32),
     ]
 

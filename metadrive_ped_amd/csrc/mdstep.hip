@@ -26,7 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "md_entity.h"
+#include "md_scenario.h"
 
 namespace {
 
@@ -1794,6 +1794,209 @@ __global__ __launch_bounds__(64 * kWaveEnvs) void wave_step_kernel(MdWorld w, Md
     MD_STAMP_AT(11);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Scenario mode (MdConfig.traffic_mode 4): one ScenarioEnv step per launch, one 4-wave workgroup per scene.
+//   stage-in     the scene's mover state -> LDS
+//   decide       one WAVE per reactive vehicle (TrajectoryIDMPolicy): projection on its own path with one LANE per
+//                polyline segment + wavefront arg-min; arrival; every fifth step (staggered by policy_index) the
+//                front search: one lane per candidate object (20 m, any chassis corner inside the path's outline),
+//                arg-min of the gaps; PID steering + IDM acceleration on lane 0
+//   integrate    one thread per mover (agent + reactive vehicles; replayed ones are kinematic)
+//   after_step   wave 0: one lane per track slot -- replay pose of frame k / removal / spawn; the spawns that get a
+//                reactive policy take consecutive policy indices through a ballot prefix count (slot order, as the
+//                reference's dict order)
+//   agent        wave 0 projects the agent on the reference trajectory (lanes = segments) while wave 1 runs its contacts
+//   observe      lane 0 of wave 0: state + 22 navigation dims + ScenarioEnv reward / cost / done; lidar sectors on all waves
+// The scalar logic is include/md_scenario.h, shared with the oracle (which runs the serial forms).
+// ------------------------------------------------------------------------------------------------
+// InterpolatingLine.local_coordinates by one wave: lanes = segments (chunks of 64), first minimum wins like np.argmin
+__device__ __forceinline__ int poly_argmin_wave(const MdPoly& p, float px, float py, int lane_id) {
+    float bd = 3.0e38f;
+    int bi = 0;
+    for (int i0 = 0; i0 < p.n; i0 += 64) {
+        const int i = i0 + lane_id;
+        float d = (i < p.n) ? md_seg_dist(&p.segs[i], px, py) : 3.0e38f;
+        int idx = i;
+        wave_argmin(d, idx);   // ascending lane order = ascending segment index: equal distances keep the first
+        if (d < bd) {
+            bd = d;
+            bi = idx;
+        }
+    }
+    return bi;
+}
+
+// first segment (ascending) for which `pred` holds, else the last one; pred evaluated by one lane per segment
+template <typename F>
+__device__ __forceinline__ int poly_first_wave(const MdPoly& p, int lane_id, F pred) {
+    for (int i0 = 0; i0 < p.n; i0 += 64) {
+        const int i = i0 + lane_id;
+        const unsigned long long m = __ballot(i < p.n && pred(p.segs[i]));
+        if (m) return i0 + __ffsll((long long)m) - 1;
+    }
+    return p.n - 1;
+}
+
+__device__ __forceinline__ void traj_locate_wave(const MdPoly& p, float px, float py, int lane_id, MdTrajLoc* o) {
+    const int best = poly_argmin_wave(p, px, py, lane_id);
+    md_poly_local_at(&p, best, px, py, &o->lng, &o->lat);
+    const float lng = o->lng;
+    const int ih = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len > lng; });
+    const int is = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len + 0.1f >= lng; });
+    o->heading_at = p.segs[ih].heading;
+    o->lat_dx = p.segs[is].dy;
+    o->lat_dy = -p.segs[is].dx;
+}
+
+// TrajectoryIDMPolicy.act of the vehicle in `slot` by one wave (md_tidm_vehicle is the serial form)
+__device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
+                                  int lane_id) {
+    const size_t ng = (size_t)e * c.cap + slot;
+    const MdPoly route = md_poly_of(&w, ng);
+    const float px = s.shape[slot].cx, py = s.shape[slot].cy;
+    const float length = route.length;
+    const int ie = poly_first_wave(route, lane_id, [length](const MdSeg& g) { return g.cum + g.len + 0.1f >= length; });
+    const MdSeg ge = route.segs[ie];
+    const float end_x = ge.sx + (length - ge.cum) * ge.dx, end_y = ge.sy + (length - ge.cum) * ge.dy;
+    if (md_norm(px - end_x, py - end_y) < MD_TIDM_DEST_RADIUS) {
+        if (lane_id == 0) s.nav[slot].ck0 = MD_SC_ARRIVED;
+        return;
+    }
+    const int do_speed_control = (k % MD_TIDM_BATCH) == s.nav[slot].timer;
+    const int best = poly_argmin_wave(route, px, py, lane_id);
+    float cur_long, tmp;
+    md_poly_local_at(&route, best, px, py, &cur_long, &tmp);
+    int front = -1;
+    float front_dist = MD_TIDM_MAX_DIST;
+    if (do_speed_control) {
+        const float* pv = w.polyv + 2 * (size_t)w.polyv_off[ng];
+        const int n_v = w.polyv_off[ng + 1] - w.polyv_off[ng];
+        for (int j0 = 0; j0 < c.cap; j0 += 64) {
+            const int j = j0 + lane_id;
+            float g = -1.0f;
+            if (j < c.cap && j != slot) g = md_tidm_front_gap(&route, pv, n_v, cur_long, px, py, &s.shape[j]);
+            float key = (g > 0.0f && g < MD_TIDM_MAX_DIST) ? g : 3.0e38f;
+            int idx = j;
+            wave_argmin(key, idx);
+            if (key < front_dist) {
+                front_dist = key;
+                front = idx;
+            }
+        }
+    }
+    if (lane_id == 0) md_tidm_decide(&route, &s, slot, do_speed_control, front, front_dist, cur_long);
+}
+
+__global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, int lidar_stride,
+                                                           int lidar_offset) {
+    constexpr int kBlock = 256, kWaves = 4;
+    const int e = blockIdx.x;
+    if (e >= c.n_envs) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int cap = c.cap, A = c.agents_per_env;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MdShape* l_shape = reinterpret_cast<MdShape*>(smem);
+    MdDyn* l_dyn = reinterpret_cast<MdDyn*>(l_shape + cap);
+    MdPid* l_pid = reinterpret_cast<MdPid*>(l_dyn + cap);
+    MdParam* l_param = reinterpret_cast<MdParam*>(l_pid + cap);
+    MdNav* l_nav = reinterpret_cast<MdNav*>(l_param + cap);
+    float* l_action = reinterpret_cast<float*>(l_nav + cap);
+    uint32_t* l_flags = reinterpret_cast<uint32_t*>(l_action + 2 * cap);
+    uint32_t* l_cfl = l_flags + cap;
+    MdTrajLoc* l_loc = reinterpret_cast<MdTrajLoc*>(l_cfl + ((cap + 3) & ~3));   // [A]
+    int* l_count = reinterpret_cast<int*>(l_loc + A);
+
+    const MdState gv = md_env_view(&g, &c, e);
+    const int reset_flag = gv.need_reset[0];
+    const bool fused_act = gv.agent_action != nullptr;
+    const bool do_reset = reset_flag != 0;
+    copy16(l_shape, do_reset ? gv.shape0 : gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
+    copy16(l_dyn, do_reset ? gv.dyn0 : gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+    copy16(l_pid, do_reset ? gv.pid0 : gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
+    copy16(l_nav, do_reset ? gv.nav0 : gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
+    copy16(l_param, gv.param, cap * (int)sizeof(MdParam), tid, kBlock);
+    for (int j = tid; j < cap; j += kBlock) {
+        if (do_reset) {
+            l_action[2 * j] = 0.0f;
+            l_action[2 * j + 1] = 0.0f;
+            l_flags[j] = 0u;
+        } else {
+            const float* src = (fused_act && j < A) ? gv.agent_action : gv.action;
+            l_action[2 * j] = src[2 * j];
+            l_action[2 * j + 1] = src[2 * j + 1];
+            l_flags[j] = gv.flags[j];
+        }
+    }
+    if (tid == 0) *l_count = do_reset ? 0 : gv.next_agent_id[0];   // idm_policy_count
+    MdState s = gv;
+    s.shape = l_shape;
+    s.dyn = l_dyn;
+    s.nav = l_nav;
+    s.pid = l_pid;
+    s.action = l_action;
+    s.flags = l_flags;
+    s.param = l_param;
+    s.next_agent_id = l_count;
+    __syncthreads();
+    const int just_reset = do_reset ? 1 : 0;
+    const int k = just_reset ? 0 : s.nav[0].steps + 1;   // engine.episode_step of this step
+    if (!just_reset) {
+        for (int j = A + wave; j < cap; j += kWaves)
+            if (s.nav[j].ck0 == MD_SC_IDM && md_present(s.shape[j].flags)) tidm_vehicle_wave(w, s, c, e, j, k, lane);
+        __syncthreads();
+        for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
+        __syncthreads();
+    }
+    // ---- after_step of the traffic manager: lanes = track slots, in slot order ----
+    if (wave == 0) {
+        for (int j0 = A; j0 < cap; j0 += 64) {
+            const int j = j0 + lane;
+            const bool in = j < cap;
+            const int wants = in ? md_scenario_slot_after_step(&w, &s, &c, e, j, k, 0, 1) : 0;
+            const unsigned long long m = __ballot(wants != 0);
+            const int before = *l_count + __popcll(m & ((1ull << lane) - 1ull));
+            if (in) md_scenario_slot_after_step(&w, &s, &c, e, j, k, before, 0);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *l_count += __popcll(m);
+            wave_sync();
+        }
+    }
+    __syncthreads();
+    // ---- the agents: projection on the reference trajectory (wave 0) beside their contacts (wave 1) ----
+    for (int a = 0; a < A; ++a) {
+        if (wave == 0) {
+            const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
+            MdTrajLoc L;
+            traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L);
+            if (lane == 0) l_loc[a] = L;
+        } else if (wave == 1) {
+            contacts_vehicle(w, s, c, e, a, lane, l_cfl);
+        }
+    }
+    __syncthreads();
+    if (tid < A) {
+        const int a = tid;
+        s.flags[a] = l_cfl[a];
+        const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
+        md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], ref.length);
+    }
+    if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
+    __syncthreads();
+    copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+    copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
+    copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
+    copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
+    for (int j = tid; j < cap; j += kBlock) {
+        gv.action[2 * j] = l_action[2 * j];
+        gv.action[2 * j + 1] = l_action[2 * j + 1];
+        gv.flags[j] = l_flags[j];
+    }
+    if (tid == 0) {
+        gv.next_agent_id[0] = *l_count;
+        if (do_reset) gv.need_reset[0] = 0;
+    }
+}
+
 // "Others" block of the observation (Lidar.get_surrounding_vehicles_info): one thread per agent, after the
 // step kernel has written the detected sets and the new state back.  Off in the headline configs.
 __global__ __launch_bounds__(64) void others_kernel(MdWorld w, MdState g, MdConfig c) {
@@ -1951,7 +2154,7 @@ int check_world(const MdWorld* w) {
 
 // traffic_mode respawn / hybrid: the respawn-lane tables, the env RNG and the route snapshot must be there
 int check_traffic_mode(const MdWorld* w, const MdState* s, const MdConfig* c) {
-    if (c->traffic_mode == 0) return MD_OK;
+    if (c->traffic_mode == 0 || c->traffic_mode == 4) return MD_OK;   // 4 (scenario): validated by md_step itself
     if (c->traffic_mode < 0 || c->traffic_mode > 3 || c->is_multi_agent) {
         snprintf(g_err, sizeof g_err, "traffic_mode=%d is not valid here (0 trigger, 1 respawn, 2 hybrid, 3 replay; "
                  "single-agent envs)", c->traffic_mode);
@@ -2200,6 +2403,34 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
     if (r != MD_OK) return r;
     r = check_traffic_mode(w, s, c);
     if (r != MD_OK) return r;
+    if (c->traffic_mode == 4) {   // scenario mode: its own kernel (ScenarioEnv step)
+        NEED(w->poly_off); NEED(w->segs); NEED(w->polyv_off); NEED(w->polyv); NEED(w->ckpt_off); NEED(w->ckpt_xy);
+        NEED(w->track_meta); NEED(s->track_shape); NEED(s->track_dyn); NEED(s->next_agent_id);
+        if (c->is_multi_agent || c->agents_per_env != 1 || c->track_len <= 0) {
+            snprintf(g_err, sizeof g_err, "scenario mode: single-agent scenes with track_len > 0 (got agents=%d track_len=%d)",
+                     c->agents_per_env, c->track_len);
+            return MD_EINVAL;
+        }
+        if (c->obs_dim != md_sc_obs_lidar(c) + c->n_beams) {
+            snprintf(g_err, sizeof g_err, "scenario mode: obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim,
+                     md_sc_obs_lidar(c), c->n_beams);
+            return MD_EINVAL;
+        }
+        const size_t lds = (size_t)c->cap * (4 * 32 + 64 + 8 + 4) + (size_t)((c->cap + 3) & ~3) * 4 +
+                           (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16;
+        if (lds > 64 * 1024) {
+            snprintf(g_err, sizeof g_err, "scenario mode: LDS image needs %zu B (cap=%d)", lds, c->cap);
+            return MD_EINVAL;
+        }
+        hipLaunchKernelGGL(scenario_step_kernel, dim3(c->n_envs), dim3(256), lds, (hipStream_t)stream, *w, *s, *c, s->obs, c->obs_dim,
+                           md_sc_obs_lidar(c));
+        hipError_t err4 = hipGetLastError();
+        if (err4 != hipSuccess) {
+            snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err4));
+            return MD_ELAUNCH;
+        }
+        return MD_OK;
+    }
     if (c->obs_dim != md_obs_lidar(c) + c->n_beams) {
         snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim, md_obs_lidar(c), c->n_beams);
         return MD_EINVAL;

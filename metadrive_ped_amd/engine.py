@@ -372,6 +372,10 @@ class BatchedEngine:
         self.dyn_f = sd["dyn"].view(torch.float32).view(self.E, self.cap, 8)
         self.nav_i = sd["nav"].view(torch.int32).view(self.E, self.cap, 16)
         self.agent_id = sd["agent_id"].view(torch.int32).view(self.E, self.cap) if "agent_id" in sd else None
+        if getattr(h, "tracks", None) is not None:     # scenario mode: the scenes' recorded frames come with the host scene
+            tr = h.tracks
+            self.set_tracks(dict(shape=torch.from_numpy(np.ascontiguousarray(tr["shape"]).view(np.uint8).reshape(tr["shape"].shape[0], -1)),
+                                 dyn=torch.from_numpy(np.ascontiguousarray(tr["dyn"])), seeds=tr["seeds"], cap=tr["cap"]))
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

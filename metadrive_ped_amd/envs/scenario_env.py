@@ -1,0 +1,88 @@
+"""BatchedScenarioEnv: the reset()/step() surface of the reference's ScenarioEnv (envs/scenario_env.py) for E
+lock-stepped scenes on one MI355X.  Scene e replays scenario description e of the list handed in (the reference reads
+them from `data_directory`; here they are passed as dicts in the same format, e.g. from BatchedMetaDriveEnv.
+export_scenarios() or metadrive_ped_amd.scenario.synthetic_scenarios()).
+
+Returns like the single-agent env: obs [E, obs_dim] (side cloud | state | 22 navigation dims | lidar), reward [E],
+terminated [E], truncated [E], info = dict of [E] tensors with ScenarioEnv's keys (route_completion, cost, crash_*,
+out_of_road, arrive_dest, max_step, ...)."""
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.envs.spaces import Box, LazyInfo
+from metadrive_ped_amd.scenario import ScenarioHostScene, make_scenario_config, synthetic_scenarios
+
+
+def scenario_bench_config(common):
+    """bench.py --workload scenario: reactive traffic, 240-beam lidar, 200-frame synthetic scenes"""
+    cfg = make_scenario_config(dict(common, reactive_traffic=True, horizon=400,
+                                    vehicle_config=dict(lidar=dict(num_lasers=240, distance=50))))
+    return cfg
+
+
+class BatchedScenarioEnv:
+    metadata = {"render_modes": []}
+
+    @classmethod
+    def default_config(cls):
+        return make_scenario_config({})
+
+    def __init__(self, config=None, scenarios=None):
+        self.config = make_scenario_config(config)
+        self.num_envs = self.config["num_envs"]
+        if scenarios is None:
+            scenarios = synthetic_scenarios(self.num_envs, self.config["start_scenario_index"] + self.config["env_seed_offset"])
+        self.scenarios = scenarios
+        self.host = None
+        self.engine = None
+        self.action_space = Box(-1.0, 1.0, (2, ), np.float32)
+        vc = self.config["vehicle_config"]
+        n = vc["lidar"]["num_lasers"] if vc["lidar"]["distance"] > 0 else 0
+        n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
+        n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
+        self._obs_dim = (n_s or 2) + 6 + (n_l or 1) + 22 + n
+        self.observation_space = Box(-0.0, 1.0, (self._obs_dim, ), np.float32)
+
+    def lazy_init(self, host=None):
+        if self.engine is None:
+            from metadrive_ped_amd.engine import BatchedEngine
+            self.host = host or ScenarioHostScene(self.config, self.scenarios)
+            self.engine = BatchedEngine(self.config, host=self.host)
+
+    def reset(self, seed=None):
+        self.lazy_init()
+        self.engine.reset()
+        return self.engine.obs[:, 0, :], self._info()
+
+    def step(self, actions):
+        if self.engine is None:
+            raise RuntimeError("call reset() before step()")
+        torch = self.engine.torch
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
+        if a.dim() == 1:
+            a = a.unsqueeze(0).expand(self.num_envs, 2)
+        if tuple(a.shape) != (self.num_envs, 2):
+            raise ValueError("actions must have shape [{}, 2], got {}".format(self.num_envs, tuple(a.shape)))
+        self.engine.step(a)
+        fl = self.engine.flags[:, 0]
+        return self.engine.obs[:, 0, :], self.engine.reward[:, 0], (fl & abi.FL_TERMINATED) != 0, (fl & abi.FL_TRUNCATED) != 0, \
+            self._info()
+
+    def _info(self):
+        e = self.engine
+        fl = e.flags[:, 0]
+        si = e.step_info[:, 0, :]
+        bit = lambda m: (lambda: (fl & m) != 0)
+        eager = {"velocity": si[:, 1], "step_energy": si[:, 2], "episode_energy": si[:, 3], "step_reward": si[:, 0],
+                 "episode_reward": si[:, 4], "episode_length": e.nav_i[:, 0, 8], "cost": e.cost[:, 0], "total_cost": si[:, 5],
+                 "route_completion": si[:, 6], "action": e.action[:, 0, :], "raw_action": e.action[:, 0, :]}
+        lazy = {"crash_vehicle": bit(abi.FL_CRASH_VEHICLE), "crash_object": bit(abi.FL_CRASH_OBJECT),
+                "crash_human": bit(abi.FL_CRASH_HUMAN), "crash_building": bit(abi.FL_CRASH_BUILDING),
+                "crash_sidewalk": bit(abi.FL_CRASH_SIDEWALK), "out_of_road": bit(abi.FL_OUT_OF_ROAD),
+                "arrive_dest": bit(abi.FL_ARRIVE_DEST), "max_step": bit(abi.FL_MAX_STEP),
+                "crash": bit(abi.FL_CRASH_VEHICLE | abi.FL_CRASH_OBJECT | abi.FL_CRASH_BUILDING | abi.FL_CRASH_SIDEWALK |
+                             abi.FL_CRASH_HUMAN)}
+        return LazyInfo(eager, lazy)
+
+    def close(self):
+        self.engine = None

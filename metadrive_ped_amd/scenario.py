@@ -1,0 +1,540 @@
+"""Host side of SCENARIO mode: scenario descriptions (the reference's unified format, metadrive/scenario/
+scenario_description.py) -> the tables and reset state of a batch of ScenarioEnv scenes.
+
+What the reference does per episode (envs/scenario_env.py, manager/scenario_map_manager.py:49-75,
+manager/scenario_traffic_manager.py, manager/scenario_data_manager.py) and what becomes of it here:
+
+  ScenarioMapManager.update_route   the SDC's recorded track -> PointLane reference trajectory, the agent's spawn pose /
+                                    velocity = the track's first frame            -> slot 0, polyline 0, checkpoint table
+  ScenarioTrafficManager            every other track -> a mover slot: frames [T] of pose / validity (replay), its own
+                                    path as a polyline + outline polygon (TrajectoryIDMPolicy route), static / length tests
+  TrajectoryNavigation.set_route    checkpoints every 2 m along the reference trajectory
+
+PolyLine restates utils/interpolating_line.py:12-71 (segment construction) in float64; the device tables are float32.
+The maps of scenario descriptions exported by this package hold lanes only (no road-line features), so no line / sidewalk
+bodies exist in these scenes: the side detector reports "nothing" and no line flags are raised.
+"""
+import copy
+import math
+
+import numpy as np
+
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.mapgen.tables import beam_table
+
+# ScenarioEnv's own defaults (envs/scenario_env.py:21-95); keys not listed keep BaseEnv's
+SCENARIO_DEFAULT_CONFIG = dict(
+    start_scenario_index=0, num_scenarios=3, sequential_seed=False,
+    no_traffic=False, no_static_vehicles=False, no_light=False, reactive_traffic=False, filter_overlapping_car=True,
+    even_sample_vehicle_class=True, default_vehicle_in_traffic=False, static_traffic_object=True,
+    success_reward=5.0, out_of_road_penalty=5.0, on_lane_line_penalty=1.0, crash_vehicle_penalty=1.0,
+    crash_object_penalty=1.0, crash_human_penalty=1.0, driving_reward=1.0, steering_range_penalty=0.5,
+    heading_penalty=1.0, lateral_penalty=0.5, max_lateral_dist=4.0, no_negative_reward=True,
+    crash_vehicle_cost=1.0, crash_object_cost=1.0, out_of_road_cost=1.0, crash_human_cost=1.0,
+    out_of_route_done=False, crash_vehicle_done=False, crash_object_done=False, crash_human_done=False,
+    relax_out_of_road_done=True, allowed_more_steps=None,
+)
+SCENARIO_VEHICLE_CONFIG = dict(lidar=dict(num_lasers=120, distance=50), lane_line_detector=dict(num_lasers=0, distance=50),
+                               side_detector=dict(num_lasers=12, distance=50))
+_ONLY_SCENARIO_KEYS = ("start_scenario_index", "sequential_seed", "no_traffic", "no_static_vehicles", "no_light",
+                       "reactive_traffic", "filter_overlapping_car", "even_sample_vehicle_class",
+                       "default_vehicle_in_traffic", "on_lane_line_penalty", "crash_human_penalty",
+                       "steering_range_penalty", "heading_penalty", "lateral_penalty", "max_lateral_dist",
+                       "no_negative_reward", "crash_human_cost", "relax_out_of_road_done", "allowed_more_steps")
+
+STATIC_THRESHOLD = 3.0        # ScenarioTrafficManager.STATIC_THRESHOLD
+IDM_CREATE_MIN_LENGTH = 5.0   # ScenarioTrafficManager.IDM_CREATE_MIN_LENGTH
+MIN_VALID_FRAME_LEN = 20      # ScenarioTrafficManager.MIN_VALID_FRAME_LEN
+ROUTE_WIDTH = 2.0             # get_idm_route(traj_points, width=2)
+
+
+def make_scenario_config(user=None):
+    """BaseEnv defaults + ScenarioEnv's (scenario_env.py:21-95) + the batch keys; `user` laid over them."""
+    from metadrive_ped_amd.config import make_config
+    user = copy.deepcopy(dict(user or {}))
+    sc = copy.deepcopy(SCENARIO_DEFAULT_CONFIG)
+    own = {}
+    for k in list(user):
+        if k in _ONLY_SCENARIO_KEYS:
+            own[k] = user.pop(k)
+    for k in _ONLY_SCENARIO_KEYS:
+        own.setdefault(k, sc[k])
+    base = {k: v for k, v in sc.items() if k not in _ONLY_SCENARIO_KEYS}
+    vc = copy.deepcopy(SCENARIO_VEHICLE_CONFIG)
+    for k, v in (user.pop("vehicle_config", None) or {}).items():
+        if isinstance(v, dict) and k in vc:
+            vc[k].update(v)
+        else:
+            vc[k] = v
+    base.update(user)
+    base["vehicle_config"] = vc
+    base.setdefault("traffic_density", 0.0)
+    cfg = make_config(base)
+    cfg.update(own)
+    cfg["scenario_mode"] = True
+    return cfg
+
+
+class PolyLine:
+    """InterpolatingLine (utils/interpolating_line.py): consecutive points are merged until a piece is longer than 1 m;
+    pieces shorter than 1e-6 are dropped; a track that never moves becomes one 0.1 m piece along +x."""
+    def __init__(self, points):
+        pts = np.asarray(points, dtype=np.float64)[..., :2]
+        starts, ends = [], []
+        i, n = 0, len(pts)
+        while i < n - 1:
+            j = n - 1
+            for q in range(i + 1, n):
+                if math.hypot(*(pts[i] - pts[q])) > 1:
+                    j = q
+                    break
+            if math.hypot(*(pts[i] - pts[j])) >= 1e-6:
+                starts.append(pts[i])
+                ends.append(pts[j])
+            i = j
+        static = not starts
+        if static:
+            starts, ends = [pts[0]], [pts[0] + np.array([0.1, 0.0])]
+        self.start = np.asarray(starts)
+        self.end = np.asarray(ends)
+        d = self.end - self.start
+        self.seg_len = np.hypot(d[:, 0], d[:, 1])
+        self.direction = d / self.seg_len[:, None]
+        self.heading = np.arctan2(d[:, 1], d[:, 0])
+        self.cum = np.concatenate([[0.0], np.cumsum(self.seg_len)[:-1]])
+        self.length = float(self.seg_len.sum())
+        # lateral_direction = get_vertical_vector(end - start)[1] = (dy, -dx); the never-moving one-piece line has (0, 1)
+        # hard-wired (interpolating_line.py:118-131) -- the device derives (dy, -dx) from the direction in every case,
+        # which only differs for that degenerate line (a parked SDC: the episode ends at once, route length < 2)
+        self.lateral = np.stack([self.direction[:, 1], -self.direction[:, 0]], 1)
+        if static:
+            self.lateral = np.array([[0.0, 1.0]])
+
+    def _seg_at(self, s):
+        """segment() / get_point(): the first piece whose accumulated end + 0.1 reaches s, else the last"""
+        acc = 0.0
+        for i, L in enumerate(self.seg_len):
+            acc += L
+            if acc + 0.1 >= s:
+                return i
+        return len(self.seg_len) - 1
+
+    def position(self, s, lateral=0.0):
+        i = self._seg_at(s)
+        d = self.direction[i]
+        return self.start[i] + (s - self.cum[i]) * d + lateral * self.lateral[i]
+
+    def heading_at(self, s):
+        acc = 0.0
+        for i, L in enumerate(self.seg_len):
+            acc += L
+            if acc > s:
+                return float(self.heading[i])
+        return float(self.heading[-1])
+
+    def local_coordinates(self, p):
+        p = np.asarray(p, dtype=np.float64)
+        sgn = ((self.start - p) * self.direction).sum(1)
+        t = ((p - self.end) * self.direction).sum(1)
+        h = np.maximum.reduce([sgn, t, np.zeros(len(sgn))])
+        dpa = p - self.start
+        c = dpa[:, 0] * self.direction[:, 1] - dpa[:, 1] * self.direction[:, 0]
+        i = int(np.argmin(np.hypot(h, c)))
+        d = self.direction[i]
+        return float(self.cum[i] + dpa[i] @ d), float(dpa[i] @ self.lateral[i])
+
+    def records(self):
+        r = np.zeros(len(self.seg_len), dtype=abi.SEG_DT)
+        r["sx"], r["sy"] = self.start[:, 0], self.start[:, 1]
+        r["ex"], r["ey"] = self.end[:, 0], self.end[:, 1]
+        r["dx"], r["dy"] = self.direction[:, 0], self.direction[:, 1]
+        r["len"], r["heading"], r["cum"] = self.seg_len, self.heading, self.cum
+        return r
+
+    def checkpoints(self):
+        """TrajectoryNavigation.discretize_reference_trajectory (trajectory_navigation.py:96-103)"""
+        num = int(self.length / 2.0)
+        pts = [self.position(i * 2.0, 0.0) for i in range(num)]
+        pts.append(self.position(self.length, 0.0))
+        return np.asarray(pts)
+
+    def outline(self, width=ROUTE_WIDTH):
+        """PointLane.auto_generate_polygon (component/lane/point_lane.py:60-106): the strip of the given width sampled
+        every metre, prolonged by one metre beyond both ends."""
+        h0, h1 = self.heading_at(0.0), self.heading_at(self.length)
+        d0 = np.array([math.cos(h0), math.sin(h0)])
+        d1 = np.array([math.cos(h1), math.sin(h1)])
+        longs = np.arange(0, self.length + 1.0, 1.0)
+        out = []
+        for side in (0, 1):
+            seq = longs if side == 0 else longs[::-1]
+            lat = -width / 2 if side == 0 else width / 2
+            for t, s in enumerate(seq):
+                p = self.position(float(s), lat)
+                at_start = (t == 0 and side == 0) or (t == len(seq) - 1 and side == 1)
+                at_end = (t == 0 and side == 1) or (t == len(seq) - 1 and side == 0)
+                if at_start:
+                    if side == 1:
+                        out.append(p)
+                    out.append(p - d0)
+                    if side == 0:
+                        out.append(p)
+                elif at_end:
+                    if side == 0:
+                        out.append(p)
+                    out.append(p + d1)
+                    if side == 1:
+                        out.append(p)
+                else:
+                    out.append(p)
+        return np.asarray(out)
+
+
+def _first_run(valid):
+    """[t0, t1) of the first run of valid frames, or None"""
+    idx = np.nonzero(valid)[0]
+    if len(idx) == 0:
+        return None
+    t0 = int(idx[0])
+    t1 = t0
+    while t1 < len(valid) and valid[t1]:
+        t1 += 1
+    return t0, t1
+
+
+_KIND_OF_TYPE = {"VEHICLE": abi.KIND_VEHICLE, "PEDESTRIAN": abi.KIND_PEDESTRIAN, "CYCLIST": abi.KIND_CYCLIST,
+                 "TRAFFIC_CONE": abi.KIND_CONE, "TRAFFIC_BARRIER": abi.KIND_BARRIER}
+
+
+def vehicle_class_for(length, counters):
+    """get_vehicle_type with even sampling (scenario_traffic_manager.py:339-361).  `counters`: the per-episode type
+    counts; the reference seeds them from the traffic manager's stream, whose position depends on Bullet-side
+    spawns: they start at 0 here (unpinned)."""
+    if length <= 4:
+        return "s"
+    if length <= 5.5:
+        counters[1] += 1
+        return ["l", "m", "s"][counters[1] % 3]
+    counters[2] += 1
+    return ["l", "xl"][counters[2] % 2]
+
+
+class _World:
+    def __init__(self, arrays, n_envs):
+        self.arrays = arrays
+        self.n_maps = 1
+        self.n_envs = n_envs
+
+
+class ScenarioHostScene:
+    """The HostScene of scenario mode: one scenario description per env (`scenarios[e]` -> env e)."""
+    def __init__(self, cfg, scenarios):
+        from metadrive_ped_amd.engine import make_md_config
+        from metadrive_ped_amd.scene import vehicle_param_record
+        from metadrive_ped_amd.rng import get_np_random
+        self.cfg = cfg
+        E = cfg["num_envs"]
+        if len(scenarios) != E:
+            raise ValueError("need one scenario per env: got {} for {} envs".format(len(scenarios), E))
+        T = int(scenarios[0]["length"])
+        if any(int(sc["length"]) != T for sc in scenarios):
+            raise ValueError("all scenarios of a batch must have the same number of frames")
+        n_tracks = max(len(sc["tracks"]) for sc in scenarios)
+        cap = cfg["mover_capacity"] or min(abi.MD_MAX_CAP, max(8, (n_tracks + 7) // 8 * 8))
+        if n_tracks > cap:
+            raise ValueError("a scenario holds {} objects, the mover capacity is {}".format(n_tracks, cap))
+        A = 1
+        self.E, self.cap, self.A, self.T = E, cap, A, T
+        vc = cfg["vehicle_config"]
+        self.n_beams = int(vc["lidar"]["num_lasers"]) if vc["lidar"]["distance"] > 0 else 0
+        self.n_side = int(vc["side_detector"]["num_lasers"]) if vc["side_detector"]["distance"] > 0 else 0
+        self.n_ll = int(vc["lane_line_detector"]["num_lasers"]) if vc["lane_line_detector"]["distance"] > 0 else 0
+        self.obs_base = 0
+        self.state_dim = (self.n_side or 2) + 6 + (self.n_ll or 1) + 22
+        self.num_others, self.add_others_navi, self.others_dim = 0, False, 0
+        self.obs_dim = self.state_dim + self.n_beams
+        self.seeds = [int(cfg["start_seed"]) + ((cfg["env_seed_offset"] + e) % max(1, cfg["num_scenarios"])) for e in range(E)]
+        self.spawn = None
+        self.traffic_respawns = False
+        self.scenes, self.map_tables = {}, []
+        N = E * cap
+        dt = cfg["physics_world_step_size"]
+
+        shape0 = np.zeros(N, dtype=abi.SHAPE_DT)
+        shape0["aux"] = -1
+        dyn0 = np.zeros(N, dtype=abi.DYN_DT)
+        nav0 = np.zeros(N, dtype=abi.NAV_DT)
+        nav0["lane"], nav0["target_lane"], nav0["road0"], nav0["road1"] = -1, -1, -1, -1
+        pid0 = np.zeros(N, dtype=abi.PID_DT)
+        pid0["target_speed"] = 40.0
+        param = np.zeros(N, dtype=abi.PARAM_DT)
+        param["max_speed_kmh"], param["lf"], param["lr"] = 80.0, 1.0, 1.0
+        fshape = np.zeros((T, N), dtype=abi.SHAPE_DT)
+        fshape["aux"] = -1
+        fdyn = np.zeros((T, N, 2), np.float32)
+        meta = np.zeros((N, 4), np.int32)
+        meta[:, 2] = abi.TM_NEVER
+        segs, poly_off = [], [0]
+        verts, polyv_off = [], [0]
+        ckpts, ckpt_off = [], [0]
+        self.track_ids = []
+        for e, sc in enumerate(scenarios):
+            sdc_id = str(sc["metadata"]["sdc_id"])
+            order = [sdc_id] + [k for k in sc["tracks"] if str(k) != sdc_id]
+            self.track_ids.append(order)
+            counters = [0, 0, 0]
+            polys = [None] * cap
+            for j, oid in enumerate(order):
+                tr = sc["tracks"][oid] if oid in sc["tracks"] else sc["tracks"][int(oid)]
+                st = tr["state"]
+                valid = np.asarray(st["valid"]).astype(bool)
+                pos = np.asarray(st["position"], dtype=np.float64)[:, :2]
+                heading = np.asarray(st["heading"], dtype=np.float64)
+                vel = np.asarray(st["velocity"], dtype=np.float64)
+                n = e * cap + j
+                run = _first_run(valid)
+                if j == 0:
+                    # the agent: default vehicle at the SDC's first frame (scenario_map_manager.py:55-75); its route =
+                    # the whole track up to the first > 100 m jump (parse_full_trajectory, parse_object_state.py:77-90)
+                    cut = len(pos)
+                    for t in range(len(pos) - 1):
+                        if math.hypot(*(pos[t] - pos[t + 1])) > 100:
+                            cut = t
+                            break
+                    polys[0] = PolyLine(pos[:cut])
+                    prm, length, width, _ = vehicle_param_record("default", int(get_np_random(self.seeds[e]).randint(0, 2 ** 16)), dt)
+                    param[n] = prm
+                    h = float(heading[0])
+                    sh = shape0[n]
+                    sh["cx"], sh["cy"], sh["c"], sh["s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
+                    sh["hl"], sh["hw"] = length / 2, width / 2
+                    sh["flags"] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT
+                    shape0[n] = sh
+                    d = dyn0[n]
+                    d["heading"], d["speed"] = h, float(vel[0, 0] * math.cos(h) + vel[0, 1] * math.sin(h))
+                    d["last_x"], d["last_y"], d["last_c"], d["last_s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
+                    dyn0[n] = d
+                    meta[n] = (0, len(pos), abi.TM_NEVER, 0)
+                    ck = polys[0].checkpoints()
+                    ckpts.append(ck)
+                    ckpt_off.append(ckpt_off[-1] + len(ck))
+                    continue
+                kind = _KIND_OF_TYPE.get(tr["type"])
+                if kind is None or run is None or cfg["no_traffic"]:
+                    continue
+                t0, t1 = run
+                flags = 0
+                if kind == abi.KIND_VEHICLE:
+                    vp = pos[valid]
+                    if float(np.max(np.std(vp, axis=0)[:2])) > STATIC_THRESHOLD:
+                        flags |= abi.TM_MOVING
+                    if math.hypot(*(pos[t0] - pos[t1 - 1])) > IDM_CREATE_MIN_LENGTH:
+                        flags |= abi.TM_LENGTH_OK
+                    rec_len = float(np.asarray(st["length"])[t0]) if "length" in st else 4.5
+                    vtype = vehicle_class_for(rec_len, counters)
+                    prm, length, width, _ = vehicle_param_record(vtype, int(get_np_random(self.seeds[e] * 131 + j).randint(0, 2 ** 16)), dt)
+                    param[n] = prm
+                    hl, hw = length / 2, width / 2
+                    polys[j] = PolyLine(pos[t0:t1])
+                elif kind == abi.KIND_PEDESTRIAN:
+                    hl = hw = 0.35
+                elif kind == abi.KIND_CYCLIST:
+                    hl, hw = 0.875, 0.2
+                elif kind == abi.KIND_CONE:
+                    hl = hw = 0.2
+                    if int(valid.sum()) < MIN_VALID_FRAME_LEN:
+                        flags |= abi.TM_NEVER
+                else:
+                    hl, hw = 0.15, 1.0
+                    if int(valid.sum()) < MIN_VALID_FRAME_LEN:
+                        flags |= abi.TM_NEVER
+                meta[n] = (t0, t1, flags, 0)
+                f = fshape[:, n]
+                f["cx"][valid], f["cy"][valid] = pos[valid, 0], pos[valid, 1]
+                f["c"][valid], f["s"][valid] = np.cos(heading[valid]), np.sin(heading[valid])
+                f["hl"][valid], f["hw"][valid] = hl, hw
+                fl = kind | abi.F_ALIVE
+                if kind in (abi.KIND_CONE, abi.KIND_BARRIER):
+                    fl |= abi.F_STATIC
+                f["flags"][valid] = fl
+                fshape[:, n] = f
+                fdyn[valid, n, 0] = heading[valid]
+                fdyn[valid, n, 1] = np.hypot(vel[valid, 0], vel[valid, 1])
+                # a free slot still carries the class's size, so that the device only rewrites the pose on a spawn
+                shape0[n]["hl"], shape0[n]["hw"] = hl, hw
+            for j in range(cap):
+                pl = polys[j]
+                recs = pl.records() if pl is not None else np.zeros(0, dtype=abi.SEG_DT)
+                segs.append(recs)
+                poly_off.append(poly_off[-1] + len(recs))
+                n = e * cap + j
+                want_outline = j > 0 and pl is not None and (meta[n, 2] & abi.TM_MOVING) and (meta[n, 2] & abi.TM_LENGTH_OK)
+                v = pl.outline() if want_outline else np.zeros((0, 2))
+                verts.append(v)
+                polyv_off.append(polyv_off[-1] + len(v))
+        a = {}
+        a["env_map"] = np.zeros(E, np.int32)
+        a["lane_off"] = np.asarray([0, 1], np.int32)
+        a["lanes"] = np.zeros(1, dtype=abi.LANE_DT)
+        a["hull_xy"] = np.zeros((1, 2), np.float32)
+        a["road_off"] = np.asarray([0, 1], np.int32)
+        a["roads"] = np.zeros(1, dtype=abi.ROAD_DT)
+        a["quad_off"] = np.asarray([0, 0], np.int32)
+        a["quads"] = np.zeros((1, 8), np.float32)
+        a["quad_kind"] = np.zeros(1, np.int32)
+        g = np.zeros(1, dtype=abi.GRID_DT)      # one empty cell that covers everything: no static bodies in these scenes
+        g["x0"], g["y0"], g["inv_cell"], g["nx"], g["ny"], g["cell_base"] = -1.0e7, -1.0e7, 5.0e-8, 1, 1, 0
+        a["grid"] = g
+        a["cell_start"] = np.asarray([0, 0], np.int32)
+        a["cell_items"] = np.zeros(1, np.int32)
+        a["node_adj_off"] = np.asarray([0, 0], np.int32)
+        a["node_adj"] = np.zeros((1, 2), np.int32)
+        a["node_off"] = np.asarray([0, 1], np.int32)
+        a["beam_cs"] = beam_table(self.n_beams)
+        a["poly_off"] = np.asarray(poly_off, np.int32)
+        a["segs"] = np.concatenate(segs) if sum(len(x) for x in segs) else np.zeros(1, dtype=abi.SEG_DT)
+        a["polyv_off"] = np.asarray(polyv_off, np.int32)
+        vv = np.concatenate(verts) if sum(len(x) for x in verts) else np.zeros((1, 2))
+        a["polyv"] = np.ascontiguousarray(vv, dtype=np.float32)
+        a["ckpt_off"] = np.asarray(ckpt_off, np.int32)
+        a["ckpt_xy"] = np.ascontiguousarray(np.concatenate(ckpts), dtype=np.float32)
+        a["track_meta"] = meta
+        self.world = _World(a, E)
+        st = {}
+        st["shape0"], st["dyn0"], st["nav0"], st["pid0"], st["param"] = shape0, dyn0, nav0, pid0, param
+        st["route_nodes"] = np.full((N, abi.MD_ROUTE_LEN), -1, np.int32)
+        st["route_roads"] = np.full((N, abi.MD_ROUTE_LEN), -1, np.int32)
+        st["final_lane"] = np.zeros(N, np.int32)
+        st["idm_rand"] = np.zeros((N, abi.MD_IDM_RAND), np.int32)
+        for k in ("shape", "dyn", "nav", "pid"):
+            st[k] = st[k + "0"].copy()
+        st["action"] = np.zeros((N, 2), np.float32)
+        st["flags"] = np.zeros(N, np.uint32)
+        st["obs"] = np.zeros((E * A, self.obs_dim), np.float32)
+        st["reward"] = np.zeros(E * A, np.float32)
+        st["cost"] = np.zeros(E * A, np.float32)
+        st["step_info"] = np.zeros((E * A, 8), np.float32)
+        st["need_reset"] = np.ones(E, np.int32)
+        st["next_agent_id"] = np.zeros(E, np.int32)     # ScenarioTrafficManager.idm_policy_count
+        self.state = st
+        self.tracks = dict(shape=fshape, dyn=fdyn, seeds=list(self.seeds), cap=cap)
+        k = make_md_config(dict(cfg, traffic_mode="trigger"), E, A, cap, self.n_beams)
+        k.traffic_mode = 4
+        k.n_side, k.n_lane_line = self.n_side, self.n_ll
+        k.obs_dim = self.obs_dim
+        k.track_len = T
+        k.scenario_length = T
+        for name in ("on_lane_line_penalty", "crash_human_penalty", "steering_range_penalty", "heading_penalty",
+                     "lateral_penalty", "max_lateral_dist", "crash_human_cost"):
+            setattr(k, name, float(cfg[name]))
+        for name in ("no_negative_reward", "relax_out_of_road_done", "reactive_traffic", "filter_overlapping_car",
+                     "no_static_vehicles"):
+            setattr(k, name, int(bool(cfg[name])))
+        k.allowed_more_steps = int(cfg["allowed_more_steps"] or 0)
+        self.md_config = k
+        self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
+        self.ll_beams = beam_table(self.n_ll, np.pi / 2) if self.n_ll else None
+
+    def clone_state(self):
+        return {k: v.copy() for k, v in self.state.items()}
+
+
+# --------------------------------------------------------------------------------------------------
+# Synthetic scenario descriptions (bench / tests): the container holds no ScenarioNet data (nuScenes, Waymo), so scenes
+# of the same SHAPE are generated -- a curving multi-lane road, an SDC track along it, vehicles ahead, beside and
+# behind it (the ones behind are what ScenarioTrafficManager makes reactive), parked cars, late-appearing and
+# vanishing tracks, pedestrians, cones -- in the reference's own description format (scenario_description.py:1-120).
+# --------------------------------------------------------------------------------------------------
+def _path(rng, n_pts, ds=0.5):
+    """a smooth centre line: heading = integral of a slowly varying curvature"""
+    amp = rng.uniform(0.004, 0.02)
+    wl = rng.uniform(120.0, 300.0)
+    ph = rng.uniform(0, 2 * math.pi)
+    s = np.arange(n_pts) * ds
+    kappa = amp * np.sin(2 * math.pi * s / wl + ph)
+    h0 = rng.uniform(-math.pi, math.pi)
+    heading = h0 + np.cumsum(kappa) * ds
+    x = np.cumsum(np.cos(heading)) * ds + rng.uniform(-500, 500)
+    y = np.cumsum(np.sin(heading)) * ds + rng.uniform(-500, 500)
+    return s, np.stack([x, y], 1), heading
+
+
+def _sample(s_axis, xy, heading, s, lateral):
+    """pose at arc length s (clamped) with a lateral offset to the right"""
+    s = np.clip(s, s_axis[0], s_axis[-1])
+    x = np.interp(s, s_axis, xy[:, 0])
+    y = np.interp(s, s_axis, xy[:, 1])
+    h = np.interp(s, s_axis, heading)
+    return x + lateral * np.sin(h), y - lateral * np.cos(h), h
+
+
+def _track_dict(oid, typ, T, valid, x, y, h, speed, length, width, height):
+    v = valid.astype(np.float32)
+    pos = np.zeros((T, 3), np.float32)
+    pos[:, 0], pos[:, 1] = x * v, y * v
+    vel = np.stack([speed * np.cos(h), speed * np.sin(h)], 1).astype(np.float32) * v[:, None]
+    return {"type": typ,
+            "state": {"position": pos, "heading": (h * v).astype(np.float32), "velocity": vel, "valid": valid.copy(),
+                      "length": np.full(T, length, np.float32) * v, "width": np.full(T, width, np.float32) * v,
+                      "height": np.full(T, height, np.float32) * v},
+            "metadata": {"type": typ, "object_id": str(oid), "track_length": int(T)}}
+
+
+def synthetic_scenario(seed, T=200, n_vehicles=18, n_parked=3, n_pedestrians=2, n_cones=4):
+    rng = np.random.RandomState(seed)
+    s_axis, xy, heading = _path(rng, 4000)
+    t = np.arange(T) * 0.1
+    tracks = {}
+    ego_v = rng.uniform(6.0, 11.0)
+    ego_s0 = 600.0
+    ego_s = ego_s0 + ego_v * t + 0.5 * rng.uniform(-0.15, 0.15) * t * t
+    x, y, h = _sample(s_axis, xy, heading, ego_s, 0.0)
+    sp = np.gradient(ego_s, 0.1)
+    tracks["0"] = _track_dict("0", "VEHICLE", T, np.ones(T, bool), x, y, h, sp, 4.5, 1.85, 1.5)
+    oid = 1
+    for i in range(n_vehicles):
+        lane = float(rng.choice([-3.5, 0.0, 3.5]))
+        behind = i < n_vehicles // 2
+        ds0 = rng.uniform(-45.0, -9.0) if behind else rng.uniform(9.0, 70.0)
+        if lane == 0.0 and abs(ds0) < 12.0:
+            ds0 = math.copysign(12.0, ds0)
+        v = max(0.5, ego_v + rng.uniform(-3.0, 3.0))
+        s_v = ego_s0 + ds0 + v * t
+        x, y, h = _sample(s_axis, xy, heading, s_v, lane)
+        valid = np.ones(T, bool)
+        r = rng.rand()
+        if r < 0.15:
+            valid[:int(rng.randint(5, 60))] = False          # appears later
+        elif r < 0.3:
+            valid[int(rng.randint(80, T - 5)):] = False       # vanishes
+        length = float(rng.choice([3.9, 4.6, 5.2, 6.0]))
+        tracks[str(oid)] = _track_dict(oid, "VEHICLE", T, valid, x, y, h, np.full(T, v), length, 1.9, 1.6)
+        oid += 1
+    for i in range(n_parked):
+        s_p = ego_s0 + rng.uniform(-30.0, 150.0)
+        x, y, h = _sample(s_axis, xy, heading, np.full(T, s_p), float(rng.choice([-6.5, 6.5])))
+        tracks[str(oid)] = _track_dict(oid, "VEHICLE", T, np.ones(T, bool), x, y, h, np.zeros(T), 4.4, 1.8, 1.5)
+        oid += 1
+    for i in range(n_pedestrians):
+        s_p = ego_s0 + rng.uniform(10.0, 120.0) + rng.uniform(-1.0, 1.0) * t
+        x, y, h = _sample(s_axis, xy, heading, s_p, float(rng.choice([-7.5, 7.5])))
+        typ = "PEDESTRIAN" if i % 2 == 0 else "CYCLIST"
+        tracks[str(oid)] = _track_dict(oid, typ, T, np.ones(T, bool), x, y, h, np.full(T, 1.0), 0.7, 0.7, 1.75)
+        oid += 1
+    for i in range(n_cones):
+        s_p = ego_s0 + 40.0 + 3.0 * i
+        x, y, h = _sample(s_axis, xy, heading, np.full(T, s_p), 5.2)
+        valid = np.ones(T, bool)
+        if i == n_cones - 1:
+            valid[10:] = False                                 # a noise object: fewer than MIN_VALID_FRAME_LEN frames
+        tracks[str(oid)] = _track_dict(oid, "TRAFFIC_CONE", T, valid, x, y, h, np.zeros(T), 0.4, 0.4, 1.0)
+        oid += 1
+    return {"id": "synthetic-%d" % seed, "version": "metadrive_ped_amd synthetic (MetaDrive v0.4.2.2 scenario format)",
+            "length": int(T),
+            "metadata": {"ts": t.astype(np.float32), "metadrive_processed": False, "coordinate": "metadrive",
+                         "dataset": "synthetic", "seed": int(seed), "sdc_id": "0", "scenario_id": "synthetic-%d" % seed},
+            "tracks": tracks, "dynamic_map_states": {}, "map_features": {}}
+
+
+def synthetic_scenarios(n, seed0=0, **kw):
+    return [synthetic_scenario(seed0 + i, **kw) for i in range(n)]

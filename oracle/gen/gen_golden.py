@@ -800,6 +800,251 @@ def section_idm_policy():
     dump("idm_policy.json", dict(lane_width=W, rand_value=7, cases=cases))
 
 
+def section_scenario():
+    """Scenario mode (BASELINE configs[4]): the reference's own classes on synthetic tracks --
+    InterpolatingLine / PointLane (segments, local_coordinates, position, heading_theta_at, lateral_direction, the outline
+    polygon), TrajectoryNavigation.update_localization (22 dims incl. the unpacking quirk at trajectory_navigation.py:134,
+    route completion), ScenarioEnv reward / cost / done, TrajectoryIDMPolicy.act (steering PID, speed control every fifth
+    step, single-lane front search), get_max_valid_indicis and the static-car test.
+    Supplied by the generator (placeholders in this container): BaseVehicle.convert_to_local_coordinates = the (forward,
+    left) projection (as in agent_step.json); lane.point_on_lane (shapely) = an even-odd point-in-polygon test on the
+    lane's own polygon."""
+    import types
+    from collections import deque
+    from types import SimpleNamespace
+    sys.path.insert(0, ROOT)
+    from metadrive.component.lane.point_lane import PointLane
+    from metadrive.component.navigation_module.trajectory_navigation import TrajectoryNavigation
+    from metadrive.component.vehicle.base_vehicle import BaseVehicle
+    from metadrive.component.vehicle.PID_controller import PIDController
+    from metadrive.envs.scenario_env import ScenarioEnv, SCENARIO_ENV_CONFIG
+    from metadrive.policy.idm_policy import TrajectoryIDMPolicy, FrontBackObjects
+    from metadrive.scenario.parse_object_state import get_idm_route, get_max_valid_indicis
+    from metadrive.manager.scenario_traffic_manager import ScenarioTrafficManager
+    from metadrive.obs.state_obs import StateObservation
+    from metadrive.component.map.base_map import BaseMap
+    from metadrive_ped_amd.scenario import synthetic_scenario
+    rng = np.random.RandomState(515)
+    out = dict(supplied_by_generator=["convert_to_local_coordinates (forward, left)", "point_on_lane (even-odd on lane.polygon)"])
+
+    def crossing(poly, p):
+        inside = False
+        n = len(poly)
+        j = n - 1
+        for i in range(n):
+            xi, yi, xj, yj = poly[i][0], poly[i][1], poly[j][0], poly[j][1]
+            if ((yi > p[1]) != (yj > p[1])) and (p[0] < (xj - xi) * (p[1] - yi) / (yj - yi) + xi):
+                inside = not inside
+            j = i
+        return inside
+
+    PointLane.point_on_lane = lambda self, point: crossing(self.polygon, point)
+
+    # ---- polylines -------------------------------------------------------------------------------
+    lines = []
+    tracks_for_lines = []
+    for seed in (1, 2):
+        sc = synthetic_scenario(seed, T=120)
+        for oid in ("0", "5", "12"):
+            st = sc["tracks"][oid]["state"]
+            v = st["valid"].astype(bool)
+            tracks_for_lines.append(np.asarray(st["position"], np.float64)[v][:, :2])
+    # a hand-made one with repeated points, a stop in the middle and a sharp corner
+    tracks_for_lines.append(np.array([[0, 0], [0.3, 0], [0.6, 0], [0.6, 0], [0.6, 0], [1.4, 0.1], [2.9, 0.2], [4.0, 0.2], [4.0, 1.5],
+                                      [4.0, 3.2], [3.0, 5.0], [3.0, 5.0], [2.0, 7.5]], np.float64))
+    tracks_for_lines.append(np.array([[5.0, 5.0]] * 6, np.float64))          # never moves
+    for pts in tracks_for_lines:
+        lane = get_idm_route(pts)
+        segs = [dict(start=[float(x) for x in sg["start_point"]], end=[float(x) for x in sg["end_point"]], length=float(sg["length"]),
+                     heading=float(sg["heading"]), direction=[float(x) for x in sg["direction"]],
+                     lateral_direction=[float(x) for x in sg["lateral_direction"]]) for sg in lane.segment_property]
+        q = []
+        for _ in range(30):
+            s_ = float(rng.uniform(-3, lane.length + 3))
+            lat = float(rng.uniform(-6, 6))
+            base = lane.position(float(np.clip(s_, 0, lane.length)), 0)
+            h = lane.heading_theta_at(float(np.clip(s_, 0, lane.length)))
+            p = (float(base[0] + lat * math.sin(h) + rng.uniform(-0.3, 0.3)), float(base[1] - lat * math.cos(h) + rng.uniform(-0.3, 0.3)))
+            lg, lt = lane.local_coordinates(p)
+            pos = lane.position(s_, lat)
+            ld = lane.lateral_direction(lg)
+            q.append(dict(point=list(p), long=float(lg), lat=float(lt), s=s_, lateral=lat, position=[float(pos[0]), float(pos[1])],
+                          heading_at_long=float(lane.heading_theta_at(lg)), lateral_direction=[float(ld[0]), float(ld[1])]))
+        lines.append(dict(points=pts.tolist(), length=float(lane.length), width=float(lane.width), segments=segs, queries=q,
+                          polygon=np.asarray(lane.polygon).tolist(), start=[float(x) for x in lane.start], end=[float(x) for x in lane.end]))
+    out["polylines"] = lines
+
+    # ---- TrajectoryNavigation + state observation + ScenarioEnv reward / cost / done ---------------------
+    def make_vehicle(pos, heading, speed, last_heading, act, flags, lane, nav):
+        hx, hy = math.cos(heading), math.sin(heading)
+        veh = SimpleNamespace(position=np.array(pos, np.float64), heading=np.array([hx, hy]), heading_theta=heading,
+                              last_heading_dir=np.array([math.cos(last_heading), math.sin(last_heading)]), speed=speed,
+                              speed_km_h=speed * 3.6, max_speed_km_h=80.0, steering=act[0], MAX_STEERING=BaseVehicle.MAX_STEERING,
+                              last_current_action=[(0.0, 0.0), (act[0], act[1])], current_action=act, lane=lane, navigation=nav,
+                              engine=None, WIDTH=1.852, LENGTH=4.515,
+                              config={"side_detector": {"num_lasers": 0, "distance": 50}, "lane_line_detector": {"num_lasers": 0, "distance": 20}},
+                              **flags)
+        veh.convert_to_local_coordinates = lambda vec, origin, hx=hx, hy=hy: np.array(
+            [(vec[0] - (origin[0] if hasattr(origin, "__len__") else origin)) * hx + (vec[1] - (origin[1] if hasattr(origin, "__len__") else origin)) * hy,
+             (vec[1] - (origin[1] if hasattr(origin, "__len__") else origin)) * hx - (vec[0] - (origin[0] if hasattr(origin, "__len__") else origin)) * hy])
+        veh.heading_diff = types.MethodType(BaseVehicle.heading_diff, veh)
+        return veh
+
+    agent_cases = []
+    for seed in (11, 12, 13):
+        sc = synthetic_scenario(seed, T=120)
+        pts = np.asarray(sc["tracks"]["0"]["state"]["position"], np.float64)[:, :2]
+        lane = get_idm_route(pts)
+
+        class Nav(TrajectoryNavigation):
+            reference_trajectory = lane
+            engine = SimpleNamespace(global_config=dict(max_lateral_dist=4.0))
+            map = SimpleNamespace(MAX_LANE_NUM=BaseMap.MAX_LANE_NUM, MAX_LANE_WIDTH=BaseMap.MAX_LANE_WIDTH)
+
+        nav = object.__new__(Nav)
+        nav._navi_info = np.zeros((TrajectoryNavigation.get_navigation_info_dim(), ), dtype=np.float32)
+        nav._show_navi_info = False
+        nav._ckpt_vis_models = None
+        nav._current_lane = lane
+        nav.checkpoints = TrajectoryNavigation.discretize_reference_trajectory(nav)
+        nav.last_current_long = deque([0.0, 0.0], maxlen=2)
+        nav.last_current_lat = deque([0.0, 0.0], maxlen=2)
+        nav.last_current_heading_theta_at_long = deque([0.0, 0.0], maxlen=2)
+        nav._route_completion = 0
+        samples = []
+        s_prev = float(rng.uniform(0, 10))
+        for k in range(60):
+            kind = rng.rand()
+            if kind < 0.08:
+                s_now = float(rng.uniform(-6, 1))                     # before the start: negative completion
+            elif kind < 0.2:
+                s_now = float(rng.uniform(lane.length * 0.94, lane.length + 3))   # at the end
+            else:
+                s_now = float(np.clip(s_prev + rng.uniform(-0.5, 2.5), 0, lane.length))
+            lat = float(rng.uniform(-5.5, 5.5) if rng.rand() < 0.35 else rng.uniform(-1.0, 1.0))
+            base = lane.position(float(np.clip(s_now, 0, lane.length)), lat)
+            if s_now < 0:
+                base = lane.position(0, lat) + s_now * np.array([math.cos(lane.heading_theta_at(0)), math.sin(lane.heading_theta_at(0))])
+            heading = float(lane.heading_theta_at(float(np.clip(s_now, 0, lane.length))) + rng.uniform(-0.6, 0.6))
+            speed = float(rng.choice([rng.uniform(0, 0.5), rng.uniform(2, 20)]))
+            last_heading = heading - float(rng.uniform(-0.08, 0.08))
+            act = [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))]
+            flags = dict(crash_vehicle=bool(rng.rand() < 0.12), crash_object=bool(rng.rand() < 0.08), crash_building=bool(rng.rand() < 0.03),
+                         crash_human=bool(rng.rand() < 0.05), crash_sidewalk=bool(rng.rand() < 0.06),
+                         on_yellow_continuous_line=bool(rng.rand() < 0.06), on_white_continuous_line=bool(rng.rand() < 0.06))
+            veh = make_vehicle([float(base[0]), float(base[1])], heading, speed, last_heading, act, flags, lane, nav)
+            long_before = float(nav.last_current_long[1])
+            TrajectoryNavigation.update_localization(nav, veh)
+            veh.dist_to_left_side, veh.dist_to_right_side = BaseVehicle._dist_to_route_left_right(veh)
+            obs_self = SimpleNamespace(config={"random_agent_model": False}, engine=None)
+            state9 = [float(x) for x in StateObservation.vehicle_state(obs_self, veh)]
+            cfgv = int(rng.randint(4))
+            cfg = dict(SCENARIO_ENV_CONFIG)
+            steps, horizon = int(rng.randint(0, 200)), int(rng.choice([0, 100]))
+            cfg.update(horizon=(horizon or None), truncate_as_terminate=bool(rng.rand() < 0.3), relax_out_of_road_done=bool(cfgv != 1),
+                       out_of_route_done=bool(cfgv == 1 and rng.rand() < 0.5), crash_vehicle_done=bool(cfgv == 2), crash_object_done=bool(cfgv == 2),
+                       crash_human_done=bool(cfgv == 2), no_negative_reward=bool(cfgv != 3),
+                       allowed_more_steps=(int(rng.choice([0, 20])) or None))
+            eng = SimpleNamespace(curriculum_manager=MagicMock(), data_manager=SimpleNamespace(current_scenario_length=160, current_scenario_id="x",
+                                  current_scenario_difficulty=0, data_coverage=0), current_level=0, current_seed=seed,
+                                  map_manager=SimpleNamespace(num_stored_maps=0))
+            env = SimpleNamespace(agents={"a": veh}, config=cfg, episode_lengths={"a": steps + 1}, current_seed=seed, logger=MagicMock(), engine=eng)
+            env._is_out_of_road = types.MethodType(ScenarioEnv._is_out_of_road, env)
+            env._is_arrive_destination = ScenarioEnv._is_arrive_destination
+            reward, rinfo = ScenarioEnv.reward_function(env, "a")
+            done, dinfo = ScenarioEnv.done_function(env, "a")
+            cost, _ = ScenarioEnv.cost_function(env, "a")
+            samples.append(dict(pos=[float(base[0]), float(base[1])], heading=heading, speed=speed, last_heading=last_heading, action=act,
+                                flags=flags, steps=steps, horizon=horizon, long_before=long_before, long=float(nav.last_current_long[1]),
+                                lat=float(nav.last_current_lat[1]), heading_at=float(nav.last_current_heading_theta_at_long[1]),
+                                navi=[float(x) for x in nav._navi_info], route_completion=float(nav.route_completion), state9=state9,
+                                config={k_: cfg[k_] for k_ in ("truncate_as_terminate", "relax_out_of_road_done", "out_of_route_done",
+                                                               "crash_vehicle_done", "crash_object_done", "crash_human_done",
+                                                               "no_negative_reward", "allowed_more_steps")},
+                                reward=float(reward), step_reward=float(rinfo["step_reward"]), cost=float(cost), done=bool(done),
+                                done_info={k_: bool(v) for k_, v in dinfo.items() if k_ != "env_seed"}))
+            s_prev = max(s_now, 0.0)
+        agent_cases.append(dict(points=pts.tolist(), checkpoints=np.asarray(nav.checkpoints).tolist(), scenario_length=160, samples=samples))
+    out["agent"] = agent_cases
+
+    # ---- TrajectoryIDMPolicy.act ----------------------------------------------------------------------
+    idm_cases = []
+    for seed in (21, 22):
+        sc = synthetic_scenario(seed, T=120)
+        for oid in ("1", "2", "3"):
+            st = sc["tracks"][oid]["state"]
+            v = st["valid"].astype(bool)
+            pts = np.asarray(st["position"], np.float64)[v][:, :2]
+            route = get_idm_route(pts)
+            p = object.__new__(TrajectoryIDMPolicy)
+            p.traj_to_follow = route
+            p.routing_target_lane = route
+            p.target_speed = TrajectoryIDMPolicy.NORMAL_SPEED
+            p.destination = np.asarray(route.end)
+            p.enable_lane_change = False
+            p.disable_idm_deceleration = False
+            p.heading_pid = PIDController(1.2, 0.1, 3.5)
+            p.lateral_pid = PIDController(0.3, .0, 0.0)
+            p.last_action = [0, 0]
+            p.action_info = {}
+            p.policy_index = int(rng.randint(5))
+            seq = []
+            s_now = float(rng.uniform(2, 20))
+            for step in range(1, 26):
+                s_now = float(min(s_now + rng.uniform(0.2, 1.5), route.length - 0.5))
+                lat = float(rng.uniform(-0.8, 0.8))
+                pos = route.position(s_now, lat)
+                heading = float(route.heading_theta_at(s_now) + rng.uniform(-0.3, 0.3))
+                speed = float(rng.uniform(0, 14))
+                hx, hy = math.cos(heading), math.sin(heading)
+                objs, recs = [], []
+                for j in range(int(rng.randint(0, 5))):
+                    ds = float(rng.uniform(-15, 26))
+                    olat = float(rng.choice([0.0, 0.0, 1.6, 3.5, -3.5]) + rng.uniform(-0.3, 0.3))
+                    op = route.position(float(np.clip(s_now + ds, 0, route.length)), olat)
+                    oh = float(route.heading_theta_at(float(np.clip(s_now + ds, 0, route.length))) + rng.uniform(-0.2, 0.2))
+                    ov = float(rng.uniform(0, 12))
+                    L, W = 4.6, 1.9
+                    c_, s__ = math.cos(oh), math.sin(oh)
+                    bb = [np.array([op[0] + c_ * L / 2 - s__ * W / 2 * sg2, op[1] + s__ * L / 2 * 1 + c_ * W / 2 * sg2]) if False else None for sg2 in (1, )]
+                    corners = [np.array([op[0] + sx * c_ * L / 2 - sy * s__ * W / 2, op[1] + sx * s__ * L / 2 + sy * c_ * W / 2])
+                               for sx, sy in ((1, 1), (1, -1), (-1, -1), (-1, 1))]
+                    objs.append(SimpleNamespace(position=np.array([float(op[0]), float(op[1])]), bounding_box=corners,
+                                                velocity_km_h=np.array([ov * c_, ov * s__]) * 3.6, speed_km_h=ov * 3.6, slot=j + 1))
+                    recs.append(dict(pos=[float(op[0]), float(op[1])], heading=oh, speed=ov, length=L, width=W))
+                ego = SimpleNamespace(position=np.array([float(pos[0]), float(pos[1])]), heading_theta=heading, speed_km_h=speed * 3.6,
+                                      velocity_km_h=np.array([hx, hy]) * speed * 3.6, heading=np.array([hx, hy]),
+                                      lidar=SimpleNamespace(get_surrounding_objects=lambda v_, _o=objs: list(_o)))
+                p.control_object = ego
+                do_speed = (step % ScenarioTrafficManager.IDM_ACT_BATCH_SIZE) == p.policy_index
+                arrived = bool(p.arrive_destination)
+                action = TrajectoryIDMPolicy.act(p, do_speed)
+                seq.append(dict(step=step, pos=[float(pos[0]), float(pos[1])], heading=heading, speed=speed, objs=recs,
+                                do_speed_control=bool(do_speed), arrived=arrived, action=[float(action[0]), float(action[1])]))
+            idm_cases.append(dict(points=pts.tolist(), policy_index=p.policy_index, polygon=np.asarray(route.polygon).tolist(), sequence=seq))
+    out["traj_idm"] = idm_cases
+
+    # ---- track bookkeeping --------------------------------------------------------------------------
+    book = []
+    for seed in (31, 32):
+        sc = synthetic_scenario(seed, T=120)
+        for oid, tr in sc["tracks"].items():
+            st = tr["state"]
+            valid = st["valid"].astype(bool)
+            if not valid.any():
+                continue
+            t0 = int(np.nonzero(valid)[0][0])
+            a, b = get_max_valid_indicis(tr, t0)
+            vp = st["position"][np.where(st["valid"])]
+            moving = bool(np.max(np.std(vp, axis=0)[:2]) > ScenarioTrafficManager.STATIC_THRESHOLD)
+            d = st["position"][a][..., :2] - st["position"][b - 1][..., :2]
+            book.append(dict(seed=seed, oid=oid, type=tr["type"], t0=t0, run=[int(a), int(b)], moving=moving,
+                             length_ok=bool(math.hypot(float(d[0]), float(d[1])) > ScenarioTrafficManager.IDM_CREATE_MIN_LENGTH),
+                             noise=bool(np.sum(st["valid"]) < ScenarioTrafficManager.MIN_VALID_FRAME_LEN)))
+    out["bookkeeping"] = book
+    dump("scenario.json", out)
+
+
 def section_pg_maps_v2():
     """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
     straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
@@ -902,7 +1147,7 @@ def section_scenario_export():
     dump("scenario_export.json", dict(accepted_by_reference_sanity_check=True, scenarios=out))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":

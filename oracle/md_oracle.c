@@ -30,7 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "md_entity.h"
+#include "md_scenario.h"
 
 #define EXPORT __attribute__((visibility("default")))
 
@@ -417,6 +417,52 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Scenario mode (traffic_mode 4): one ScenarioEnv step (envs/scenario_env.py + manager/scenario_traffic_manager.py),
+ * in the reference's order: reactive traffic decides (before_step), everything driven moves, the traffic manager's
+ * after_step replays / removes / spawns at frame k, then the agent's contacts, navigation, observation, lidar.
+ * -----------------------------------------------------------------------------------------*/
+static void step_env_scenario(const MdWorld* w, const MdState* s, const MdConfig* c, int e) {
+    const int base = e * c->cap;
+    int just_reset = 0;
+    if (s->agent_action)
+        for (int a = 0; a < c->agents_per_env; ++a) {
+            s->action[2 * (base + a)] = s->agent_action[2 * (e * c->agents_per_env + a)];
+            s->action[2 * (base + a) + 1] = s->agent_action[2 * (e * c->agents_per_env + a) + 1];
+        }
+    if (s->need_reset[e]) {
+        memcpy(&s->shape[base], &s->shape0[base], sizeof(MdShape) * c->cap);
+        memcpy(&s->dyn[base], &s->dyn0[base], sizeof(MdDyn) * c->cap);
+        memcpy(&s->nav[base], &s->nav0[base], sizeof(MdNav) * c->cap);
+        memcpy(&s->pid[base], &s->pid0[base], sizeof(MdPid) * c->cap);
+        for (int j = 0; j < c->cap; ++j) {
+            s->flags[base + j] = 0;
+            s->action[2 * (base + j)] = 0.0f;
+            s->action[2 * (base + j) + 1] = 0.0f;
+        }
+        s->next_agent_id[e] = 0;   /* idm_policy_count (scenario_traffic_manager.py:87) */
+        s->need_reset[e] = 0;
+        just_reset = 1;
+    }
+    MdState v = md_env_view(s, c, e);
+    const int k = just_reset ? 0 : v.nav[0].steps + 1;   /* engine.episode_step of this step */
+    if (!just_reset) {
+        for (int j = c->agents_per_env; j < c->cap; ++j)
+            if (v.nav[j].ck0 == MD_SC_IDM && md_present(v.shape[j].flags)) md_tidm_vehicle(w, &v, c, e, j, k);
+        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
+    }
+    md_scenario_after_step_env(w, &v, c, e, k);
+    for (int a = 0; a < c->agents_per_env; ++a) {
+        s->flags[base + a] = 0;
+        contacts_mover(w, s, c, e, a);
+        md_scenario_observe(w, &v, c, e, a, just_reset);
+        if (c->n_beams > 0) {
+            float* row = s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim;
+            lidar_agent(w, s, c, e, a, row + md_sc_obs_lidar(c));
+        }
+    }
+}
+
 EXPORT int ref_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c) {
     for (int e = 0; e < c->n_envs; ++e) {
         MdState v = md_env_view(s, c, e);
@@ -425,8 +471,13 @@ EXPORT int ref_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c) 
     return MD_OK;
 }
 
+static void step_any(const MdWorld* w, const MdState* s, const MdConfig* c, int e) {
+    if (c->traffic_mode == 4) step_env_scenario(w, s, c, e);
+    else step_env(w, s, c, e);
+}
+
 EXPORT int ref_step(const MdWorld* w, const MdState* s, const MdConfig* c) {
-    for (int e = 0; e < c->n_envs; ++e) step_env(w, s, c, e);
+    for (int e = 0; e < c->n_envs; ++e) step_any(w, s, c, e);
     return MD_OK;
 }
 
@@ -439,7 +490,7 @@ typedef struct {
 
 static void* step_worker(void* p) {
     StepJob* j = (StepJob*)p;
-    for (int e = j->e0; e < j->e1; ++e) step_env(j->w, j->s, j->c, e);
+    for (int e = j->e0; e < j->e1; ++e) step_any(j->w, j->s, j->c, e);
     return 0;
 }
 
@@ -550,6 +601,44 @@ EXPORT void ref_idm_vehicle(const MdLane* lanes, int n_lanes, const MdRoad* road
     c.n_envs = 1; c.cap = cap; c.agents_per_env = 1; c.enable_idm_lane_change = enable_lane_change;
     md_idm_vehicle(&w, &s, &c, 0, slot);
 }
+/* scenario-mode probes (tests/test_scenario.py): polyline of n segments */
+EXPORT void ref_poly_local(const MdSeg* segs, int n, float px, float py, float* out4) {
+    MdPoly p;
+    p.segs = segs; p.n = n; p.length = segs[n - 1].cum + segs[n - 1].len;
+    MdTrajLoc L;
+    md_traj_locate(&p, px, py, &L);
+    out4[0] = L.lng; out4[1] = L.lat; out4[2] = L.heading_at; out4[3] = p.length;
+}
+EXPORT void ref_poly_position(const MdSeg* segs, int n, float s_, float lateral, float* out2) {
+    MdPoly p;
+    p.segs = segs; p.n = n; p.length = segs[n - 1].cum + segs[n - 1].len;
+    md_poly_position(&p, s_, lateral, &out2[0], &out2[1]);
+}
+EXPORT void ref_traj_navi(const MdSeg* segs, int n, const float* ckpt, int n_ckpt, float px, float py, float heading,
+                          float max_lateral_dist, float* out22) {
+    MdPoly p;
+    p.segs = segs; p.n = n; p.length = segs[n - 1].cum + segs[n - 1].len;
+    MdTrajLoc L;
+    md_traj_locate(&p, px, py, &L);
+    float sn, cs;
+    md_sincos(heading, &sn, &cs);
+    md_traj_navi(ckpt, n_ckpt, &L, px, py, cs, sn, heading, max_lateral_dist, out22);
+}
+/* md_scenario_observe of every env's agent on the state as it stands (flags as given: no contact phase) */
+EXPORT int ref_scenario_observe(const MdWorld* w, const MdState* s, const MdConfig* c) {
+    for (int e = 0; e < c->n_envs; ++e) {
+        MdState v = md_env_view(s, c, e);
+        md_scenario_observe(w, &v, c, e, 0, 0);
+    }
+    return MD_OK;
+}
+/* TrajectoryIDMPolicy.act of one slot at episode step k */
+EXPORT int ref_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, int k) {
+    MdState v = md_env_view(s, c, e);
+    md_tidm_vehicle(w, &v, c, e, slot, k);
+    return MD_OK;
+}
+EXPORT int ref_point_in_polygon(const float* xy, int n, float px, float py) { return md_point_in_polygon(xy, n, px, py); }
 EXPORT int ref_abi(int32_t* sizes, int n) {
     int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),
                      sizeof(MdRoad), sizeof(MdGrid), sizeof(MdWorld), sizeof(MdState), sizeof(MdConfig)};

@@ -76,6 +76,15 @@ def load(path=None):
     lib.ref_idm_vehicle.restype = None
     lib.ref_idm_vehicle.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.ref_scenario_observe.restype = C.c_int
+    lib.ref_scenario_observe.argtypes = [W, S, K]
+    lib.ref_tidm_vehicle.restype = C.c_int
+    lib.ref_tidm_vehicle.argtypes = [W, S, K, C.c_int, C.c_int, C.c_int]
+    lib.ref_poly_local.argtypes = [C.c_void_p, C.c_int, f, f, C.c_void_p]
+    lib.ref_poly_position.argtypes = [C.c_void_p, C.c_int, f, f, C.c_void_p]
+    lib.ref_traj_navi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, f, f, f, f, C.c_void_p]
+    lib.ref_point_in_polygon.restype = C.c_int
+    lib.ref_point_in_polygon.argtypes = [C.c_void_p, C.c_int, f, f]
     lib.ref_probe_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     abi.check_abi(lib.ref_abi, path)
     _LIBS[path] = lib

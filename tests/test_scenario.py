@@ -1,0 +1,363 @@
+"""Scenario mode (BASELINE configs[4]: ScenarioEnv + reactive TrajectoryIDMPolicy traffic).
+
+CPU: the host tables + the oracle against the reference's own classes (tests/golden/scenario.json: InterpolatingLine /
+PointLane, TrajectoryNavigation, ScenarioEnv reward / cost / done, TrajectoryIDMPolicy) and behaviour of the traffic
+lifecycle.  GPU: scenario_step_kernel bit-exact against the oracle on synthetic scenes and on scenes exported from PG
+rollouts; a 2048-scene property test (BASELINE configs[4]'s batch)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from metadrive_ped_amd import abi
+from metadrive_ped_amd.scenario import PolyLine, ScenarioHostScene, make_scenario_config, synthetic_scenarios
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SC_KEYS = ["shape", "dyn", "nav", "pid", "action", "flags", "obs", "reward", "cost", "step_info", "need_reset", "next_agent_id"]
+
+
+def _oracle(host):
+    o = ob.OracleWorld(host)
+    o.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+    return o
+
+
+def _follow(obs, n_side=12, gain_h=6.0, gain_l=2.0, throttle=0.3):
+    """a small route follower on the navigation dims (lateral, heading error)"""
+    o_navi = (n_side or 2) + 6 + 1
+    a = np.zeros((len(obs), 1, 2), np.float32)
+    a[:, 0, 0] = np.clip(gain_h * (obs[:, o_navi + 19] - 0.5) + gain_l * (obs[:, o_navi + 18] - 0.5), -1, 1)
+    a[:, 0, 1] = throttle
+    return a
+
+
+def test_scenario_rollout_on_the_oracle_lifecycle_and_reactive_traffic():
+    E = 8
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=400, auto_reset=False))
+    host = ScenarioHostScene(cfg, synthetic_scenarios(E, 300))
+    assert host.obs_dim == 12 + 6 + 1 + 22 + 120
+    o = _oracle(host)
+    o.reset()
+    nav = o.state["nav"].reshape(E, host.cap)
+    sh = o.state["shape"].reshape(E, host.cap)
+    meta = host.world.arrays["track_meta"].reshape(E, host.cap, 4)
+    # after the reset: every spawnable track valid at frame 0 is in the world, the ones behind the ego that move are reactive
+    # with policy indices 0, 1, 2, 3, 4, 0, ... in slot order (scenario_traffic_manager.py:231-236)
+    for e in range(E):
+        idm = np.nonzero(nav["ck0"][e] == abi.SC_IDM)[0]
+        assert len(idm) >= 3
+        assert list(nav["timer"][e][idm]) == [i % 5 for i in range(len(idm))]
+        assert o.state["next_agent_id"][e] == len(idm)
+        ego = sh[e, 0]
+        for j in idm:
+            rx, ry = sh["cx"][e, j] - ego["cx"], sh["cy"][e, j] - ego["cy"]
+            assert rx * ego["c"] + ry * ego["s"] < -1.0                     # behind the ego
+            assert o.state["dyn"]["speed"].reshape(E, host.cap)[e, j] == 0.0   # spawned at rest
+        never = (meta[e, :, 2] & abi.TM_NEVER) != 0
+        assert (nav["ck0"][e][never] == abi.SC_ABSENT).all()
+        late = (meta[e, :, 0] > 0) & ~never
+        assert (nav["ck0"][e][late] == abi.SC_ABSENT).all()
+    frames = host.tracks["shape"].reshape(host.T, E, host.cap)
+    succeeded = np.zeros(E, bool)
+    for t in range(1, 230):
+        o.step(_follow(o.obs))
+        k = t
+        if k < host.T:
+            # replayed movers sit exactly on their recorded frame; absent ones are not alive
+            rep = nav["ck0"] == abi.SC_REPLAY
+            kinds = sh["flags"] & abi.KIND_MASK
+            moving_rep = rep & ~np.isin(kinds, [abi.KIND_CONE, abi.KIND_BARRIER])
+            assert np.array_equal(sh["cx"][moving_rep], frames["cx"][k][moving_rep])
+            assert ((frames["flags"][k][moving_rep] & abi.F_ALIVE) != 0).all()
+            absent = (nav["ck0"] == abi.SC_ABSENT)
+            absent[:, 0] = False
+            assert ((sh["flags"][absent] & abi.F_ALIVE) == 0).all()
+        fl = o.state["flags"].reshape(E, host.cap)[:, 0]
+        succeeded |= (fl & abi.FL_ARRIVE_DEST) != 0
+    # after the data are over only reactive vehicles and static objects remain
+    rep = nav["ck0"] == abi.SC_REPLAY
+    kinds = sh["flags"] & abi.KIND_MASK
+    assert np.isin(kinds[rep], [abi.KIND_CONE, abi.KIND_BARRIER]).all()
+    assert succeeded.sum() >= E // 2          # the follower completes most routes
+    assert (o.state["step_info"][:, 6] > 0.5).all()
+
+
+def test_reactive_vehicle_brakes_behind_a_stopped_ego():
+    """The point of reactive_traffic: a TrajectoryIDMPolicy vehicle following the ego slows down when the ego stops, while
+    the same track replayed (reactive_traffic off) drives through it."""
+    E = 4
+    scs = synthetic_scenarios(E, 900, n_vehicles=10)
+    out = {}
+    for reactive in (True, False):
+        cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=reactive, horizon=400, auto_reset=False))
+        host = ScenarioHostScene(cfg, scs)
+        o = _oracle(host)
+        o.reset()
+        crashed = np.zeros(E, bool)
+        for t in range(150):
+            a = _follow(o.obs, throttle=-1.0)          # the ego brakes to a halt and stays
+            o.step(a)
+            crashed |= (o.state["flags"].reshape(E, host.cap)[:, 0] & abi.FL_CRASH_VEHICLE) != 0
+        nav = o.state["nav"].reshape(E, host.cap)
+        sp = o.state["dyn"]["speed"].reshape(E, host.cap)
+        out[reactive] = (crashed.copy(), nav["ck0"].copy(), sp.copy())
+    # same-lane followers: replayed ones run into the halted ego in some scene, reactive ones queue up behind it
+    assert out[False][0].sum() > out[True][0].sum()
+    idm = out[True][1] == abi.SC_IDM
+    assert idm.sum() >= 4
+    assert (out[True][2][idm] < 12.0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reactive", [True, False])
+def test_scenario_step_gpu_parity(reactive):
+    import torch
+    from metadrive_ped_amd.engine import BatchedEngine
+    E = 24
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=reactive, horizon=260, auto_reset=True))
+    host = ScenarioHostScene(cfg, synthetic_scenarios(E, 40))
+    eng = BatchedEngine(cfg, host=host)
+    o = _oracle(host)
+    eng.reset()
+    o.reset()
+    from helpers import assert_state_equal
+    assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="scenario reset")
+    rng = np.random.RandomState(3)
+    for t in range(320):
+        a = _follow(o.obs, throttle=0.35 if (t // 60) % 2 == 0 else -0.4)
+        a[:, 0, 0] += rng.uniform(-0.05, 0.05, size=E).astype(np.float32)
+        a[::5, 0, 0] += 0.4 * math.sin(t * 0.05)          # some egos wander off the route
+        eng.step(torch.from_numpy(a).to(eng.device))
+        o.step(a)
+        if t % 20 == 0 or t > 300:
+            assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="scenario step %d" % t)
+    st = eng.download_state()
+    assert_state_equal(st, o.state, keys=SC_KEYS, where="scenario final")
+    nav = st["nav"].reshape(E, host.cap)
+    if reactive:
+        assert (nav["ck0"] == abi.SC_IDM).any() or st["next_agent_id"].sum() > 0
+    assert np.isfinite(st["obs"]).all() and st["obs"].min() >= 0.0 and st["obs"].max() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors from the reference's own classes (oracle/gen/gen_golden.py::section_scenario)
+def _golden():
+    with open(os.path.join(GOLDEN, "scenario.json")) as fh:
+        return json.load(fh)
+
+
+def f32(x):
+    return float(np.float32(x))
+
+
+def _tie_zone(pl, p, eps=2e-3):
+    p = np.asarray(p, np.float64)
+    a = ((pl.start - p) * pl.direction).sum(1)
+    b = ((p - pl.end) * pl.direction).sum(1)
+    h = np.maximum.reduce([a, b, np.zeros(len(a))])
+    dpa = p - pl.start
+    c = dpa[:, 0] * pl.direction[:, 1] - dpa[:, 1] * pl.direction[:, 0]
+    d = np.sort(np.hypot(h, c))
+    return len(d) > 1 and d[1] - d[0] < eps
+
+
+def test_polyline_against_interpolating_line_and_point_lane():
+    g = _golden()
+    lib = ob.load()
+    n_q = 0
+    for rec in g["polylines"]:
+        pl = PolyLine(np.asarray(rec["points"]))
+        assert len(pl.seg_len) == len(rec["segments"])
+        for i, sg in enumerate(rec["segments"]):
+            np.testing.assert_allclose(pl.start[i], sg["start"], atol=1e-9)
+            np.testing.assert_allclose(pl.end[i], sg["end"], atol=1e-9)
+            assert abs(pl.seg_len[i] - sg["length"]) < 1e-9 and abs(pl.heading[i] - sg["heading"]) < 1e-9
+            np.testing.assert_allclose(pl.direction[i], sg["direction"], atol=1e-9)
+            if len(rec["segments"]) > 1 or sg["length"] != 0.1:      # (the static one-piece line: lateral hard-wired to +y)
+                np.testing.assert_allclose([pl.direction[i][1], -pl.direction[i][0]], sg["lateral_direction"], atol=1e-9)
+        assert abs(pl.length - rec["length"]) < 1e-9
+        np.testing.assert_allclose(pl.outline(rec["width"]), rec["polygon"], atol=1e-9)        # PointLane.auto_generate_polygon
+        np.testing.assert_allclose(pl.position(0.0), rec["start"], atol=1e-9)
+        np.testing.assert_allclose(pl.position(pl.length), rec["end"], atol=1e-9)
+        segs = pl.records()
+        out4 = np.zeros(4, np.float32)
+        out2 = np.zeros(2, np.float32)
+        for q in rec["queries"]:
+            lg, lt = pl.local_coordinates(q["point"])
+            assert abs(lg - q["long"]) < 1e-9 and abs(lt - q["lat"]) < 1e-9
+            np.testing.assert_allclose(pl.position(q["s"], q["lateral"]), q["position"], atol=1e-9)
+            assert abs(pl.heading_at(lg) - q["heading_at_long"]) < 1e-12
+            # the float32 oracle: coordinates of a few hundred metres -> millimetres.  Outside a convex corner the
+            # nearest point of BOTH adjacent pieces is their shared vertex: an exact tie that rounding decides, in the
+            # reference as well -- such points say nothing about the arithmetic
+            if _tie_zone(pl, q["point"]) or (len(rec["segments"]) == 1 and rec["segments"][0]["length"] == 0.1):
+                continue      # (the never-moving line: its hard-wired lateral direction is not modelled on the device)
+            lib.ref_poly_local(segs.ctypes.data, len(segs), f32(q["point"][0]), f32(q["point"][1]), out4.ctypes.data)
+            assert abs(out4[0] - q["long"]) < 3e-3 and abs(out4[1] - q["lat"]) < 3e-3, (out4, q)
+            assert abs(out4[3] - rec["length"]) < 1e-3
+            lib.ref_poly_position(segs.ctypes.data, len(segs), f32(q["s"]), f32(q["lateral"]), out2.ctypes.data)
+            np.testing.assert_allclose(out2, q["position"], atol=3e-3)
+            n_q += 1
+    assert n_q > 150
+
+
+def _one_scene_host(points, T=160, extra_tracks=None, **cfg_kw):
+    """a ScenarioHostScene whose SDC track follows `points`"""
+    from metadrive_ped_amd.scenario import _track_dict
+    pts = np.asarray(points, np.float64)
+    n = len(pts)
+    h = np.arctan2(np.gradient(pts[:, 1]), np.gradient(pts[:, 0]))
+    tracks = {"0": _track_dict("0", "VEHICLE", n, np.ones(n, bool), pts[:, 0], pts[:, 1], h, np.zeros(n), 4.5, 1.85, 1.5)}
+    tracks.update(extra_tracks or {})
+    sc = {"id": "t", "version": "t", "length": n, "metadata": {"sdc_id": "0", "ts": np.arange(n) * 0.1}, "tracks": tracks,
+          "dynamic_map_states": {}, "map_features": {}}
+    cfg = make_scenario_config(dict(dict(num_envs=1, num_scenarios=1, auto_reset=False), **cfg_kw))
+    return ScenarioHostScene(cfg, [sc])
+
+
+def test_trajectory_navigation_reward_cost_done_against_reference():
+    """TrajectoryNavigation.update_localization (22 dims, unpacking quirk, route completion), the state observation with a
+    PointLane, ScenarioEnv.reward_function / cost_function / done_function: the oracle on posed agents."""
+    g = _golden()
+    FLAG = dict(crash_vehicle=abi.FL_CRASH_VEHICLE, crash_object=abi.FL_CRASH_OBJECT, crash_building=abi.FL_CRASH_BUILDING,
+                crash_human=abi.FL_CRASH_HUMAN, crash_sidewalk=abi.FL_CRASH_SIDEWALK,
+                on_yellow_continuous_line=abi.FL_ON_YELLOW_CONT, on_white_continuous_line=abi.FL_ON_WHITE_CONT)
+    n = 0
+    for case in g["agent"]:
+        host = _one_scene_host(case["points"], vehicle_config=dict(side_detector=dict(num_lasers=0, distance=50),
+                                                                    lidar=dict(num_lasers=0, distance=0)))
+        np.testing.assert_allclose(host.world.arrays["ckpt_xy"], case["checkpoints"], atol=2e-4)
+        ref_line = PolyLine(np.asarray(case["points"]))
+        assert host.obs_dim == 2 + 6 + 1 + 22
+        for smp in case["samples"]:
+            if abs((smp["long"] / 2.0) - round(smp["long"] / 2.0)) < 2e-3 or _tie_zone(ref_line, smp["pos"]):
+                continue        # float32 vs float64 right at a checkpoint boundary / in a corner's tie zone
+            o = ob.OracleWorld(host, host.clone_state())
+            st, k = o.state, o.k
+            st["need_reset"][:] = 0
+            sh, dy = st["shape"], st["dyn"]
+            sh["cx"][0], sh["cy"][0] = smp["pos"]
+            sh["c"][0], sh["s"][0] = math.cos(smp["heading"]), math.sin(smp["heading"])
+            dy["heading"][0], dy["speed"][0] = smp["heading"], smp["speed"]
+            dy["steering"][0] = smp["action"][0]
+            dy["last_c"][0], dy["last_s"][0] = math.cos(smp["last_heading"]), math.sin(smp["last_heading"])
+            dy["last_x"][0], dy["last_y"][0] = smp["pos"]
+            st["action"][0] = smp["action"]
+            st["pid"]["hp"][0] = smp["long_before"]
+            st["nav"]["steps"][0] = smp["steps"]
+            fl = 0
+            for name, bit in FLAG.items():
+                if smp["flags"][name]:
+                    fl |= bit
+            st["flags"][0] = fl
+            cf = smp["config"]
+            k.horizon = smp["horizon"]
+            k.truncate_as_terminate = int(cf["truncate_as_terminate"])
+            k.relax_out_of_road_done = int(cf["relax_out_of_road_done"])
+            k.out_of_route_done = int(cf["out_of_route_done"])
+            k.crash_vehicle_done, k.crash_object_done, k.crash_human_done = int(cf["crash_vehicle_done"]), int(cf["crash_object_done"]), int(cf["crash_human_done"])
+            k.no_negative_reward = int(cf["no_negative_reward"])
+            k.allowed_more_steps = int(cf["allowed_more_steps"] or 0)
+            k.scenario_length = case["scenario_length"]
+            o.call("ref_scenario_observe")
+            obs = st["obs"][0]
+            np.testing.assert_allclose(obs[:7], smp["state9"][:7], atol=2e-5, err_msg=str(smp))     # borders, heading_diff, speed, steering, actions
+            assert abs(obs[7] - smp["state9"][7]) < 1e-3                                           # yaw rate: acos near 1
+            assert abs(obs[8] - smp["state9"][8]) < 5e-4                                           # lateral / 4.5 (float32 coordinates)
+            np.testing.assert_allclose(obs[9:31], smp["navi"], atol=2e-4, err_msg=str(smp))
+            assert obs[9] == obs[10] and obs[25] == obs[26]                                        # the unpacking quirk: both slots alike
+            assert abs(st["step_info"][0, 6] - smp["route_completion"]) < 1e-4
+            out = int(st["flags"][0])
+            di = smp["done_info"]
+            edge = abs(abs(smp["lat"]) - 4.0) < 5e-3 or abs(smp["route_completion"] - 0.95) < 1e-4 or \
+                abs(smp["route_completion"] + 0.1) < 1e-4 or abs(abs(smp["lat"]) - 10.0) < 5e-3
+            if not edge:
+                assert bool(out & abi.FL_ARRIVE_DEST) == di["arrive_dest"], smp
+                assert bool(out & abi.FL_OUT_OF_ROAD) == di["out_of_road"], smp
+                assert bool(out & abi.FL_MAX_STEP) == di["max_step"], smp
+                assert bool(out & abi.FL_TERMINATED) == smp["done"], smp
+                assert abs(st["reward"][0] - smp["reward"]) < 3e-3, (st["reward"][0], smp)
+                assert abs(st["step_info"][0, 0] - smp["step_reward"]) < 3e-3
+                assert abs(st["cost"][0] - smp["cost"]) < 1e-6
+                n += 1
+    assert n >= 100
+
+
+def test_trajectory_idm_policy_act_against_reference():
+    """TrajectoryIDMPolicy.act: heading PID (1.2, 0.1, 3.5) carried over the sequence, speed control only when
+    step % 5 == policy_index (else the last acceleration), single-lane front search within 20 m over objects that have a
+    chassis corner on the route's outline, arrival inside 2 m of the route's end."""
+    from metadrive_ped_amd.scenario import _track_dict
+    g = _golden()
+    lib = ob.load()
+    n_speed = n_front = 0
+    for case in g["traj_idm"]:
+        pts = np.asarray(case["points"], np.float64)
+        n = len(pts)
+        hh = np.arctan2(np.gradient(pts[:, 1]), np.gradient(pts[:, 0]))
+        extra = {"1": _track_dict("1", "VEHICLE", n, np.ones(n, bool), pts[:, 0], pts[:, 1], hh, np.full(n, 5.0), 4.6, 1.9, 1.5)}
+        for q in range(2, 6):
+            extra[str(q)] = _track_dict(str(q), "VEHICLE", n, np.ones(n, bool), pts[:, 0] + 500.0, pts[:, 1], hh, np.full(n, 5.0), 4.6, 1.9, 1.5)
+        host = _one_scene_host(pts + np.array([0.0, 300.0]), T=n, extra_tracks=extra, reactive_traffic=True)
+        a = host.world.arrays
+        np.testing.assert_allclose(a["polyv"][a["polyv_off"][1]:a["polyv_off"][2]], case["polygon"], atol=2e-4)
+        o = ob.OracleWorld(host, host.clone_state())
+        o.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+        st = o.state
+        cap = host.cap
+        sh, dy, nav = st["shape"], st["dyn"], st["nav"]
+        nav["ck0"][1], nav["timer"][1] = abi.SC_IDM, case["policy_index"]
+        for smp in case["sequence"]:
+            sh["flags"][1] = abi.KIND_VEHICLE | abi.F_ALIVE
+            sh["cx"][1], sh["cy"][1] = smp["pos"]
+            sh["c"][1], sh["s"][1] = math.cos(smp["heading"]), math.sin(smp["heading"])
+            dy["heading"][1], dy["speed"][1] = smp["heading"], smp["speed"]
+            sh["flags"][2:cap] = 0
+            for j, ob_ in enumerate(smp["objs"], start=2):
+                sh["flags"][j] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_STATIC
+                sh["cx"][j], sh["cy"][j] = ob_["pos"]
+                sh["c"][j], sh["s"][j] = math.cos(ob_["heading"]), math.sin(ob_["heading"])
+                sh["hl"][j], sh["hw"][j] = ob_["length"] / 2, ob_["width"] / 2
+                dy["speed"][j], dy["heading"][j] = ob_["speed"], ob_["heading"]
+            nav["ck0"][1] = abi.SC_IDM
+            lib.ref_tidm_vehicle(o.w, o.s, o.k, 0, 1, smp["step"])
+            assert (nav["ck0"][1] == abi.SC_ARRIVED) == smp["arrived"]
+            if smp["arrived"]:
+                continue            # the manager removes it; the reference's act() is not reached
+            assert ((smp["step"] % 5) == case["policy_index"]) == smp["do_speed_control"]
+            act = st["action"][1]
+            assert abs(act[0] - smp["action"][0]) < 2e-3 * max(1.0, abs(smp["action"][0])), (act, smp["action"])
+            assert abs(act[1] - smp["action"][1]) < 2e-3 * max(1.0, abs(smp["action"][1])), (act, smp)
+            n_speed += smp["do_speed_control"]
+            n_front += smp["do_speed_control"] and len(smp["objs"]) > 0
+    assert n_speed >= 20 and n_front >= 10
+
+
+def test_track_bookkeeping_against_reference():
+    """first valid run (get_max_valid_indicis), static-car test (std of the valid positions > 3 m), minimum length for a
+    reactive policy, noise objects (< 20 valid frames): ScenarioHostScene's track_meta."""
+    from metadrive_ped_amd.scenario import synthetic_scenario
+    g = _golden()
+    by_seed = {}
+    for b in g["bookkeeping"]:
+        by_seed.setdefault(b["seed"], []).append(b)
+    n = 0
+    for seed, rows in by_seed.items():
+        sc = synthetic_scenario(seed, T=120)
+        cfg = make_scenario_config(dict(num_envs=1, num_scenarios=1))
+        host = ScenarioHostScene(cfg, [sc])
+        meta = host.world.arrays["track_meta"]
+        for b in rows:
+            j = host.track_ids[0].index(b["oid"])
+            if j == 0:
+                continue
+            assert [int(meta[j, 0]), int(meta[j, 1])] == b["run"], b
+            if b["type"] == "VEHICLE":
+                assert bool(meta[j, 2] & abi.TM_MOVING) == b["moving"] and bool(meta[j, 2] & abi.TM_LENGTH_OK) == b["length_ok"], b
+            if b["type"] == "TRAFFIC_CONE":
+                assert bool(meta[j, 2] & abi.TM_NEVER) == b["noise"], b
+            n += 1
+    assert n > 40
