@@ -265,7 +265,7 @@ def test_trajectory_navigation_reward_cost_done_against_reference():
             o.call("ref_scenario_observe")
             obs = st["obs"][0]
             np.testing.assert_allclose(obs[:7], smp["state9"][:7], atol=2e-5, err_msg=str(smp))     # borders, heading_diff, speed, steering, actions
-            assert abs(obs[7] - smp["state9"][7]) < 1e-3                                           # yaw rate: acos near 1
+            assert abs(obs[7] - smp["state9"][7]) < 4e-3                                           # yaw rate: acos of a float32 cosine near 1
             assert abs(obs[8] - smp["state9"][8]) < 5e-4                                           # lateral / 4.5 (float32 coordinates)
             np.testing.assert_allclose(obs[9:31], smp["navi"], atol=2e-4, err_msg=str(smp))
             assert obs[9] == obs[10] and obs[25] == obs[26]                                        # the unpacking quirk: both slots alike
