@@ -227,6 +227,9 @@ def main():
     n_cpu1 = max(1, n_cpu // 16)
 
     def build_hosts():
+        if args.workload == "scenario":
+            from metadrive_ped_amd.scenario import ScenarioHostScene, synthetic_scenarios
+            return dict(main=ScenarioHostScene(cfg, synthetic_scenarios(E, rank * E)))
         h = dict(main=HostScene(cfg))
         if args.workload == "replay":   # the recording run's scenes
             h["rcfg"] = make_config(dict(common, map=3, traffic_density=0.1, horizon=200, traffic_mode="trigger"))

@@ -16,6 +16,7 @@ bodies exist in these scenes: the side detector reports "nothing" and no line fl
 """
 import copy
 import math
+import os
 
 import numpy as np
 
@@ -124,6 +125,13 @@ class PolyLine:
         d = self.direction[i]
         return self.start[i] + (s - self.cum[i]) * d + lateral * self.lateral[i]
 
+    def positions(self, s, lateral=0.0):
+        """position() for an array of longitudinals (same piece rule: first accumulated end + 0.1 >= s, else the last)"""
+        s = np.asarray(s, dtype=np.float64)
+        ends = np.cumsum(self.seg_len)      # the reference accumulates in this order too
+        i = np.minimum(np.searchsorted(ends + 0.1, s, side="left"), len(ends) - 1)
+        return self.start[i] + (s - self.cum[i])[:, None] * self.direction[i] + lateral * self.lateral[i]
+
     def heading_at(self, s):
         acc = 0.0
         for i, L in enumerate(self.seg_len):
@@ -154,9 +162,7 @@ class PolyLine:
     def checkpoints(self):
         """TrajectoryNavigation.discretize_reference_trajectory (trajectory_navigation.py:96-103)"""
         num = int(self.length / 2.0)
-        pts = [self.position(i * 2.0, 0.0) for i in range(num)]
-        pts.append(self.position(self.length, 0.0))
-        return np.asarray(pts)
+        return np.concatenate([self.positions(np.arange(num) * 2.0), self.position(self.length, 0.0)[None]])
 
     def outline(self, width=ROUTE_WIDTH):
         """PointLane.auto_generate_polygon (component/lane/point_lane.py:60-106): the strip of the given width sampled
@@ -169,8 +175,9 @@ class PolyLine:
         for side in (0, 1):
             seq = longs if side == 0 else longs[::-1]
             lat = -width / 2 if side == 0 else width / 2
-            for t, s in enumerate(seq):
-                p = self.position(float(s), lat)
+            pts = self.positions(seq, lat)
+            for t in range(len(seq)):
+                p = pts[t]
                 at_start = (t == 0 and side == 0) or (t == len(seq) - 1 and side == 1)
                 at_end = (t == 0 and side == 1) or (t == len(seq) - 1 and side == 0)
                 if at_start:
@@ -219,6 +226,112 @@ def vehicle_class_for(length, counters):
     return ["l", "xl"][counters[2] % 2]
 
 
+def _build_scene(job):
+    """One scenario description -> the per-scene arrays (module-level so that a fork pool can run it)."""
+    from metadrive_ped_amd.scene import vehicle_param_record
+    from metadrive_ped_amd.rng import get_np_random
+    e, sc, cap, T, seed, dt, no_traffic = job
+    shape0 = np.zeros(cap, dtype=abi.SHAPE_DT)
+    shape0["aux"] = -1
+    dyn0 = np.zeros(cap, dtype=abi.DYN_DT)
+    param = np.zeros(cap, dtype=abi.PARAM_DT)
+    param["max_speed_kmh"], param["lf"], param["lr"] = 80.0, 1.0, 1.0
+    fshape = np.zeros((T, cap), dtype=abi.SHAPE_DT)
+    fshape["aux"] = -1
+    fdyn = np.zeros((T, cap, 2), np.float32)
+    meta = np.zeros((cap, 4), np.int32)
+    meta[:, 2] = abi.TM_NEVER
+    sdc_id = str(sc["metadata"]["sdc_id"])
+    order = [sdc_id] + [str(k) for k in sc["tracks"] if str(k) != sdc_id]
+    counters = [0, 0, 0]
+    polys = [None] * cap
+    ck = None
+    for j, oid in enumerate(order):
+        tr = sc["tracks"][oid] if oid in sc["tracks"] else sc["tracks"][int(oid)]
+        st = tr["state"]
+        valid = np.asarray(st["valid"]).astype(bool)
+        pos = np.asarray(st["position"], dtype=np.float64)[:, :2]
+        heading = np.asarray(st["heading"], dtype=np.float64)
+        vel = np.asarray(st["velocity"], dtype=np.float64)
+        n = j
+        run = _first_run(valid)
+        if j == 0:
+            # the agent: default vehicle at the SDC's first frame (scenario_map_manager.py:55-75); its route =
+            # the whole track up to the first > 100 m jump (parse_full_trajectory, parse_object_state.py:77-90)
+            cut = len(pos)
+            for t in range(len(pos) - 1):
+                if math.hypot(*(pos[t] - pos[t + 1])) > 100:
+                    cut = t
+                    break
+            polys[0] = PolyLine(pos[:cut])
+            prm, length, width, _ = vehicle_param_record("default", int(get_np_random(seed).randint(0, 2 ** 16)), dt)
+            param[n] = prm
+            h = float(heading[0])
+            sh = shape0[n]
+            sh["cx"], sh["cy"], sh["c"], sh["s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
+            sh["hl"], sh["hw"] = length / 2, width / 2
+            sh["flags"] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT
+            shape0[n] = sh
+            d = dyn0[n]
+            d["heading"], d["speed"] = h, float(vel[0, 0] * math.cos(h) + vel[0, 1] * math.sin(h))
+            d["last_x"], d["last_y"], d["last_c"], d["last_s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
+            dyn0[n] = d
+            meta[n] = (0, len(pos), abi.TM_NEVER, 0)
+            ck = polys[0].checkpoints()
+            continue
+        kind = _KIND_OF_TYPE.get(tr["type"])
+        if kind is None or run is None or no_traffic:
+            continue
+        t0, t1 = run
+        flags = 0
+        if kind == abi.KIND_VEHICLE:
+            vp = pos[valid]
+            if float(np.max(np.std(vp, axis=0)[:2])) > STATIC_THRESHOLD:
+                flags |= abi.TM_MOVING
+            if math.hypot(*(pos[t0] - pos[t1 - 1])) > IDM_CREATE_MIN_LENGTH:
+                flags |= abi.TM_LENGTH_OK
+            rec_len = float(np.asarray(st["length"])[t0]) if "length" in st else 4.5
+            vtype = vehicle_class_for(rec_len, counters)
+            prm, length, width, _ = vehicle_param_record(vtype, int(get_np_random(seed * 131 + j).randint(0, 2 ** 16)), dt)
+            param[n] = prm
+            hl, hw = length / 2, width / 2
+            polys[j] = PolyLine(pos[t0:t1])
+        elif kind == abi.KIND_PEDESTRIAN:
+            hl = hw = 0.35
+        elif kind == abi.KIND_CYCLIST:
+            hl, hw = 0.875, 0.2
+        elif kind == abi.KIND_CONE:
+            hl = hw = 0.2
+            if int(valid.sum()) < MIN_VALID_FRAME_LEN:
+                flags |= abi.TM_NEVER
+        else:
+            hl, hw = 0.15, 1.0
+            if int(valid.sum()) < MIN_VALID_FRAME_LEN:
+                flags |= abi.TM_NEVER
+        meta[n] = (t0, t1, flags, 0)
+        f = fshape[:, n]
+        f["cx"][valid], f["cy"][valid] = pos[valid, 0], pos[valid, 1]
+        f["c"][valid], f["s"][valid] = np.cos(heading[valid]), np.sin(heading[valid])
+        f["hl"][valid], f["hw"][valid] = hl, hw
+        fl = kind | abi.F_ALIVE
+        if kind in (abi.KIND_CONE, abi.KIND_BARRIER):
+            fl |= abi.F_STATIC
+        f["flags"][valid] = fl
+        fshape[:, n] = f
+        fdyn[valid, n, 0] = heading[valid]
+        fdyn[valid, n, 1] = np.hypot(vel[valid, 0], vel[valid, 1])
+        # a free slot still carries the class's size, so that the device only rewrites the pose on a spawn
+        shape0[n]["hl"], shape0[n]["hw"] = hl, hw
+    segs, verts = [], []
+    for j in range(cap):
+        pl = polys[j]
+        segs.append(pl.records() if pl is not None else np.zeros(0, dtype=abi.SEG_DT))
+        want_outline = j > 0 and pl is not None and (meta[j, 2] & abi.TM_MOVING) and (meta[j, 2] & abi.TM_LENGTH_OK)
+        verts.append(pl.outline() if want_outline else np.zeros((0, 2)))
+    return dict(shape0=shape0, dyn0=dyn0, param=param, fshape=fshape, fdyn=fdyn, meta=meta, order=order, segs=segs, verts=verts, ckpt=ck)
+
+
+
 class _World:
     def __init__(self, arrays, n_envs):
         self.arrays = arrays
@@ -260,118 +373,45 @@ class ScenarioHostScene:
         N = E * cap
         dt = cfg["physics_world_step_size"]
 
-        shape0 = np.zeros(N, dtype=abi.SHAPE_DT)
-        shape0["aux"] = -1
-        dyn0 = np.zeros(N, dtype=abi.DYN_DT)
+        jobs = [(e, scenarios[e], cap, T, self.seeds[e], dt, bool(cfg["no_traffic"])) for e in range(E)]
+        workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
+        try:
+            import torch
+            if torch.cuda.is_initialized():
+                workers = 1          # never fork a process that has initialised the GPU (see HostScene)
+        except ImportError:
+            pass
+        if E >= 64 and workers > 1:
+            import multiprocessing as mp
+            pool = mp.get_context("fork").Pool(workers)
+            try:
+                built = pool.map(_build_scene, jobs, chunksize=max(1, E // (workers * 4)))
+            finally:
+                pool.close()
+                pool.join()
+        else:
+            built = [_build_scene(j) for j in jobs]
+        shape0 = np.concatenate([b_["shape0"] for b_ in built])
+        dyn0 = np.concatenate([b_["dyn0"] for b_ in built])
+        param = np.concatenate([b_["param"] for b_ in built])
         nav0 = np.zeros(N, dtype=abi.NAV_DT)
         nav0["lane"], nav0["target_lane"], nav0["road0"], nav0["road1"] = -1, -1, -1, -1
         pid0 = np.zeros(N, dtype=abi.PID_DT)
         pid0["target_speed"] = 40.0
-        param = np.zeros(N, dtype=abi.PARAM_DT)
-        param["max_speed_kmh"], param["lf"], param["lr"] = 80.0, 1.0, 1.0
-        fshape = np.zeros((T, N), dtype=abi.SHAPE_DT)
-        fshape["aux"] = -1
-        fdyn = np.zeros((T, N, 2), np.float32)
-        meta = np.zeros((N, 4), np.int32)
-        meta[:, 2] = abi.TM_NEVER
-        segs, poly_off = [], [0]
-        verts, polyv_off = [], [0]
-        ckpts, ckpt_off = [], [0]
-        self.track_ids = []
-        for e, sc in enumerate(scenarios):
-            sdc_id = str(sc["metadata"]["sdc_id"])
-            order = [sdc_id] + [k for k in sc["tracks"] if str(k) != sdc_id]
-            self.track_ids.append(order)
-            counters = [0, 0, 0]
-            polys = [None] * cap
-            for j, oid in enumerate(order):
-                tr = sc["tracks"][oid] if oid in sc["tracks"] else sc["tracks"][int(oid)]
-                st = tr["state"]
-                valid = np.asarray(st["valid"]).astype(bool)
-                pos = np.asarray(st["position"], dtype=np.float64)[:, :2]
-                heading = np.asarray(st["heading"], dtype=np.float64)
-                vel = np.asarray(st["velocity"], dtype=np.float64)
-                n = e * cap + j
-                run = _first_run(valid)
-                if j == 0:
-                    # the agent: default vehicle at the SDC's first frame (scenario_map_manager.py:55-75); its route =
-                    # the whole track up to the first > 100 m jump (parse_full_trajectory, parse_object_state.py:77-90)
-                    cut = len(pos)
-                    for t in range(len(pos) - 1):
-                        if math.hypot(*(pos[t] - pos[t + 1])) > 100:
-                            cut = t
-                            break
-                    polys[0] = PolyLine(pos[:cut])
-                    prm, length, width, _ = vehicle_param_record("default", int(get_np_random(self.seeds[e]).randint(0, 2 ** 16)), dt)
-                    param[n] = prm
-                    h = float(heading[0])
-                    sh = shape0[n]
-                    sh["cx"], sh["cy"], sh["c"], sh["s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
-                    sh["hl"], sh["hw"] = length / 2, width / 2
-                    sh["flags"] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT
-                    shape0[n] = sh
-                    d = dyn0[n]
-                    d["heading"], d["speed"] = h, float(vel[0, 0] * math.cos(h) + vel[0, 1] * math.sin(h))
-                    d["last_x"], d["last_y"], d["last_c"], d["last_s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
-                    dyn0[n] = d
-                    meta[n] = (0, len(pos), abi.TM_NEVER, 0)
-                    ck = polys[0].checkpoints()
-                    ckpts.append(ck)
-                    ckpt_off.append(ckpt_off[-1] + len(ck))
-                    continue
-                kind = _KIND_OF_TYPE.get(tr["type"])
-                if kind is None or run is None or cfg["no_traffic"]:
-                    continue
-                t0, t1 = run
-                flags = 0
-                if kind == abi.KIND_VEHICLE:
-                    vp = pos[valid]
-                    if float(np.max(np.std(vp, axis=0)[:2])) > STATIC_THRESHOLD:
-                        flags |= abi.TM_MOVING
-                    if math.hypot(*(pos[t0] - pos[t1 - 1])) > IDM_CREATE_MIN_LENGTH:
-                        flags |= abi.TM_LENGTH_OK
-                    rec_len = float(np.asarray(st["length"])[t0]) if "length" in st else 4.5
-                    vtype = vehicle_class_for(rec_len, counters)
-                    prm, length, width, _ = vehicle_param_record(vtype, int(get_np_random(self.seeds[e] * 131 + j).randint(0, 2 ** 16)), dt)
-                    param[n] = prm
-                    hl, hw = length / 2, width / 2
-                    polys[j] = PolyLine(pos[t0:t1])
-                elif kind == abi.KIND_PEDESTRIAN:
-                    hl = hw = 0.35
-                elif kind == abi.KIND_CYCLIST:
-                    hl, hw = 0.875, 0.2
-                elif kind == abi.KIND_CONE:
-                    hl = hw = 0.2
-                    if int(valid.sum()) < MIN_VALID_FRAME_LEN:
-                        flags |= abi.TM_NEVER
-                else:
-                    hl, hw = 0.15, 1.0
-                    if int(valid.sum()) < MIN_VALID_FRAME_LEN:
-                        flags |= abi.TM_NEVER
-                meta[n] = (t0, t1, flags, 0)
-                f = fshape[:, n]
-                f["cx"][valid], f["cy"][valid] = pos[valid, 0], pos[valid, 1]
-                f["c"][valid], f["s"][valid] = np.cos(heading[valid]), np.sin(heading[valid])
-                f["hl"][valid], f["hw"][valid] = hl, hw
-                fl = kind | abi.F_ALIVE
-                if kind in (abi.KIND_CONE, abi.KIND_BARRIER):
-                    fl |= abi.F_STATIC
-                f["flags"][valid] = fl
-                fshape[:, n] = f
-                fdyn[valid, n, 0] = heading[valid]
-                fdyn[valid, n, 1] = np.hypot(vel[valid, 0], vel[valid, 1])
-                # a free slot still carries the class's size, so that the device only rewrites the pose on a spawn
-                shape0[n]["hl"], shape0[n]["hw"] = hl, hw
-            for j in range(cap):
-                pl = polys[j]
-                recs = pl.records() if pl is not None else np.zeros(0, dtype=abi.SEG_DT)
-                segs.append(recs)
-                poly_off.append(poly_off[-1] + len(recs))
-                n = e * cap + j
-                want_outline = j > 0 and pl is not None and (meta[n, 2] & abi.TM_MOVING) and (meta[n, 2] & abi.TM_LENGTH_OK)
-                v = pl.outline() if want_outline else np.zeros((0, 2))
+        fshape = np.concatenate([b_["fshape"] for b_ in built], axis=1)
+        fdyn = np.concatenate([b_["fdyn"] for b_ in built], axis=1)
+        meta = np.concatenate([b_["meta"] for b_ in built])
+        self.track_ids = [b_["order"] for b_ in built]
+        segs, poly_off, verts, polyv_off, ckpts, ckpt_off = [], [0], [], [0], [], [0]
+        for b_ in built:
+            for r in b_["segs"]:
+                segs.append(r)
+                poly_off.append(poly_off[-1] + len(r))
+            for v in b_["verts"]:
                 verts.append(v)
                 polyv_off.append(polyv_off[-1] + len(v))
+            ckpts.append(b_["ckpt"])
+            ckpt_off.append(ckpt_off[-1] + len(b_["ckpt"]))
         a = {}
         a["env_map"] = np.zeros(E, np.int32)
         a["lane_off"] = np.asarray([0, 1], np.int32)

@@ -361,3 +361,79 @@ def test_track_bookkeeping_against_reference():
                 assert bool(meta[j, 2] & abi.TM_NEVER) == b["noise"], b
             n += 1
     assert n > 40
+
+
+@pytest.mark.gpu
+def test_scenarios_exported_from_pg_rollouts_gpu_parity():
+    """record -> export_scenarios() -> ScenarioEnv: scenes recorded on PG maps with the IDM-driven agent as the SDC, loaded
+    as scenario descriptions; HIP and oracle agree bit for bit, and the follower completes the recorded routes."""
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
+    from metadrive_ped_amd.scenario_export import tracks_to_scenarios
+    E = 12
+    pg = HostScene(make_config(dict(num_envs=E, num_scenarios=E, start_seed=5, traffic_density=0.2, agent_policy="IDMPolicy",
+                                    horizon=1000, auto_reset=False, map="SCS")))
+    rec = ob.OracleWorld(pg)
+    rec.reset()
+    scs = tracks_to_scenarios(ob.record_episode(rec, [None] * 150), pg)
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=300, auto_reset=True))
+    host = ScenarioHostScene(cfg, scs)
+    eng = BatchedEngine(cfg, host=host)
+    o = _oracle(host)
+    eng.reset()
+    o.reset()
+    done = np.zeros(E, bool)
+    for t in range(200):
+        a = _follow(o.obs, throttle=0.4)
+        eng.step(torch.from_numpy(a).to(eng.device))
+        o.step(a)
+        done |= (o.state["flags"].reshape(E, host.cap)[:, 0] & abi.FL_ARRIVE_DEST) != 0
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="pg scenario step %d" % t)
+    assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="pg scenario final")
+    assert done.sum() >= E // 2
+
+
+@pytest.mark.gpu
+def test_scenario_full_size_properties_and_env_api():
+    """BASELINE configs[4]'s batch: 2048 scenes with reactive traffic through BatchedScenarioEnv -- observation bounds,
+    run-to-run bit determinism, the oracle on a sampled slice of the scenes, episodes that end and restart."""
+    import torch
+    from metadrive_ped_amd.envs.scenario_env import BatchedScenarioEnv
+    E = 2048
+    user = dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=250, auto_reset=True)
+    scs = synthetic_scenarios(E, 7000)
+    runs = []
+    for rep in range(2):
+        env = BatchedScenarioEnv(user, scenarios=scs)
+        if rep == 0:
+            host = ScenarioHostScene(env.config, scs)
+        env.lazy_init(host=host)
+        obs, info = env.reset()
+        assert tuple(obs.shape) == (E, env.observation_space.shape[0]) and obs.dtype == torch.float32
+        ended = torch.zeros(E, dtype=torch.bool, device=obs.device)
+        for t in range(120):
+            a = torch.zeros(E, 2, device=obs.device)
+            o_navi = 12 + 6 + 1
+            a[:, 0] = (6.0 * (obs[:, o_navi + 19] - 0.5) + 2.0 * (obs[:, o_navi + 18] - 0.5)).clamp(-1, 1)
+            a[:, 1] = 0.5
+            obs, rew, term, trunc, info = env.step(a)
+            ended |= term | trunc
+        assert float(obs.min()) >= 0.0 and float(obs.max()) <= 1.0 and bool(torch.isfinite(rew).all())
+        assert float(info["route_completion"].max()) > 0.3
+        runs.append((obs.clone().cpu().numpy(), env.engine.download_state()))
+        env.close()
+    assert runs[0][0].tobytes() == runs[1][0].tobytes()
+    for key in ("shape", "nav", "flags", "reward"):
+        assert runs[0][1][key].tobytes() == runs[1][1][key].tobytes(), key
+    # the oracle on every 64th scene, same actions recomputed from its own observations
+    idx = list(range(0, E, 64))
+    sub = ScenarioHostScene(make_scenario_config(dict(user, num_envs=len(idx), num_scenarios=len(idx))), [scs[i] for i in idx])
+    o = _oracle(sub)
+    o.reset()
+    for t in range(120):
+        o.step(_follow(o.obs, throttle=0.5))
+    got = runs[0][0][idx]
+    assert got.tobytes() == o.obs.tobytes()
