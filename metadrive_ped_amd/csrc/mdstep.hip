@@ -1809,21 +1809,34 @@ __global__ __launch_bounds__(64 * kWaveEnvs) void wave_step_kernel(MdWorld w, Md
 //   observe      lane 0 of wave 0: state + 22 navigation dims + ScenarioEnv reward / cost / done; lidar sectors on all waves
 // The scalar logic is include/md_scenario.h, shared with the oracle (which runs the serial forms).
 // ------------------------------------------------------------------------------------------------
-// InterpolatingLine.local_coordinates by one wave: lanes = segments (chunks of 64), first minimum wins like np.argmin
+// InterpolatingLine.local_coordinates by one wave: lanes = segments (chunks of 64), first minimum wins like np.argmin.
+// Every lane first keeps the best of ITS segments (lane, lane + 64, ...: a strict < keeps the earliest), then ONE dense
+// wave reduction: the minimum distance by a 6-step butterfly, and among the lanes that hold it the lowest segment index
+// (a sparse set, usually one lane: ballot walk).
 __device__ __forceinline__ int poly_argmin_wave(const MdPoly& p, float px, float py, int lane_id) {
     float bd = 3.0e38f;
-    int bi = 0;
-    for (int i0 = 0; i0 < p.n; i0 += 64) {
-        const int i = i0 + lane_id;
-        float d = (i < p.n) ? md_seg_dist(&p.segs[i], px, py) : 3.0e38f;
-        int idx = i;
-        wave_argmin(d, idx);   // ascending lane order = ascending segment index: equal distances keep the first
+    int bi = 0x7fffffff;
+    for (int i = lane_id; i < p.n; i += 64) {
+        const float d = md_seg_dist(&p.segs[i], px, py);
         if (d < bd) {
             bd = d;
-            bi = idx;
+            bi = i;
         }
     }
-    return bi;
+    float m = bd;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
+    return wave_min_i(bi, bd == m, 0);
+}
+
+// crossing number of the ray from (px, py) over the polygon's edges, lanes = edges: odd = inside (md_point_in_polygon)
+__device__ __forceinline__ bool point_in_polygon_wave(const float* xy, int n, float px, float py, int lane_id) {
+    int cnt = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane_id;
+        cnt += __popcll(__ballot(i < n && md_polygon_edge_crosses(xy, n, i, px, py)));
+    }
+    return (cnt & 1) != 0;
 }
 
 // first segment (ascending) for which `pred` holds, else the last one; pred evaluated by one lane per segment
@@ -1869,18 +1882,37 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     int front = -1;
     float front_dist = MD_TIDM_MAX_DIST;
     if (do_speed_control) {
+        // md_tidm_front_gap, wave form: lanes = movers for the 20 m filter; the survivors (a handful) one after the other,
+        // each corner of the chassis against the outline with lanes = polygon edges, then the projection on the route
+        // with lanes = segments.  Ascending slot order and a strict < keep the lowest slot among equal gaps.
         const float* pv = w.polyv + 2 * (size_t)w.polyv_off[ng];
         const int n_v = w.polyv_off[ng + 1] - w.polyv_off[ng];
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
-            const int j = j0 + lane_id;
-            float g = -1.0f;
-            if (j < c.cap && j != slot) g = md_tidm_front_gap(&route, pv, n_v, cur_long, px, py, &s.shape[j]);
-            float key = (g > 0.0f && g < MD_TIDM_MAX_DIST) ? g : 3.0e38f;
-            int idx = j;
-            wave_argmin(key, idx);
-            if (key < front_dist) {
-                front_dist = key;
-                front = idx;
+            const int jl = j0 + lane_id;
+            bool near = false;
+            if (jl < c.cap && jl != slot) {
+                const MdShape o = s.shape[jl];
+                near = md_present(o.flags) && !(md_norm(o.cx - px, o.cy - py) > MD_TIDM_MAX_DIST);
+            }
+            unsigned long long mk = __ballot(near);
+            while (mk) {
+                const int j = j0 + __ffsll((long long)mk) - 1;
+                mk &= mk - 1;
+                const MdShape o = s.shape[j];   // wave-uniform
+                const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
+                const bool on = point_in_polygon_wave(pv, n_v, o.cx + ex + fx, o.cy + ey + fy, lane_id) ||
+                                point_in_polygon_wave(pv, n_v, o.cx + ex - fx, o.cy + ey - fy, lane_id) ||
+                                point_in_polygon_wave(pv, n_v, o.cx - ex - fx, o.cy - ey - fy, lane_id) ||
+                                point_in_polygon_wave(pv, n_v, o.cx - ex + fx, o.cy - ey + fy, lane_id);
+                if (!on) continue;
+                const int bo = poly_argmin_wave(route, o.cx, o.cy, lane_id);
+                float lg, lt;
+                md_poly_local_at(&route, bo, o.cx, o.cy, &lg, &lt);
+                const float gap = lg - cur_long;
+                if (gap > 0.0f && gap < front_dist) {
+                    front_dist = gap;
+                    front = j;
+                }
             }
         }
     }

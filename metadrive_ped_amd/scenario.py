@@ -373,7 +373,10 @@ class ScenarioHostScene:
         N = E * cap
         dt = cfg["physics_world_step_size"]
 
-        jobs = [(e, scenarios[e], cap, T, self.seeds[e], dt, bool(cfg["no_traffic"])) for e in range(E)]
+        # vehicle parameters are sampled from a stream seeded by the scenario's OWN seed where it carries one, so that a
+        # scene behaves the same in whatever batch (slot, shard) it is loaded
+        jobs = [(e, scenarios[e], cap, T, int(scenarios[e]["metadata"].get("seed", self.seeds[e])), dt, bool(cfg["no_traffic"]))
+                for e in range(E)]
         workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
         try:
             import torch
