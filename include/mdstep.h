@@ -390,6 +390,12 @@ int md_probe_stream_copy(void* dst, const void* src, size_t nbytes, void* stream
 int md_lidar(const MdWorld* w, const MdState* s, const MdConfig* c, float* out, int out_stride, int out_offset,
              void* stream);
 
+/* Lidar.perceive complete (component/sensors/lidar.py:49-73): md_lidar's cloud points plus `detected_objects` --
+ * detected[(e*A+a)*2 .. +1] = the 128-bit set of the slots some beam of agent a hit first.  Needs only MdState.shape,
+ * MdWorld.beam_cs and the sizes in MdConfig: the sensor-level plug (metadrive_ped_amd/sensors.py: BatchedLidar). */
+int md_lidar_detect(const MdWorld* w, const MdState* s, const MdConfig* c, float* out, int out_stride, int out_offset,
+                    uint64_t* detected, void* stream);
+
 /* Side / lane-line detectors: DistanceDetector.perceive with the static line boxes as targets
  * (component/sensors/distance_detector.py:194-209; obs/state_obs.py:77-86,129-140).
  * kind_mask selects MD_Q_* kinds (bit k set = kind k is a target). beam table = beam_cs. */

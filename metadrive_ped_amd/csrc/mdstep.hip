@@ -2029,6 +2029,26 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
     }
 }
 
+// Lidar.perceive as a sensor on its own (md_lidar_detect): cloud points AND the detected-object sets, from nothing but
+// the shape table.  One workgroup per env, shapes + sets in LDS, (agent, sector) items dealt to the waves.
+__global__ __launch_bounds__(256) void lidar_detect_kernel(MdWorld w, MdState g, MdConfig c, float* out, int out_stride, int out_offset,
+                                                          unsigned long long* detected) {
+    const int e = blockIdx.x;
+    if (e >= c.n_envs) return;
+    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    MdShape* l_shape = reinterpret_cast<MdShape*>(smem);
+    unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_shape + c.cap);
+    copy16(l_shape, g.shape + (size_t)e * c.cap, c.cap * (int)sizeof(MdShape), tid, 256);
+    for (int j = tid; j < 2 * c.agents_per_env; j += 256) l_det[j] = 0ull;
+    __syncthreads();
+    MdState s = g;
+    s.shape = l_shape;
+    phase_lidar(w, s, c, e, tid, 4, out, out_stride, out_offset, l_det);
+    __syncthreads();
+    for (int j = tid; j < 2 * c.agents_per_env; j += 256) detected[(size_t)e * c.agents_per_env * 2 + j] = l_det[j];
+}
+
 // "Others" block of the observation (Lidar.get_surrounding_vehicles_info): one thread per agent, after the
 // step kernel has written the detected sets and the new state back.  Off in the headline configs.
 __global__ __launch_bounds__(64) void others_kernel(MdWorld w, MdState g, MdConfig c) {
@@ -2292,6 +2312,26 @@ __attribute__((visibility("default"))) int md_lidar(const MdWorld* w, const MdSt
         return MD_EINVAL;
     }
     return launch<PH_LIDAR>(w, s, c, out, out_stride, out_offset, stream);
+}
+
+__attribute__((visibility("default"))) int md_lidar_detect(const MdWorld* w, const MdState* s, const MdConfig* c, float* out,
+                                                          int out_stride, int out_offset, uint64_t* detected, void* stream) {
+    int r = check_common(w, s, c);
+    if (r != MD_OK) return r;
+    NEED(out); NEED(detected); NEED(w->beam_cs);
+    if (c->n_beams <= 0 || out_stride < c->n_beams + out_offset || out_offset < 0) {
+        snprintf(g_err, sizeof g_err, "md_lidar_detect: n_beams=%d stride=%d offset=%d", c->n_beams, out_stride, out_offset);
+        return MD_EINVAL;
+    }
+    const size_t lds = (size_t)c->cap * sizeof(MdShape) + (size_t)c->agents_per_env * 16 + 16;
+    hipLaunchKernelGGL(lidar_detect_kernel, dim3(c->n_envs), dim3(256), lds, (hipStream_t)stream, *w, *s, *c, out, out_stride,
+                       out_offset, (unsigned long long*)detected);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
 }
 
 __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c,

@@ -348,3 +348,160 @@ def test_step_is_capturable_in_a_hip_graph():
     assert torch.equal(e1.obs, e2.obs) and torch.equal(e1.reward, e2.reward)
     for k in ("shape", "dyn", "nav", "flags"):
         assert torch.equal(e1.state_dev[k], e2.state_dev[k]), k
+
+
+def _run_twice_and_sample(cfg, host, acts, sub_cfg_fn, sub, A, keys=("obs", "reward", "flags")):
+    """two runs on the GPU must agree bit for bit; the first `sub` envs must agree with the oracle stepping that slice"""
+    import torch
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
+    import oracle_binding as ob
+    finals = []
+    for run in range(2):
+        eng = BatchedEngine(cfg, host=host)
+        eng.reset()
+        for a in acts:
+            eng.step(a)
+        torch.cuda.synchronize()
+        finals.append(eng.download_state())
+        del eng
+    for k in finals[0]:
+        assert finals[0][k].tobytes() == finals[1][k].tobytes(), k
+    sub_host = HostScene(sub_cfg_fn(sub))
+    o = ob.OracleWorld(sub_host)
+    o.reset()
+    for a in acts:
+        o.step(a[:sub].cpu().numpy())
+    E = host.E
+    for k in keys:
+        got = finals[0][k].reshape(E, -1)[:sub]
+        want = o.state[k].reshape(sub, -1)
+        assert got.tobytes() == want.tobytes(), k
+    return finals[0]
+
+
+def test_full_size_default_maps_4096():
+    """BASELINE configs[1] as the bench runs it: 4096 envs, one scenario seed each, the reference's DEFAULT block
+    distribution (ramps, intersections, roundabouts: the non-staged kernel variant), 240 beams, density 0.1."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    E = 4096
+    mk = lambda n: make_config(dict(num_envs=n, num_scenarios=E, map=3, traffic_density=0.1, horizon=100, mover_capacity=24))
+    cfg = mk(E)
+    host = HostScene(cfg)
+    assert host.world.arrays["lane_off"][1:].max() - 0 > 64 and int(np.diff(host.world.arrays["lane_off"]).max()) > 64
+    acts = [torch.from_numpy(scripted_actions(E, 1, t)).cuda() for t in range(130)]
+    st = _run_twice_and_sample(cfg, host, acts, mk, 48, 1)
+    obs = st["obs"]
+    assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+    assert st["nav"]["steps"].reshape(E, -1)[:, 0].max() <= 100
+
+
+def test_full_size_safe_env_8192():
+    """BASELINE configs[3]'s per-GPU shard: 8192 SafeMetaDriveEnv (accident scenes, crashes cost but do not end the
+    episode), 240 beams."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.envs.metadrive_env import BatchedSafeMetaDriveEnv
+    from metadrive_ped_amd import abi
+    E = 8192
+    mk = lambda n: make_config(dict(BatchedSafeMetaDriveEnv.SAFE_DEFAULTS, num_envs=n, num_scenarios=512, map=3, horizon=120,
+                                    mover_capacity=64))
+    cfg = mk(E)
+    host = HostScene(cfg)
+    kinds = host.state["shape0"]["flags"] & abi.KIND_MASK
+    assert (kinds == abi.KIND_CONE).sum() > 10000
+    acts = []
+    for t in range(140):
+        a = scripted_actions(E, 1, t, seed=4)
+        a[:, :, 0] *= 0.3
+        acts.append(torch.from_numpy(a).cuda())
+    st = _run_twice_and_sample(cfg, host, acts, mk, 48, 1, keys=("obs", "reward", "cost", "flags"))
+    obs = st["obs"]
+    assert np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+    fl = st["flags"].reshape(E, -1)[:, 0]
+    assert st["step_info"][:, 5].max() > 0          # total_cost accumulates somewhere
+    assert ((fl & abi.FL_CRASH_OBJECT) != 0).sum() >= 0
+
+
+def test_full_size_roundabout_1024x40():
+    """BASELINE configs[2]: 1024 MultiAgentRoundaboutEnv x 40 agents, 240 beams, respawn on."""
+    import torch
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
+    import oracle_binding as ob
+    E, A = 1024, 40
+    mk = lambda n: BatchedMultiAgentRoundaboutEnv(dict(num_envs=n, num_scenarios=E, horizon=120,
+                                                       vehicle_config=dict(lidar=dict(num_lasers=240, distance=50)))).config
+    cfg = mk(E)
+    host = HostScene(cfg)
+    assert host.A == A and host.n_beams == 240
+    acts = [torch.from_numpy(scripted_actions(E, A, t, seed=9)).cuda() for t in range(100)]
+    finals = []
+    for run in range(2):
+        eng = BatchedEngine(cfg, host=host)
+        eng.reset()
+        for a in acts:
+            eng.step(a)
+        torch.cuda.synchronize()
+        finals.append(eng.download_state())
+        del eng
+    for k in finals[0]:
+        assert finals[0][k].tobytes() == finals[1][k].tobytes(), k
+    obs = finals[0]["obs"]
+    assert obs.shape == (E * A, 19 + 240) and np.isfinite(obs).all() and (obs >= 0).all() and (obs <= 1).all()
+    assert (finals[0]["next_agent_id"] > A).sum() > E // 2       # respawns happened in most envs
+    sub = 12
+    o = ob.OracleWorld(HostScene(mk(sub)))
+    o.reset()
+    for a in acts:
+        o.step(a[:sub].cpu().numpy())
+    for k in ("obs", "reward", "flags", "agent_id"):
+        per = finals[0][k].size // E
+        assert finals[0][k].reshape(E, -1)[:sub].tobytes() == o.state[k].reshape(sub, -1).tobytes(), k
+
+
+def test_batched_lidar_sensor_plug_matches_the_oracle():
+    """BatchedLidar.perceive (the reference's Lidar.perceive signature and return value) through md_lidar_detect: cloud
+    points bit-equal to the oracle's brute-force lidar on the same shape table, detected_objects = the bodies some beam
+    hit first, a known geometric answer, beam masks."""
+    from types import SimpleNamespace
+    import oracle_binding as ob
+    from metadrive_ped_amd import abi
+    from metadrive_ped_amd.mapgen.tables import beam_table
+    from metadrive_ped_amd.sensors import BatchedLidar
+    rng = np.random.RandomState(5)
+    lidar = BatchedLidar("cuda:0")
+    ego = SimpleNamespace(position=(10.0, -3.0), heading_theta=0.3, LENGTH=4.515, WIDTH=1.852)
+    ahead = SimpleNamespace(position=(10.0 + 20.0 * np.cos(0.3), -3.0 + 20.0 * np.sin(0.3)), heading_theta=0.3, LENGTH=4.0, WIDTH=1.8)
+    cone = SimpleNamespace(position=(10.0 - 8.0 * np.sin(0.3), -3.0 + 8.0 * np.cos(0.3)), heading_theta=0.0, RADIUS=0.2)
+    far = SimpleNamespace(position=(200.0, 200.0), heading_theta=0.0, LENGTH=4.0, WIDTH=1.8)
+    cloud, found = lidar.perceive(ego, [ego, ahead, cone, far], num_lasers=240, distance=50)
+    assert len(cloud) == 240 and found == {ahead, cone}
+    assert abs(cloud[0] - (20.0 - 2.0) / 50.0) < 1e-4                 # beam 0 along the heading hits the rear of `ahead`
+    assert abs(cloud[60] - (8.0 - 0.2) / 50.0) < 1e-4                 # beam 60 = 90 deg to the left hits the cone
+    assert cloud[120] == 1.0
+    # a batch of random worlds against the oracle on the very same shape table
+    E, M, B = 16, 12, 120
+    vehicles, worlds = [], []
+    for e in range(E):
+        v = SimpleNamespace(position=tuple(rng.uniform(-20, 20, 2)), heading_theta=float(rng.uniform(-3, 3)), LENGTH=4.5, WIDTH=1.85)
+        objs = [SimpleNamespace(position=tuple(np.asarray(v.position) + rng.uniform(-45, 45, 2)), heading_theta=float(rng.uniform(-3, 3)),
+                                LENGTH=float(rng.uniform(3.5, 6)), WIDTH=float(rng.uniform(1.6, 2.1))) for _ in range(M)]
+        vehicles.append(v)
+        worlds.append([v] + objs)
+    mask = [rng.rand(B) < 0.7 for _ in range(E)]
+    clouds, sets = lidar.perceive_batch(vehicles, worlds, B, 50.0, detector_mask=mask)
+    cap = M + 1
+    shape = np.zeros((E, cap), dtype=abi.SHAPE_DT)
+    for e in range(E):
+        for j, o in enumerate(worlds[e]):
+            shape[e, j] = (o.position[0], o.position[1], np.cos(o.heading_theta), np.sin(o.heading_theta), o.LENGTH / 2, o.WIDTH / 2,
+                           abi.KIND_VEHICLE | abi.F_ALIVE, -1)
+    want = ob.lidar_raw(shape.reshape(-1), beam_table(B), E, cap, B, 50.0)
+    for e in range(E):
+        w_e = np.where(mask[e], want[e], np.float32(1.0))
+        assert np.asarray(clouds[e], np.float32).tobytes() == w_e.astype(np.float32).tobytes()
+        assert all(o in worlds[e][1:] for o in sets[e])
+    assert any(len(s_) > 0 for s_ in sets)
