@@ -1826,7 +1826,7 @@ __device__ __forceinline__ int poly_argmin_wave(const MdPoly& p, float px, float
     float m = bd;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
-    return wave_min_i(bi, bd == m, 0);
+    return wave_min_i(bi, bd == m, 0x7fffffff);
 }
 
 // crossing number of the ray from (px, py) over the polygon's edges, lanes = edges: odd = inside (md_point_in_polygon)

@@ -466,11 +466,14 @@ def test_batched_lidar_sensor_plug_matches_the_oracle():
     """BatchedLidar.perceive (the reference's Lidar.perceive signature and return value) through md_lidar_detect: cloud
     points bit-equal to the oracle's brute-force lidar on the same shape table, detected_objects = the bodies some beam
     hit first, a known geometric answer, beam masks."""
-    from types import SimpleNamespace
     import oracle_binding as ob
     from metadrive_ped_amd import abi
     from metadrive_ped_amd.mapgen.tables import beam_table
     from metadrive_ped_amd.sensors import BatchedLidar
+
+    class SimpleNamespace:          # hashable by identity, like the reference's objects
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
     rng = np.random.RandomState(5)
     lidar = BatchedLidar("cuda:0")
     ego = SimpleNamespace(position=(10.0, -3.0), heading_theta=0.3, LENGTH=4.515, WIDTH=1.852)
