@@ -54,6 +54,7 @@ extern "C" {
 #define MD_KIND_BARRIER 4     /* box 0.3x2.0  component/static_object/traffic_object.py:130-177  */
 #define MD_KIND_PEDESTRIAN 5  /* circle r=.35 component/traffic_participants/pedestrian.py:12-30 */
 #define MD_KIND_CYCLIST 6     /* box          component/traffic_participants/cyclist.py:28       */
+#define MD_KIND_BUILDING 7    /* box: TollGateBuilding 10 x lane width  component/buildings/tollgate_building.py:7-27 */
 #define MD_KIND_MASK 0xF
 #define MD_F_ALIVE 0x10       /* present in the world this step                                 */
 #define MD_F_AGENT 0x20       /* slot is a controlled agent                                     */

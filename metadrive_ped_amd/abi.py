@@ -17,7 +17,7 @@ MD_ROUTE_LEN = 48
 MD_IDM_RAND = 8
 
 # mover kinds / flags
-KIND_NONE, KIND_VEHICLE, KIND_CONE, KIND_WARNING, KIND_BARRIER, KIND_PEDESTRIAN, KIND_CYCLIST = range(7)
+KIND_NONE, KIND_VEHICLE, KIND_CONE, KIND_WARNING, KIND_BARRIER, KIND_PEDESTRIAN, KIND_CYCLIST, KIND_BUILDING = range(8)
 KIND_MASK = 0xF
 F_ALIVE, F_AGENT, F_PENDING, F_STATIC, F_CRASHED_ONCE, F_SPAWNED = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 

@@ -538,6 +538,7 @@ __device__ __forceinline__ void contacts_vehicle(const MdWorld& w, const MdState
         if (k == MD_KIND_VEHICLE) fl |= MD_FL_CRASH_VEHICLE;
         else if (k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_BARRIER) fl |= MD_FL_CRASH_OBJECT;
         else if (k == MD_KIND_PEDESTRIAN || k == MD_KIND_CYCLIST) fl |= MD_FL_CRASH_HUMAN;
+        else if (k == MD_KIND_BUILDING) fl |= MD_FL_CRASH_BUILDING;
     }
     // static quads through the grid: cells under the chassis AABB (+ margin)
     const int m = w.env_map[e];

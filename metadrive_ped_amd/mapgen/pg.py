@@ -1114,7 +1114,41 @@ class ParkingLot(Block):
         return ok
 
 
-BLOCK_CLASSES.update(Merge=Merge, Split=Split, Bidirection=Bidirection, ParkingLot=ParkingLot)
+class TollGate(Block):
+    """A straight stretch with toll booths (pgblock/tollgate.py:11-75): every lane line continuous, and on every ODD lane
+    of both directions a TollGateBuilding -- a solid box BUILDING_LENGTH long and one lane wide, centred on the lane
+    (buildings/tollgate_building.py:7-27) -- so only the even lanes are passable.  `buildings`: (lane, position, heading)."""
+    ID = "$"
+    SPACE = BlockParameterSpace.BOTTLENECK
+    BUILDING_LENGTH = 10.0
+    SPEED_LIMIT = 3.0   # m/s: stored on the lanes; nothing on the step path reads a lane's speed limit
+
+    def plug(self):
+        length = self.config[Parameter.length]
+        new_lane = self.basic_lane.extended(length, [LINE_CONTINUOUS, LINE_SIDE])
+        start = self.pre_socket.positive[1]
+        road = (start, self.node())
+        kw = dict(center_line_color=COLOR_YELLOW, center_line_type=LINE_CONTINUOUS, inner_lane_line_type=LINE_CONTINUOUS,
+                  side_lane_line_type=LINE_SIDE)
+        ok = create_road_from(new_lane, self.lane_num, road, self.net, self.global_net, **kw)
+        ok = create_adverse_road(road, self.net, self.global_net, **kw) and ok
+        self.add_socket(Socket(road, negate_road(*road)))
+        self.buildings = []
+        for r in (road, negate_road(*road)):
+            for idx, lane in enumerate(self.net.lanes(*r)):
+                if idx % 2 == 1:
+                    self.buildings.append((lane, lane.position(lane.length / 2, 0), lane.heading_theta_at(0)))
+        # every spawn_object draws a seed from the ENGINE's stream (engine.generate_seed), also in trials the BIG search
+        # throws away: the scene builder replays that many draws before it seeds agents and traffic
+        self.global_net.building_spawns = getattr(self.global_net, "building_spawns", 0) + len(self.buildings)
+        return ok
+
+    def clear(self):
+        super().clear()
+        self.buildings = []
+
+
+BLOCK_CLASSES.update(Merge=Merge, Split=Split, Bidirection=Bidirection, ParkingLot=ParkingLot, TollGate=TollGate)
 
 
 class MABottleneckMap:

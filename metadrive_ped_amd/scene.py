@@ -95,6 +95,13 @@ class EnvScene:
         self._next_prop_slot = cap - 1       # props fill the slot array from the top down
         self.accident_lanes = []
 
+        # ---- toll booths: spawned by their block while the map is built (PGMapManager, PRIORITY 0) ----
+        for _ in range(getattr(pg_map.net, "building_spawns", 0)):
+            engine.generate_seed()
+        for block in pg_map.blocks:
+            for lane, pos, heading in getattr(block, "buildings", ()):
+                self._place_building(lane, pos, heading, block.BUILDING_LENGTH)
+
         # ---- static props (TrafficObjectManager, PRIORITY 9: before agents and traffic) ----
         if abs(cfg.get("accident_prob", 0.0)) >= 1e-2:
             self._object_scenes(cfg, engine, object_mgr, traffic_mgr)
@@ -328,6 +335,21 @@ class EnvScene:
         else:
             sh["hl"], sh["hw"] = 0.15, 1.0
         sh["flags"] = kind | abi.F_ALIVE | abi.F_STATIC
+        sh["aux"] = self.tables.lane_id[tuple(lane.index)]
+        self.dyn[slot]["heading"] = heading
+        return slot
+
+    def _place_building(self, lane, pos, heading, length):
+        """TollGateBuilding (component/buildings/tollgate_building.py:7-27): a solid box `length` x the lane's width; a
+        BaseStaticObject with `.lane`, so the IDM of the traffic on that lane queues up behind it; crashing into it raises
+        crash_building (base_vehicle.py:737-738), which always ends the episode (envs/metadrive_env.py:170-175)."""
+        slot = self._take_prop_slot()
+        sh = self.shape[slot]
+        heading = wrap_to_pi(heading)
+        sh["cx"], sh["cy"] = pos
+        sh["c"], sh["s"] = math.cos(heading), math.sin(heading)
+        sh["hl"], sh["hw"] = length / 2.0, lane.width / 2.0
+        sh["flags"] = abi.KIND_BUILDING | abi.F_ALIVE | abi.F_STATIC
         sh["aux"] = self.tables.lane_id[tuple(lane.index)]
         self.dyn[slot]["heading"] = heading
         return slot

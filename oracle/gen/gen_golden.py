@@ -1082,10 +1082,28 @@ def section_pg_maps_v5():
     _pg_maps_cases("pg_maps_v5.json", specs)
 
 
-def _pg_maps_cases(fname, specs):
+def section_pg_maps_v6():
+    """Block sequences with the TollGate block '$' (zero probability in the default distribution): topology, line types, and
+    the toll booths the block spawns -- lane, position, heading of every TollGateBuilding, in spawn order (the engine's
+    spawn_object is recorded, not executed: it needs Bullet)."""
+    specs = [(520, 3, 3.5, 50, "block_sequence", "$"), (521, 3, 3.5, 50, "block_sequence", "S$S"),
+             (522, 2, 3.0, 50, "block_sequence", "$C"), (523, 4, 3.5, 50, "block_sequence", "C$"),
+             (524, 3, 3.5, 50, "block_sequence", "$$")]
+    _pg_maps_cases("pg_maps_v6.json", specs, record_buildings=True)
+
+
+def _pg_maps_cases(fname, specs, record_buildings=False):
     from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
     cases = []
     for seed, lane_num, lane_width, exit_length, method, parameter in specs:
+        spawned = []
+        if record_buildings:
+            import metadrive.component.pgblock.tollgate as tg
+
+            def spawn_object(cls, lane=None, position=None, heading_theta=None, **kw):
+                spawned.append((cls.__name__, lane, [float(position[0]), float(position[1])], float(heading_theta)))
+                return MagicMock()
+            tg.get_engine = lambda: MagicMock(spawn_object=spawn_object)
         big, net = build_reference_map(seed, lane_num, lane_width, exit_length, method, parameter, PGBlockDistConfig)
         for f, td in net.graph.items():
             for t, lanes in td.items():
@@ -1103,8 +1121,13 @@ def _pg_maps_cases(fname, specs):
         spawn = []
         for b in big.blocks[1:]:
             spawn.append([[list(l.index) for l in lanes] for lanes in b.get_intermediate_spawn_lanes()])
-        cases.append(dict(seed=seed, lane_num=lane_num, lane_width=lane_width, exit_length=exit_length,
-                          method=method, parameter=parameter, blocks=blocks, roads=roads, spawn_lanes=spawn))
+        case = dict(seed=seed, lane_num=lane_num, lane_width=lane_width, exit_length=exit_length,
+                    method=method, parameter=parameter, blocks=blocks, roads=roads, spawn_lanes=spawn)
+        if record_buildings:
+            from metadrive.component.buildings.tollgate_building import TollGateBuilding
+            case["buildings"] = [dict(cls=c, lane=list(l.index), position=p, heading=h, width=float(l.width),
+                                      length=float(TollGateBuilding.BUILDING_LENGTH)) for c, l, p, h in spawned]
+        cases.append(case)
     dump(fname, dict(cases=cases))
 
 
@@ -1147,7 +1170,7 @@ def section_scenario_export():
     dump("scenario_export.json", dict(accepted_by_reference_sanity_check=True, scenarios=out))
 
 
-SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
+SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":

@@ -224,6 +224,7 @@ static void contacts_mover(const MdWorld* w, const MdState* s, const MdConfig* c
         if (k == MD_KIND_VEHICLE) fl |= MD_FL_CRASH_VEHICLE;
         else if (k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_BARRIER) fl |= MD_FL_CRASH_OBJECT;
         else if (k == MD_KIND_PEDESTRIAN || k == MD_KIND_CYCLIST) fl |= MD_FL_CRASH_HUMAN;
+        else if (k == MD_KIND_BUILDING) fl |= MD_FL_CRASH_BUILDING; /* base_vehicle.py:737-738, collision_callback.py:40-41 */
     }
     int m = w->env_map[e];
     for (int q = w->quad_off[m]; q < w->quad_off[m + 1]; ++q) {
