@@ -108,6 +108,7 @@ BATCH_DEFAULT_CONFIG = dict(
     auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
     device="cuda:0",
     build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
+    traffic_epoch=0,        # random_traffic=True: bumped by every explicit env.reset(); part of the traffic stream's seed
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
     step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same
                             # results bit for bit; a machine-mapping choice)
@@ -135,7 +136,7 @@ COSMETIC_VEHICLE_CONFIG = dict(show_navi_mark=True, show_dest_mark=False, show_l
                                show_lane_line_detector=False)
 
 # Behavioural keys of subsystems that are not built: accepted at the reference's default, rejected loudly otherwise.
-_OFF_ONLY = dict(use_render=False, image_observation=False, random_traffic=False, manual_control=False, agent_observation=None,
+_OFF_ONLY = dict(use_render=False, image_observation=False, manual_control=False, agent_observation=None,
                  sensors=None, record_episode=False, replay_episode=None, only_reset_when_replay=False, use_AI_protector=False,
                  save_level=0.5)
 _OFF_ONLY_VEHICLE = dict(no_wheel_friction=False, navigation_module=None, spawn_position_heading=None, light=False)

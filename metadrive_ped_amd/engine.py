@@ -133,6 +133,7 @@ class HostScene:
                          random_lane_num=cfg["random_lane_num"], random_agent_model=cfg["random_agent_model"],
                          random_dynamics=cfg["random_dynamics"], initial_agents=cfg["initial_agents"],
                          agent_policy=cfg["agent_policy"], spawn_roads=cfg["spawn_roads"],
+                         random_traffic=cfg["random_traffic"], traffic_epoch=cfg.get("traffic_epoch", 0),
                          destination=cfg["vehicle_config"]["destination"])
         self.spawn = None
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]

@@ -103,6 +103,13 @@ class BatchedMetaDriveEnv:
                 self.engine.cfg = self.config
                 self.engine.build()
             self.config["start_seed"] = int(seed)
+        if self.config["random_traffic"] and self.engine is not None:
+            # new traffic for the coming episodes (PGTrafficManager with random_traffic: the stream is not re-seeded at
+            # reset); episodes that auto-reset in between restart from the latest draw
+            self.config["traffic_epoch"] = int(self.config.get("traffic_epoch", 0)) + 1
+            self.engine.host = None
+            self.engine.cfg = self.config
+            self.engine.build()
         self.lazy_init()
         self.engine.reset()
         return self._obs(), self._info()

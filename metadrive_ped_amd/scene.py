@@ -90,6 +90,12 @@ class EnvScene:
         object_mgr = Randomizable(seed)
         agent_mgr = Randomizable(seed)
         traffic_mgr = Randomizable(seed)
+        if cfg.get("random_traffic"):
+            # random_traffic=True: PGTrafficManager.seed() skips the re-seeding at reset (manager/traffic_manager.py:335-337),
+            # so the traffic stream runs on from wherever it is and every episode gets other traffic.  The reference's
+            # stream starts unseeded; here it is keyed by (scenario seed, how many resets the env has seen): the traffic
+            # differs from reset to reset and the run as a whole stays reproducible.
+            traffic_mgr = Randomizable((seed * 1000003 + 7919 * (int(cfg.get("traffic_epoch", 0)) + 1)) % (2 ** 31))
         dt = cfg["physics_world_step_size"]
         self._dt = dt
         self._next_prop_slot = cap - 1       # props fill the slot array from the top down

@@ -262,6 +262,8 @@ def test_random_lanes_and_inverse_traffic_rollout_parity():
     # ParkingLot block on a one-lane-per-direction road: ~150 short roads, right-angle bends of radius 4 m; reverse allowed
     ("parking_lot", dict(num_envs=6, num_scenarios=6, start_seed=421, map="SPS", map_config=dict(lane_num=1), traffic_density=0.2,
                          vehicle_config=dict(enable_reverse=True)), 160),
+    # TollGate block: toll booths (buildings) on the odd lanes; the traffic queues behind them, an agent that hits one ends
+    ("toll_gate", dict(num_envs=12, num_scenarios=12, start_seed=521, map="S$S", traffic_density=0.2, random_spawn_lane_index=True), 200),
     # VaryingDynamicsEnv: extreme agent dynamics (80 deg steering, 300 kg / 3000 N, friction 0.1 ...)
     ("varying_dynamics", dict(num_envs=24, num_scenarios=24, vehicle_config=dict(vehicle_model="varying_dynamics"),
                               random_dynamics=dict(max_engine_force=(100, 3000), max_brake_force=(20, 600),

@@ -369,3 +369,19 @@ def test_examples_and_tools_compile():
     for f in files:
         with open(f) as fh:
             ast.parse(fh.read(), filename=f)
+
+
+def test_random_traffic_redraws_the_traffic_per_reset(cs_dist):
+    """random_traffic=True (manager/traffic_manager.py:335-337: the traffic manager is not re-seeded at reset): another
+    traffic layout for every reset epoch, the map and the agent unchanged; off: identical scenes."""
+    from helpers import make_cfg
+    from metadrive_ped_amd.engine import HostScene
+    a = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6, traffic_density=0.3, random_traffic=True, traffic_epoch=0))
+    b = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6, traffic_density=0.3, random_traffic=True, traffic_epoch=1))
+    c = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6, traffic_density=0.3))
+    d = HostScene(make_cfg(cs_dist, num_envs=6, num_scenarios=6, traffic_density=0.3))
+    assert c.state["shape0"].tobytes() == d.state["shape0"].tobytes()
+    sa, sb = a.state["shape0"].reshape(6, -1), b.state["shape0"].reshape(6, -1)
+    assert sa[:, 0].tobytes() == sb[:, 0].tobytes()                       # the agents
+    assert sa[:, 1:].tobytes() != sb[:, 1:].tobytes()                     # the traffic
+    assert a.world.arrays["lanes"].tobytes() == b.world.arrays["lanes"].tobytes()

@@ -674,3 +674,39 @@ def test_nav_road_cache_follows_the_route_cursors(cs_dist):
                 assert (nav["road1"][live] == rr[rows, nav["ck1"]][live]).all()
                 advanced += int((nav["ck0"][live] > 0).sum())
         assert advanced > 0
+
+
+def test_toll_gate_booths_block_the_odd_lanes():
+    """TollGate block (pgblock/tollgate.py, buildings/tollgate_building.py): a booth on every odd lane of both directions;
+    an agent that keeps lane 1 runs into it -> crash_building, which terminates whatever the crash_*_done switches say
+    (envs/metadrive_env.py:170-175); on lane 0 it passes; the lidar sees the booth; traffic on lane 1 stops behind it."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import HostScene
+    out = {}
+    for lane_idx in (0, 1):
+        cfg = make_config(dict(num_envs=1, num_scenarios=1, start_seed=521, map="$S", traffic_density=0.0, auto_reset=False,
+                               crash_vehicle_done=False, crash_object_done=False, horizon=2000, random_spawn_lane_index=False,
+                               agent_configs=dict(default_agent=dict(spawn_lane_index=(">", ">>", lane_idx)))))
+        h = HostScene(cfg)
+        kinds = h.state["shape0"]["flags"] & abi.KIND_MASK
+        booths = np.nonzero(kinds == abi.KIND_BUILDING)[0]
+        assert len(booths) == 2          # lane 1 of the positive and of the negative road (3 lanes each)
+        assert np.allclose(h.state["shape0"]["hl"][booths], 5.0) and np.allclose(h.state["shape0"]["hw"][booths], 1.75)
+        o = ob.OracleWorld(h)
+        o.reset()
+        saw, hit, done = False, False, False
+        o_mid = 2
+        for t in range(260):
+            ob_ = o.obs[0]
+            steer = float(np.clip(4.0 * (ob_[o_mid] - 0.5) + 2.0 * (ob_[8] - 0.5), -1, 1))
+            o.step(np.array([[[steer, 0.5 if ob_[o_mid + 1] < 0.3 else 0.0]]], np.float32))
+            fl = int(o.state["flags"][0])
+            saw |= bool(o.obs[0][19] < 0.5)                     # beam 0: something within 25 m straight ahead
+            hit |= bool(fl & abi.FL_CRASH_BUILDING)
+            done |= bool(fl & abi.FL_TERMINATED)
+            if done:
+                break
+        out[lane_idx] = (saw, hit, done, float(o.state["shape"]["cx"][0]))
+    assert out[1][0] and out[1][1] and out[1][2]                # lane 1: sees it, hits it, episode over
+    assert not out[0][1]                                        # lane 0: no booth
+    assert out[0][3] > out[1][3]                                # ... and it got further
