@@ -305,6 +305,9 @@ typedef struct MdState {
     uint64_t* detected;        /* [n_envs * agents_per_env][2] bit j of the 128-bit set: some beam of the agent's lidar
                                   hit the mover in slot j first -- the `detected_objects` half of Lidar.perceive's
                                   return value (component/sensors/lidar.py:49-73); written by md_step           */
+    /* optional: work space of the phase-per-launch step (MdConfig.step_kernel 2): [2 * N + 4 * n_envs] uint32 owned by the
+     * caller like every other array; contents are meaningless between calls.  NULL = that mode is not available. */
+    uint32_t* scratch;
 } MdState;
 
 typedef struct MdConfig {

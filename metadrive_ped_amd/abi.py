@@ -98,6 +98,7 @@ class MdState(C.Structure):
         ("track_shape", P),
         ("track_dyn", P),
         ("detected", P),
+        ("scratch", P),
     ]
 
 

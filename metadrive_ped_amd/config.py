@@ -239,8 +239,8 @@ def make_config(user=None):
         raise ValueError("spawn_roads is a multi-agent env option")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
-    if cfg["step_kernel"] not in ("wg", "wave"):
-        raise ValueError("step_kernel must be 'wg' or 'wave', got {!r}".format(cfg["step_kernel"]))
+    if cfg["step_kernel"] not in ("wg", "wave", "pm"):
+        raise ValueError("step_kernel must be 'wg', 'wave' or 'pm', got {!r}".format(cfg["step_kernel"]))
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
         raise ValueError("mover_capacity must be 0 (auto) or in [num_agents, 128]")
     return cfg

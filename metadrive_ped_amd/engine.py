@@ -229,6 +229,7 @@ class HostScene:
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
         st["need_reset"] = np.ones(E, np.int32)
+        st["scratch"] = np.zeros(2 * N + 4 * E, np.uint32)      # work space of the phase-per-launch step kernels
         self.traffic_respawns = "spawn_off" in self.world.arrays and not cfg["is_multi_agent"]
         if cfg["is_multi_agent"] or self.traffic_respawns:
             # respawns (agents in MARL, traffic in the respawn / hybrid modes) rewrite routes and draw random numbers
@@ -250,7 +251,7 @@ class HostScene:
         self.md_config.random_agent_model = int(bool(cfg["random_agent_model"]))
         self.md_config.agent_idm = int(cfg["agent_policy"] == "IDMPolicy")
         self.md_config.enable_reverse = int(bool(cfg["vehicle_config"]["enable_reverse"]))
-        self.md_config.step_kernel = {"wg": 0, "wave": 1}[cfg.get("step_kernel", "wg")]
+        self.md_config.step_kernel = {"wg": 0, "wave": 1, "pm": 2}[cfg.get("step_kernel", "wg")]
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None

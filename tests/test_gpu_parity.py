@@ -8,7 +8,7 @@ from helpers import assert_state_equal, make_cfg, scripted_actions
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["wg", "wave"])
+@pytest.fixture(autouse=True, params=["wg", "wave", "pm"])
 def step_kernel(request, monkeypatch):
     """Every parity case runs with both md_step kernels of the single-agent envs (MdConfig.step_kernel): one 4-wave
     workgroup per env, and one wave per env.  (Multi-agent configs always take the workgroup kernel.)"""
