@@ -8,15 +8,6 @@ from helpers import assert_state_equal, make_cfg, scripted_actions
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["wg", "wave", "pm"])
-def step_kernel(request, monkeypatch):
-    """Every parity case runs with both md_step kernels of the single-agent envs (MdConfig.step_kernel): one 4-wave
-    workgroup per env, and one wave per env.  (Multi-agent configs always take the workgroup kernel.)"""
-    from metadrive_ped_amd import config
-    monkeypatch.setitem(config.BATCH_DEFAULT_CONFIG, "step_kernel", request.param)
-    return request.param
-
-
 def _engine_and_oracle(cs_dist, **kw):
     import torch
     from metadrive_ped_amd.engine import BatchedEngine
@@ -436,3 +427,38 @@ def test_agent_policy_idm_rollout_parity(mode):
     assert_state_equal(eng.download_state(), orc.state, where="idm agent final")
     sp = orc.state["dyn"]["speed"].reshape(E, -1)[:, 0]
     assert (sp > 1.0).sum() > E // 2, "the agents are not driving"
+
+
+@pytest.mark.parametrize("step_kernel", ["wave", "pm"])
+@pytest.mark.parametrize("name,cfg_kw,steps", [
+    ("default_maps", dict(num_envs=48, num_scenarios=48, horizon=200), 260),
+    ("safe", dict(num_envs=32, num_scenarios=32, accident_prob=0.8, traffic_density=0.05, crash_vehicle_done=False,
+                  crash_object_done=False, horizon=200), 240),
+    ("dense_many_awake", dict(num_envs=12, num_scenarios=12, map=5, traffic_density=0.5, horizon=300), 300),
+    ("hybrid_idm_agent", dict(num_envs=16, num_scenarios=16, traffic_density=0.2, traffic_mode="hybrid", agent_policy="IDMPolicy",
+                              horizon=250), 300),
+])
+def test_alternative_step_kernels_parity(step_kernel, name, cfg_kw, steps):
+    """The other machine mappings of md_step for single-agent envs (MdConfig.step_kernel): "wave" = one wave per env,
+    "pm" = one launch per phase with vehicles as work items (lean trigger-mode path; other configs fall back to the
+    default kernel).  Same wave-level device functions, same results: bit-exact against the oracle, auto-resets included."""
+    import torch
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    import oracle_binding as ob
+    cfg = make_config(dict(cfg_kw, step_kernel=step_kernel))
+    eng = BatchedEngine(cfg)
+    E = eng.E
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="%s/%s reset" % (step_kernel, name))
+    for t in range(steps):
+        a = scripted_actions(E, 1, t, seed=31)
+        a[:, :, 0] *= 0.4
+        act = None if cfg["agent_policy"] == "IDMPolicy" else torch.from_numpy(a).to(eng.device)
+        eng.step(act)
+        orc.step(None if act is None else a)
+        if t % 40 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="%s/%s step %d" % (step_kernel, name, t))
+    assert_state_equal(eng.download_state(), orc.state, where="%s/%s final" % (step_kernel, name))
