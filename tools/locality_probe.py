@@ -12,9 +12,9 @@ sys.path.insert(0, ROOT)
 def main():
     from metadrive_ped_amd.config import make_config
     from metadrive_ped_amd.engine import BatchedEngine, HostScene
-    E = 4096
+    E = int(os.environ.get("ENVS", "4096"))
     sizes = [int(x) for x in os.environ.get("MAPS", "1,8,64,512,4096").split(",")]
-    cfgs = {S: make_config(dict(num_envs=E, num_scenarios=S, horizon=1000, mover_capacity=32)) for S in sizes}
+    cfgs = {S: make_config(dict(num_envs=E, num_scenarios=min(S, E), horizon=1000, mover_capacity=32)) for S in sizes}
     hosts = {S: HostScene(cfgs[S]) for S in sizes}     # host-side generation (fork pool) before the GPU is touched
     import torch
     g = torch.Generator().manual_seed(0)
