@@ -364,7 +364,7 @@ typedef struct MdConfig {
     int32_t reactive_traffic, filter_overlapping_car, no_static_vehicles;
     int32_t allowed_more_steps;/* 0 = None                                                       */
     int32_t scenario_length;   /* frames of the scenarios (data_manager.current_scenario_length)  */
-    int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env.
+    int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env, 2 = one launch per phase.
                                 * Same results bit for bit; a machine-mapping choice, no reference counterpart. */
 } MdConfig;
 

@@ -11,10 +11,12 @@ RandomState streams in the same order:
                (base_class/base_runnable.py:22-29,82-96; block/base_block.py:95-130)
   backtracking up to MAX_TRIAL = 5 re-samples per block, then pop one block (BIG.py:83-165)
 
-Block types built so far: FirstPGBlock "I", Straight "S", Curve "C"
-(pgblock/first_block.py:13-108, straight.py:9-55, curve.py:10-90).  The other types of
-BLOCK_TYPE_DISTRIBUTION_V2 (ramps, intersections, roundabout) are not built yet: sampling one raises
-NotImplementedError naming it, so a config never silently changes the map distribution.
+Block types built: FirstPGBlock "I", Straight "S", Curve "C", Roundabout "O", StdInterSection "X", StdTInterSection "T",
+InRampOnStraight "r", OutRampOnStraight "R" -- the whole default BLOCK_TYPE_DISTRIBUTION_V2 -- and Merge "y", Split "Y",
+Bidirection "B", ParkingLot "P", TollGate "$" (pgblock/first_block.py, straight.py, curve.py, roundabout.py,
+intersection.py, std_intersection.py, t_intersection.py, std_t_intersection.py, ramp.py, bottleneck.py, bidirection.py,
+parking_lot.py, tollgate.py).  InFork / OutFork are not built (InFork raises in the reference itself, pgblock/fork.py:28):
+sampling one raises NotImplementedError naming it, so a config never silently changes the map distribution.
 
 Road-crossing check: check_lane_on_road (utils/pg/utils.py:36-71) with the bounding-box pre-filter
 of get_lanes_bounding_box (:74-147).

@@ -36,8 +36,13 @@ def _shape_of(obj):
 class BatchedLidar:
     DEFAULT_HEIGHT = 1.2          # Lidar.DEFAULT_HEIGHT (lidar.py:19): beams are horizontal at this height; 2-D here
 
-    def __init__(self, device="cuda:0"):
+    def __init__(self, *args, device="cuda:0"):
+        """`BatchedLidar("cuda:0")`, or -- the way the reference's engine builds its sensors, `cls(*args, engine)`
+        (engine/core/engine_core.py:523-534) -- `BatchedLidar(engine)` / `BatchedLidar("cuda:1", engine)`"""
         import torch
+        for a in args:
+            if isinstance(a, (str, torch.device)):
+                device = a
         from metadrive_ped_amd import _lib
         self.torch = torch
         self.lib = _lib.load()
