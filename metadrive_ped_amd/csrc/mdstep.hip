@@ -51,9 +51,21 @@ thread_local char g_err[256] = "ok";
 // values go to a buffer of their own that no kernel code reads; the production build contains none.
 #ifdef MD_STAMP
 __device__ unsigned long long* g_stamp_buf = nullptr;
+__device__ const int* g_env_order = nullptr;
+// slots 0..11: shader-cycle stamps; 12 / 13: s_memrealtime (100 MHz, one time base for the whole chip) at the first / last
+// stamp; 14: HW_ID | XCC_ID << 32 (which CU the workgroup ran on) -- tools/timeline_probe.py rebuilds the occupancy timeline
 #define MD_STAMP_AT(i)                                                                         \
     do {                                                                                       \
-        if (threadIdx.x == 0 && g_stamp_buf) g_stamp_buf[(size_t)blockIdx.x * 32 + (i)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && g_stamp_buf) {                                                 \
+            unsigned long long* sb_ = g_stamp_buf + (size_t)blockIdx.x * 32;                   \
+            sb_[(i)] = __builtin_readcyclecounter();                                           \
+            if ((i) == 0) {                                                                    \
+                sb_[12] = __builtin_amdgcn_s_memrealtime();                                    \
+                sb_[14] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |               \
+                          ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);        \
+            }                                                                                  \
+            if ((i) == 11) sb_[13] = __builtin_amdgcn_s_memrealtime();                         \
+        }                                                                                      \
     } while (0)
 #define MD_FINE_STAMP(cond, i)                                                                 \
     do {                                                                                       \
@@ -1089,12 +1101,15 @@ constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot
 #ifndef MD_ENV_BLOCK
 #define MD_ENV_BLOCK 256
 #endif
+#ifndef MD_ENV_WAVES_EU
+#define MD_ENV_WAVES_EU 7
+#endif
 // MULTI: multi-agent envs (lifecycle phase, reference order of the IDM); single-agent envs plan the traffic ahead.
 // Register budget: the single-agent fused step is compiled for 7 waves per SIMD (72 VGPRs / 96 SGPRs): measured
 // 123 us against 133 us at the compiler's own choice (6 waves) and 131 us at 8 (64 VGPRs, more spills) --
 // the step is latency-bound, so resident workgroups per CU count.  Other instantiations keep the default.
 template <int PH, bool RESPAWN, bool MULTI>
-constexpr int env_waves_per_eu() { return (PH == PH_ALL && !RESPAWN && !MULTI && MD_ENV_BLOCK >= 128) ? 7 : 0; }
+constexpr int env_waves_per_eu() { return (PH == PH_ALL && !RESPAWN && !MULTI && MD_ENV_BLOCK >= 128) ? MD_ENV_WAVES_EU : 0; }
 
 template <int PH, bool STAGE_MAP, bool RESPAWN = false, bool MULTI = false>
 __global__ __launch_bounds__(MD_ENV_BLOCK)
@@ -1104,8 +1119,12 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                                                   int lidar_stride, int lidar_offset) {
     constexpr int kBlock = MD_ENV_BLOCK;
     constexpr int kWaves = kBlock / 64;
+    if ((int)blockIdx.x >= c.n_envs) return;
+#ifdef MD_STAMP
+    const int e = g_env_order ? g_env_order[blockIdx.x] : (int)blockIdx.x;   // diagnostic: launch-order experiments
+#else
     const int e = blockIdx.x;
-    if (e >= c.n_envs) return;
+#endif
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int cap = c.cap;
@@ -2591,6 +2610,11 @@ __attribute__((visibility("default"))) const char* md_last_error(void) { return 
 __attribute__((visibility("default"))) int md_debug_set_stamp_buffer(void* dev_ptr) {
     unsigned long long* p = (unsigned long long*)dev_ptr;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? MD_OK : MD_ELAUNCH;
+}
+// diagnostic build only: a permutation of the envs (workgroup b steps env order[b]), or NULL
+__attribute__((visibility("default"))) int md_debug_set_env_order(const void* dev_ptr) {
+    const int* p = (const int*)dev_ptr;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_env_order), &p, sizeof(p)) == hipSuccess ? MD_OK : MD_ELAUNCH;
 }
 #endif
 
