@@ -66,7 +66,12 @@ MD_HD int md_obs_mid(const MdConfig* c) { return md_obs_base(c) + (c->n_side > 0
 MD_HD int md_obs_ll(const MdConfig* c) { return md_obs_mid(c) + 6; }                             /* lane-line block  */
 MD_HD int md_obs_navi(const MdConfig* c) { return md_obs_ll(c) + (c->n_lane_line > 0 ? c->n_lane_line : 1); }
 /* "others" block: num_others nearest detected vehicles x 4 dims (+4 with add_others_navi), between navi and cloud */
-MD_HD int md_obs_others(const MdConfig* c) { return md_obs_navi(c) + 10; }
+/* TollGateStateObservation (envs/marl_envs/marl_tollgate.py:62-74) drops the navigation dims; TollGateObservation (:77-110)
+ * appends [in toll block, stayed long enough] after the lidar cloud */
+MD_HD int md_is_tollgate(const MdConfig* c) { return c->is_multi_agent && c->ma_kind == MD_MA_TOLLGATE; }
+MD_HD int md_navi_dims(const MdConfig* c) { return md_is_tollgate(c) ? 0 : 10; }
+MD_HD int md_obs_tail(const MdConfig* c) { return md_is_tollgate(c) ? 2 : 0; }
+MD_HD int md_obs_others(const MdConfig* c) { return md_obs_navi(c) + md_navi_dims(c); }
 MD_HD int md_others_width(const MdConfig* c) { return c->add_others_navi ? 8 : 4; }
 MD_HD int md_obs_lidar(const MdConfig* c) { return md_obs_others(c) + (c->num_others > 0 ? c->num_others * md_others_width(c) : 0); }
 
@@ -187,6 +192,7 @@ typedef struct MdObsCtx {
     const MdLane *lane, *ref0, *ref_last, *next0, *fin, *rl;
     float cur_w, cur_n, positive_road;
     int valid;
+    int cur_block; /* navigation.current_road.block_ID() */
 } MdObsCtx;
 
 MD_HD void md_observe_ctx(const MdLane* lanes, const MdRoad* roads, const MdState* s, int n, MdObsCtx* k) {
@@ -195,8 +201,10 @@ MD_HD void md_observe_ctx(const MdLane* lanes, const MdRoad* roads, const MdStat
     k->valid = md_drives(sh->flags) && nav->lane >= 0;
     k->lane = k->ref0 = k->ref_last = k->next0 = k->fin = k->rl = lanes;
     k->cur_w = k->cur_n = k->positive_road = 0.0f;
+    k->cur_block = 0;
     if (!k->valid) return;
     const MdRoad* cur_road = &roads[nav->road0];
+    k->cur_block = cur_road->block_kind;
     int has_next = nav->ck1 != nav->ck0;
     const MdRoad* next_road = has_next ? &roads[nav->road1] : cur_road;
     k->lane = &lanes[nav->lane];
@@ -254,8 +262,10 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     MdDyn* d = &s->dyn[n];
     MdNav* nav = &s->nav[n];
     const int o_mid = md_obs_mid(c), o_ll = md_obs_ll(c), o_navi = md_obs_navi(c);
+    const int toll = md_is_tollgate(c);
     if (!k->valid) {
         for (int i = 0; i < md_obs_lidar(c); ++i) obs[i] = 0.0f;
+        for (int i = c->obs_dim - md_obs_tail(c); i < c->obs_dim; ++i) obs[i] = 0.0f;
         s->reward[ai] = 0.0f;
         s->cost[ai] = 0.0f;
         for (int i = 0; i < 8; ++i) info[i] = 0.0f;
@@ -293,10 +303,11 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     float ls = r[2][0], llat = r[2][1];
     if (c->n_lane_line <= 0) obs[o_ll] = md_clip((llat * 2.0f / c->max_lane_width + 1.0f) / 2.0f, 0.0f, 1.0f);
     /* ---- navi (node_network_navigation.py:160-168, 243-292) ---- */
-    for (int i = 0; i < 5; ++i) {
-        obs[o_navi + i] = r[3][i];
-        obs[o_navi + 5 + i] = r[4][i];
-    }
+    if (!toll)
+        for (int i = 0; i < 5; ++i) {
+            obs[o_navi + i] = r[3][i];
+            obs[o_navi + 5 + i] = r[4][i];
+        }
 
     /* ---- arrive destination (metadrive_env.py:213-227) ---- */
     float fs = r[5][0], flat = r[5][1];
@@ -307,6 +318,11 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     if (c->out_of_route_done) out_of_road = out_of_road || (fl & MD_FL_OUT_OF_ROUTE);
     else if (c->on_continuous_line_done)
         out_of_road = out_of_road || (fl & (MD_FL_ON_YELLOW_CONT | MD_FL_ON_WHITE_CONT | MD_FL_CRASH_SIDEWALK));
+    if (toll) { /* MultiAgentTollgateEnv._is_out_of_road (marl_tollgate.py:241-247): the sidewalk, or the yellow line with
+                 * cross_yellow_line_done (carried by on_continuous_line_done); leaving the lanes alone does not count */
+        out_of_road = (fl & MD_FL_CRASH_SIDEWALK) != 0;
+        if (c->on_continuous_line_done) out_of_road = out_of_road || (fl & MD_FL_ON_YELLOW_CONT);
+    }
     if (arrive) fl |= MD_FL_ARRIVE_DEST;
     if (out_of_road) fl |= MD_FL_OUT_OF_ROAD;
 
@@ -316,8 +332,16 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     float lateral_factor = 1.0f;
     if (c->use_lateral_reward) lateral_factor = md_clip(1.0f - 2.0f * md_fabs(lateral_now) / cur_w, 0.0f, 1.0f);
     float reward = 0.0f;
-    reward += c->driving_reward * (long_now - long_last) * lateral_factor * positive_road;
-    reward += c->speed_reward * (speed_kmh / P->max_speed_kmh) * positive_road;
+    if (toll) { /* MultiAgentTollgateEnv.reward_function (marl_tollgate.py:194-239): no direction factor; inside the toll
+                 * block the speed term gives way to a penalty that REPLACES the reward while lane.speed_limit < speed [km/h] */
+        reward += c->driving_reward * (long_now - long_last) * lateral_factor;
+        if (k->cur_block == '$') {
+            if (k->lane->speed_limit < speed_kmh) reward = -c->overspeed_penalty * speed_kmh / P->max_speed_kmh;
+        } else reward += c->speed_reward * (speed_kmh / P->max_speed_kmh);
+    } else {
+        reward += c->driving_reward * (long_now - long_last) * lateral_factor * positive_road;
+        reward += c->speed_reward * (speed_kmh / P->max_speed_kmh) * positive_road;
+    }
     float step_reward = reward;
     if (arrive) reward = c->success_reward;
     else if (out_of_road) reward = -c->out_of_road_penalty;
@@ -344,8 +368,15 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
         /* MultiAgentMetaDrive.done_function (multi_agent_metadrive.py:114-128) */
         int crash = (fl & (MD_FL_CRASH_VEHICLE | MD_FL_CRASH_OBJECT | MD_FL_CRASH_BUILDING | MD_FL_CRASH_SIDEWALK |
                            MD_FL_CRASH_HUMAN)) != 0;
+        if (toll) crash = (fl & MD_FL_CRASH_VEHICLE) != 0; /* marl_tollgate.py:254: only a vehicle crash is taken back */
         if (crash && !c->crash_done && !(arrive || out_of_road)) done = 0;
         if (out_of_road && !c->out_of_road_done && !arrive) done = 0;
+    }
+    if (toll && !max_step && nav->toll_entry && nav->toll_exit && nav->toll_exit - nav->toll_entry < c->min_pass_steps) {
+        /* left the toll block sooner than min_pass_steps after entering it (marl_tollgate.py:254-259): done, reported as
+         * out_of_road -- reward and cost above were taken from _is_out_of_road and do not see it */
+        done = 1;
+        fl |= MD_FL_OUT_OF_ROAD;
     }
     if (max_step) {
         fl |= MD_FL_MAX_STEP;
@@ -365,6 +396,23 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     s->flags[n] = fl;
     s->reward[ai] = reward;
     s->cost[ai] = cost;
+    if (toll) {
+        /* TollGateObservation.observe (marl_tollgate.py:96-110): the counter runs on every observation made inside the block */
+        int t = nav->toll_state & 0xffffff, last = (nav->toll_state >> 24) & 0xff;
+        const int cur = k->cur_block, in_toll = (cur == '$');
+        if (in_toll) t += 1;
+        obs[c->obs_dim - 2] = in_toll ? 1.0f : 0.0f;
+        obs[c->obs_dim - 1] = (in_toll && t > c->min_pass_steps) ? 1.0f : 0.0f;
+        /* StayTimeManager.record (marl_tollgate.py:49-60), called after the step for the agents still active (an agent that
+         * finished in this step is recorded here too: nothing reads its slot again); times in the agent's own steps
+         * (+1, 0 = none): only their difference is read */
+        if (last && last != cur) {
+            if (in_toll) nav->toll_entry = nav->steps + 1;
+            else if ((cur == 'y' || cur == 'Y') && last == '$') nav->toll_exit = nav->steps + 1;
+        }
+        last = cur;
+        nav->toll_state = t | (last << 24);
+    }
 
     /* ---- info (base_vehicle.py:243-271) ---- */
     float step_energy = just_reset ? 0.0f : r[8][1];
@@ -1012,6 +1060,7 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
             nav->timer = 0;
             nav->steps = 0;
             nav->done = 0;
+            nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
             s->final_lane[slot] = w->spawn_route_meta[2 * ri + 1];
             for (int k = 0; k < MD_ROUTE_LEN; ++k) {
                 s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];

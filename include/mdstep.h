@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 7
+#define MD_ABI_VERSION 8
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -135,7 +135,10 @@ typedef struct MdNav {
                           * (node_network_navigation.py:130-168), kept beside the cursors so that the per-step logic never
                           * indexes the 48-entry route arrays; rewritten whenever ck0 / ck1 change (checkpoint advance,
                           * respawn, reset snapshot)                                              */
-    int32_t spare[3];
+    /* MultiAgentTollgateEnv only (envs/marl_envs/marl_tollgate.py:38-112; zero elsewhere): */
+    int32_t toll_state;  /* TollGateObservation.in_toll_time (low 24 bits) | StayTimeManager.last_block << 24 (0 = none yet) */
+    int32_t toll_entry;  /* StayTimeManager.entry_time + 1 in the agent's own steps (0 = not recorded)     */
+    int32_t toll_exit;   /* StayTimeManager.exit_time + 1 (0 = not recorded)                               */
 } MdNav;
 
 /* 32-byte IDM controller state (PID_controller.py:1-22, idm_policy.py:226-233). */
@@ -164,7 +167,9 @@ typedef struct MdLane {
     int32_t hull_off;    /* offset (vertices) into MdWorld.hull_xy                              */
     int32_t hull_n;      /* vertices in the hull (CCW)                                          */
     float end_phase_w;   /* circular: wrap_to_pi(end_phase)                                     */
-    float spare0;
+    float speed_limit;   /* AbstractLane.speed_limit (lane/abs_lane.py:22-29): 3 on the lanes of a TollGate block
+                            (pgblock/tollgate.py:18,64-68), 1000 elsewhere -- read by BaseVehicle.overspeed
+                            (base_vehicle.py:909-911), which compares it with the speed in km/h                */
     float elx, ely;      /* unit lateral (right-hand) vector at the lane end: position(L, lat) = e + lat*el */
     float spare[4];
     float hull4[8];      /* hull_n == 4 (straight lanes): the four hull vertices inline, so that the
@@ -178,7 +183,9 @@ typedef struct MdRoad {
     int32_t start_node, end_node; /* map-local node ids                                         */
     int32_t negative;    /* Road.is_negative_road()                                             */
     int32_t block;       /* block index that created the road                                   */
-    int32_t spare[2];
+    int32_t block_kind;  /* Road.block_ID() (road_network/road.py:42-47): the ASCII code of the block type's letter
+                            taken from the end node (start node for a negative road), '>' for the first block */
+    int32_t spare;
 } MdRoad;
 
 /* 32-byte grid header per map: uniform grid over static geometry (lanes' hulls and quads). */
@@ -212,6 +219,9 @@ typedef struct MdSeg {
 #define MD_SC_REPLAY 1      /* ReplayTrafficParticipantPolicy: pose from the track                        */
 #define MD_SC_IDM 2         /* TrajectoryIDMPolicy: drives along its own recorded path                    */
 #define MD_SC_ARRIVED 3     /* IDM vehicle inside its destination region: removed at the end of this step */
+#define MD_MA_DEFAULT 0      /* MdConfig.ma_kind */
+#define MD_MA_TOLLGATE 1
+#define MD_MA_PARKING_LOT 2
 
 /* Static world: everything fixed between resets. */
 typedef struct MdWorld {
@@ -366,6 +376,14 @@ typedef struct MdConfig {
     int32_t scenario_length;   /* frames of the scenarios (data_manager.current_scenario_length)  */
     int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env, 2 = one launch per phase.
                                 * Same results bit for bit; a machine-mapping choice, no reference counterpart. */
+    /* which multi-agent env's rules md_observe applies (is_multi_agent only): 0 = MultiAgentMetaDrive and the envs that keep
+     * its reward / done / observation, 1 = MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py:181-266: no navigation
+     * dims, two toll dims after the lidar cloud, overspeed penalty inside the toll block, minimum stay), 2 =
+     * MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py) */
+    int32_t ma_kind;
+    int32_t min_pass_steps;    /* vehicle_config.min_pass_steps (marl_tollgate.py:28)                     */
+    float overspeed_penalty;   /* marl_tollgate.py:25                                                     */
+    int32_t n_parking;         /* parking lot env: number of parking spaces (destinations 0..n_parking-1 of the spawn tables) */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 7
+MD_ABI_VERSION = 8
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -50,18 +50,19 @@ PARAM_DT = np.dtype([("max_steer", f4), ("accel_gain", f4), ("brake_gain", f4), 
                      ("max_speed_kmh", f4), ("lf", f4), ("lr", f4), ("fric_decel", f4)])
 NAV_DT = np.dtype([("lane", i4), ("ck0", i4), ("ck1", i4), ("route_len", i4), ("target_lane", i4), ("timer", i4),
                    ("trigger_road", i4), ("trigger_order", i4), ("steps", i4), ("rand_cursor", i4), ("done", i4),
-                   ("road0", i4), ("road1", i4), ("spare", i4, (3, ))])
+                   ("road0", i4), ("road1", i4), ("toll_state", i4), ("toll_entry", i4), ("toll_exit", i4)])
 PID_DT = np.dtype([("hp", f4), ("hi", f4), ("hd", f4), ("lp", f4), ("li", f4), ("ld", f4), ("target_speed", f4),
                    ("energy", f4)])
 LANE_DT = np.dtype([("type", i4), ("road", i4), ("idx", i4), ("n_in_road", i4), ("ax", f4), ("ay", f4), ("bx", f4),
                     ("by", f4), ("length", f4), ("width", f4), ("end_phase", f4), ("dirsign", f4), ("angle", f4),
                     ("heading", f4), ("sx", f4), ("sy", f4), ("ex", f4), ("ey", f4), ("x0", f4), ("y0", f4),
-                    ("x1", f4), ("y1", f4), ("hull_off", i4), ("hull_n", i4), ("end_phase_w", f4), ("spare0", f4),
+                    ("x1", f4), ("y1", f4), ("hull_off", i4), ("hull_n", i4), ("end_phase_w", f4), ("speed_limit", f4),
                     ("elx", f4), ("ely", f4), ("spare", f4, (4, )), ("hull4", f4, (8, ))])
 ROAD_DT = np.dtype([("first_lane", i4), ("n_lanes", i4), ("start_node", i4), ("end_node", i4), ("negative", i4),
-                    ("block", i4), ("spare", i4, (2, ))])
+                    ("block", i4), ("block_kind", i4), ("spare", i4)])
 SEG_DT = np.dtype([("sx", f4), ("sy", f4), ("ex", f4), ("ey", f4), ("dx", f4), ("dy", f4), ("len", f4), ("heading", f4),
                    ("cum", f4), ("spare", f4, (3, ))])
+MA_DEFAULT, MA_TOLLGATE, MA_PARKING_LOT = 0, 1, 2
 TM_MOVING, TM_LENGTH_OK, TM_NEVER = 1, 2, 4
 SC_ABSENT, SC_REPLAY, SC_IDM, SC_ARRIVED = 0, 1, 2, 3
 GRID_DT = np.dtype([("x0", f4), ("y0", f4), ("inv_cell", f4), ("nx", i4), ("ny", i4), ("cell_base", i4),
@@ -131,6 +132,7 @@ class MdConfig(C.Structure):
         ("filter_overlapping_car", C.c_int32), ("no_static_vehicles", C.c_int32), ("allowed_more_steps", C.c_int32),
         ("scenario_length", C.c_int32),
         ("step_kernel", C.c_int32),
+        ("ma_kind", C.c_int32), ("min_pass_steps", C.c_int32), ("overspeed_penalty", C.c_float), ("n_parking", C.c_int32),
     ]
 
 

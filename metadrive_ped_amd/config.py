@@ -31,7 +31,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
-    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" (set by the multi-agent env classes)
+    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" | "tollgate" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",
@@ -47,6 +47,7 @@ BASE_DEFAULT_CONFIG = dict(
                    add_others_navi=False),
         side_detector=dict(num_lasers=0, distance=50, gaussian_noise=0.0, dropout_prob=0.0),
         lane_line_detector=dict(num_lasers=0, distance=20, gaussian_noise=0.0, dropout_prob=0.0),
+        min_pass_steps=30,               # MultiAgentTollgateEnv: steps an agent has to spend inside the toll block (marl_tollgate.py:28)
     ),
     # ===== engine =====
     use_render=False,
@@ -65,7 +66,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     random_lane_width=False,
     random_lane_num=False,
     map_config=dict(type="block_num", config=None, lane_width=3.5, lane_num=3, exit_length=50,
-                    neck_lane_num=1, neck_length=20),   # the last two: multi-agent bottleneck map only (marl_bottleneck.py:13)
+                    neck_lane_num=1, neck_length=20,    # multi-agent bottleneck map only (marl_bottleneck.py:13)
+                    toll_lane_num=8, toll_length=10),   # multi-agent tollgate map only (marl_tollgate.py:19)
     store_map=True,
     traffic_density=0.1,
     need_inverse_traffic=False,
@@ -96,6 +98,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     out_of_road_done=True,
     force_seed_spawn_manager=False,
     spawn_roads=None,
+    cross_yellow_line_done=True,   # bottleneck / bidirection / tollgate envs (marl_bottleneck.py:17,129-135, marl_tollgate.py:22,241-247)
+    overspeed_penalty=0.5,         # tollgate env (marl_tollgate.py:25)
     # VaryingDynamicsEnv (envs/varying_dynamics_env.py:14-25): None = off, else {parameter: (min, max) | None}
     random_dynamics=None,
 )
@@ -239,6 +243,8 @@ def make_config(user=None):
         raise ValueError("spawn_roads is a multi-agent env option")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
+    if not cfg["cross_yellow_line_done"] and cfg["marl_map"] != "tollgate":
+        raise NotImplementedError("cross_yellow_line_done=False is built for the tollgate env only")
     if cfg["step_kernel"] not in ("wg", "wave", "pm"):
         raise ValueError("step_kernel must be 'wg', 'wave' or 'pm', got {!r}".format(cfg["step_kernel"]))
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):

@@ -2872,8 +2872,9 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
         }
         return MD_OK;
     }
-    if (c->obs_dim != md_obs_lidar(c) + c->n_beams) {
-        snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d", c->obs_dim, md_obs_lidar(c), c->n_beams);
+    if (c->obs_dim != md_obs_lidar(c) + c->n_beams + md_obs_tail(c)) {
+        snprintf(g_err, sizeof g_err, "obs_dim=%d != %d state/navi dims + n_beams=%d + %d", c->obs_dim, md_obs_lidar(c), c->n_beams,
+                 md_obs_tail(c));
         return MD_EINVAL;
     }
     if (c->num_others < 0 || c->num_others > 16 || (c->num_others > 0 && c->n_beams <= 0)) {

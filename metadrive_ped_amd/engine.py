@@ -23,7 +23,7 @@ STATE_ARRAY_SPECS = None  # filled below
 
 def _build_marl(cfg, scene_cfg, uniq):
     """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
-    from metadrive_ped_amd.mapgen.pg import MABidirectionMap, MABottleneckMap, MAIntersectionMap, MARoundaboutMap
+    from metadrive_ped_amd.mapgen.pg import MABidirectionMap, MABottleneckMap, MAIntersectionMap, MARoundaboutMap, MATollGateMap
     from metadrive_ped_amd.marl import FIXED_DESTINATION, SPAWN_ROADS, RoundaboutScene
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     mc = cfg["map_config"]
@@ -33,6 +33,9 @@ def _build_marl(cfg, scene_cfg, uniq):
     if kind in ("bottleneck", "bidirection"):
         pg = (MABottleneckMap if kind == "bottleneck" else MABidirectionMap)(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                              neck_lane_num=mc["neck_lane_num"], neck_length=mc["neck_length"])
+    elif kind == "tollgate":
+        pg = MATollGateMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+                           toll_lane_num=mc["toll_lane_num"], toll_length=mc["toll_length"])
     else:
         cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]
         pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
@@ -106,12 +109,14 @@ class HostScene:
         self.n_side = int(vc["side_detector"]["num_lasers"]) if vc["side_detector"]["distance"] > 0 else 0
         self.n_ll = int(vc["lane_line_detector"]["num_lasers"]) if vc["lane_line_detector"]["distance"] > 0 else 0
         self.obs_base = 2 if cfg["random_agent_model"] else 0            # [length, width] lead the state dims
-        self.state_dim = self.obs_base + (self.n_side or 2) + 6 + (self.n_ll or 1) + 10   # 19 with everything off
+        self.tollgate = bool(cfg["is_multi_agent"]) and cfg["marl_map"] == "tollgate"
+        # 19 with everything off; the tollgate env's state observation has no navigation dims (marl_tollgate.py:62-74)
+        self.state_dim = self.obs_base + (self.n_side or 2) + 6 + (self.n_ll or 1) + (0 if self.tollgate else 10)
         # "others" block only exists with the lidar on (obs/state_obs.py:172-183)
         self.num_others = int(vc["lidar"]["num_others"]) if self.n_beams > 0 else 0
         self.add_others_navi = bool(vc["lidar"]["add_others_navi"]) and self.num_others > 0
         self.others_dim = self.num_others * (8 if self.add_others_navi else 4)
-        self.obs_dim = self.state_dim + self.others_dim + self.n_beams
+        self.obs_dim = self.state_dim + self.others_dim + self.n_beams + (2 if self.tollgate else 0)   # + the two toll dims
         mc = cfg["map_config"]
         seeds = [cfg["start_seed"] + ((cfg["env_seed_offset"] + e) % cfg["num_scenarios"]) for e in range(E)]
         self.seeds = seeds
@@ -151,6 +156,9 @@ class HostScene:
         build_fn = _build_one
         if cfg["is_multi_agent"] and not cfg["mover_capacity"]:
             scene_cfg["cap"] = cap = A
+            if self.tollgate:     # + the toll booths (one on every odd lane of both directions), slots in multiples of 8
+                cap = min(abi.MD_MAX_CAP, (A + 2 * (mc["toll_lane_num"] // 2) + 7) // 8 * 8)
+                scene_cfg["cap"] = cap
             self.cap = cap
             jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
         if cfg["is_multi_agent"] and not shared_map:
@@ -289,6 +297,11 @@ def make_md_config(cfg, E, A, cap, n_beams):
     k.allow_respawn = int(bool(cfg["allow_respawn"]))
     k.crash_done = int(bool(cfg["crash_done"]))
     k.out_of_road_done = int(bool(cfg["out_of_road_done"]))
+    if cfg["is_multi_agent"] and cfg["marl_map"] == "tollgate":
+        k.ma_kind = abi.MA_TOLLGATE
+        k.min_pass_steps = int(cfg["vehicle_config"]["min_pass_steps"])
+        k.overspeed_penalty = float(cfg["overspeed_penalty"])
+        k.on_continuous_line_done = int(bool(cfg["cross_yellow_line_done"]))   # _is_out_of_road (marl_tollgate.py:241-247)
     return k
 
 

@@ -57,7 +57,9 @@ class BatchedMultiAgentRoundaboutEnv:
         n_s = vc["side_detector"]["num_lasers"] if vc["side_detector"]["distance"] > 0 else 0
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
         n_o = lidar["num_others"] * (8 if lidar["add_others_navi"] else 4) if n > 0 else 0
-        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + 10 + n_o + n, ), np.float32)
+        toll = self.config["marl_map"] == "tollgate"     # no navigation dims, two toll dims after the cloud
+        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + (0 if toll else 10) + n_o + n + (2 if toll else 0), ),
+                                     np.float32)
         from metadrive_ped_amd.envs.metadrive_env import make_action_space
         self.action_space = make_action_space(self.config)
         self.engine = None
@@ -212,6 +214,36 @@ class BatchedMultiAgentBidirectionEnv(BatchedMultiAgentBottleneckEnv):
     the neck -- ONE lane that both directions share for 40-80 m -- 20 agents from both ends.  Rewards, termination and
     detectors are the bottleneck env's."""
     MAP_DEFAULTS = dict(BatchedMultiAgentBottleneckEnv.MAP_DEFAULTS, marl_map="bidirection")
+
+
+class BatchedMultiAgentTollgateEnv(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py:14-266): 40 agents from both ends of a road that widens from 3
+    to 8 lanes, passes a 10 m toll block (a booth on every odd lane, speed limit 3) and narrows again.  Its own rules, all on
+    the device (MdConfig.ma_kind = 1): the observation has no navigation dims and ends with [inside the toll block, stayed
+    longer than min_pass_steps]; inside the block the speed reward gives way to -overspeed_penalty * v / v_max while the
+    vehicle is above the limit; out of road = sidewalk or (cross_yellow_line_done) the yellow line; an agent that leaves the
+    block less than `vehicle_config.min_pass_steps` steps after entering it is done, reported as out_of_road."""
+    MAP_DEFAULTS = dict(marl_map="tollgate", num_agents=40, cross_yellow_line_done=True, speed_reward=0.0, overspeed_penalty=0.5,
+                        map_config=dict(exit_length=70, lane_num=3, toll_lane_num=8, toll_length=10),
+                        vehicle_config=dict(min_pass_steps=30, side_detector=dict(num_lasers=72, distance=20),
+                                            lane_line_detector=dict(num_lasers=4, distance=20),
+                                            lidar=dict(num_lasers=72, distance=20)))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)
+
+    def _info(self):
+        info = super()._info()
+        e, A = self.engine, self.num_agents
+        info._lazy["in_toll_time"] = lambda: e.nav_i[:, :A, 13] & 0xffffff      # MdNav.toll_state, low 24 bits
+        return info
 
 
 class BatchedMultiAgentMetaDrive(BatchedMultiAgentRoundaboutEnv):

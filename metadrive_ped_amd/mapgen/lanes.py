@@ -29,6 +29,11 @@ def wrap_to_pi(x):
 class Lane:
     """Common part: width, line decoration, graph index."""
     kind = None
+    # AbstractLane.speed_limit (lane/abs_lane.py:22): 1000 unless a builder sets it -- the bends of create_bend_straight
+    # get 20 (create_pg_block_utils.py:28), the TollGate block's lanes 3 (pgblock/tollgate.py:64-68); side lanes made from a
+    # reference lane inherit it (CreateRoadFrom), an extension starts again at 1000 (ExtendStraightLane re-initialises the lane).
+    # Only MultiAgentTollgateEnv reads it (BaseVehicle.overspeed); the ramps' own SPEED_LIMIT constants are not carried.
+    speed_limit = 1000.0
 
     def __init__(self, width, line_types):
         self.width = float(width)
@@ -97,6 +102,7 @@ class StraightLane(Lane):
     def extended(self, extra, line_types):
         """ExtendStraightLane (create_pg_block_utils.py:178-195)."""
         o = self.clone()
+        o.speed_limit = 1000.0
         o.start = self.end
         o.end = self.position(self.length + extra, 0.0)
         o.line_types = list(line_types)

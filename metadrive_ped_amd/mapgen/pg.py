@@ -257,6 +257,7 @@ def create_adverse_road(road, block_net, global_net, ignore_check=False, center_
         clockwise = not ref.clockwise
         radius = ref.radius + (num - 1) * w if not clockwise else ref.radius - (num - 1) * w
         sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
+    sym.speed_limit = ref.speed_limit      # the symmetric lane is constructed with reference_lane.speed_limit (:248,261)
     ok = create_road_from(sym, num // 2, negate_road(a, b), block_net, global_net, ignore_check,
                           center_line_type=center_line_type, side_lane_line_type=side_lane_line_type,
                           inner_lane_line_type=inner_lane_line_type, center_line_color=center_line_color)
@@ -277,6 +278,7 @@ def create_two_way_road(road, block_net, global_net, new_road, center_line_type=
         clockwise = not ref.clockwise
         radius = ref.radius + (num - 1) * w if not clockwise else ref.radius - (num - 1) * w
         sym = CircularLane(ref.center, radius, ref.end_phase, ref.angle, clockwise, w, ref.line_types)
+    sym.speed_limit = ref.speed_limit      # (:316,329)
     return create_road_from(sym, num, new_road, block_net, global_net, ignore_check, center_line_type=center_line_type,
                             side_lane_line_type=side_lane_line_type, inner_lane_line_type=inner_lane_line_type)
 
@@ -309,6 +311,7 @@ def bend_then_straight(prev, follow_len, radius, angle, clockwise, width, line_t
     # get_vertical_vector: ((-vy, vx)/n, (vy, -vx)/n); clockwise picks the second
     nxt = np.asarray((v[1] / n, -v[0] / n)) if clockwise else np.asarray((-v[1] / n, v[0] / n))
     straight = StraightLane(bend_end, nxt * follow_len + bend_end, width, line_types)
+    bend.speed_limit = straight.speed_limit = 20.0      # create_bend_straight's default (create_pg_block_utils.py:28)
     return bend, straight
 
 
@@ -1123,9 +1126,14 @@ class TollGate(Block):
     ID = "$"
     SPACE = BlockParameterSpace.BOTTLENECK
     BUILDING_LENGTH = 10.0
-    SPEED_LIMIT = 3.0   # m/s: stored on the lanes; nothing on the step path reads a lane's speed limit
+    SPEED_LIMIT = 3.0   # stored on the lanes (MdLane.speed_limit); BaseVehicle.overspeed compares it with km/h
+
+    def __init__(self, *a, extra_config=None, **k):
+        super().__init__(*a, **k)
+        self.extra_config = dict(extra_config or {})    # construct_block's own config (marl_tollgate.py:146-148)
 
     def plug(self):
+        self.config.update(self.extra_config)
         length = self.config[Parameter.length]
         new_lane = self.basic_lane.extended(length, [LINE_CONTINUOUS, LINE_SIDE])
         start = self.pre_socket.positive[1]
@@ -1138,6 +1146,7 @@ class TollGate(Block):
         self.buildings = []
         for r in (road, negate_road(*road)):
             for idx, lane in enumerate(self.net.lanes(*r)):
+                lane.speed_limit = self.SPEED_LIMIT
                 if idx % 2 == 1:
                     self.buildings.append((lane, lane.position(lane.length / 2, 0), lane.heading_theta_at(0)))
         # every spawn_object draws a seed from the ENGINE's stream (engine.generate_seed), also in trials the BIG search
@@ -1168,6 +1177,32 @@ class MABottleneckMap:
                       extra_config=dict(length=exit_length, lane_num=lane_num - neck_lane_num))
         split.construct()
         self.blocks = [first, merge, split]
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
+class MATollGateMap:
+    """FirstPGBlock + Split (to `toll_lane_num` lanes over 35 m + 2 m) + TollGate (`toll_length`) + Merge (back, exit
+    `exit_length`): the map of MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py:113-162)."""
+    BOTTLE_LENGTH = 35
+
+    def __init__(self, lane_num=3, lane_width=3.5, exit_length=70, toll_lane_num=8, toll_length=10):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        split = Split(1, list(first.sockets.values())[0], self.net, 1,
+                      extra_config=dict(length=2, lane_num=toll_lane_num - lane_num, bottle_len=self.BOTTLE_LENGTH))
+        split.construct()
+        toll = TollGate(2, list(split.sockets.values())[0], self.net, 1, extra_config=dict(length=toll_length))
+        toll.construct()
+        merge = Merge(3, list(toll.sockets.values())[0], self.net, 1,
+                      extra_config=dict(lane_num=toll_lane_num - lane_num, length=exit_length, bottle_len=self.BOTTLE_LENGTH))
+        merge.construct()
+        self.blocks = [first, split, toll, merge]
         for a, b, lanes in self.net.roads():
             for i, l in enumerate(lanes):
                 l.index = (a, b, i)
@@ -1332,3 +1367,4 @@ MARoundaboutMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, s
 MAIntersectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MABottleneckMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MABidirectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+MATollGateMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

@@ -115,6 +115,18 @@ def sidewalk_quads(lane):
     return out
 
 
+def road_block_id(start_node, end_node):
+    """Road.block_ID() (component/road_network/road.py:42-47) as an ASCII code: the block type's letter, read from the end
+    node -- from the start node for a negative road --, '>' for the first block's nodes; 0 where the name holds none
+    (decoration lanes)."""
+    import re
+    node = start_node if is_negative_road(end_node) else end_node
+    if ">" in node:
+        return ord(">")
+    m = re.search("[a-zA-Z$]", node)
+    return ord(m.group(0)) if m else 0
+
+
 class MapTables:
     """numpy tables of ONE map (all offsets map-local)."""
     def __init__(self, pg_map):
@@ -142,7 +154,7 @@ class MapTables:
             rid = len(roads)
             self.road_id[(a, b)] = rid
             roads.append((len(lanes_flat), len(lanes), node_id(a), node_id(b), int(is_negative_road(b)),
-                          block_of_road.get((a, b), -1)))
+                          block_of_road.get((a, b), -1), road_block_id(a, b)))
             for i, l in enumerate(lanes):
                 self.lane_id[(a, b, i)] = len(lanes_flat)
                 lanes_flat.append((l, rid, i, len(lanes)))
@@ -159,6 +171,7 @@ class MapTables:
             r = self.lanes[k]
             r["road"], r["idx"], r["n_in_road"] = rid, i, n
             r["length"], r["width"] = l.length, l.width
+            r["speed_limit"] = getattr(l, "speed_limit", 1000.0)
             r["sx"], r["sy"] = l.start
             r["ex"], r["ey"] = l.end
             el = l.end_lateral()
@@ -188,10 +201,10 @@ class MapTables:
 
         # --- roads / node adjacency ---
         self.roads = np.zeros(len(roads), dtype=abi.ROAD_DT)
-        for k, (fl, n, sa, sb, neg, blk) in enumerate(roads):
-            self.roads[k] = (fl, n, sa, sb, neg, blk, (0, 0))
+        for k, (fl, n, sa, sb, neg, blk, kind) in enumerate(roads):
+            self.roads[k] = (fl, n, sa, sb, neg, blk, kind, 0)
         adj = [[] for _ in range(n_nodes)]
-        for k, (fl, n, sa, sb, neg, blk) in enumerate(roads):
+        for k, (fl, n, sa, sb, neg, blk, kind) in enumerate(roads):
             adj[sa].append((sb, k))
         self.node_adj_off = np.zeros(n_nodes + 1, dtype=np.int32)
         flat = []

@@ -31,11 +31,13 @@ BOTTLENECK_SPAWN_ROADS = [(">>", ">>>"), negate_road("2Y0_0_", "2Y0_1_")]
 PG_SPAWN_ROADS = [(">>", ">>>")]
 # MABidirectionConfig.spawn_roads (envs/marl_envs/marl_bidirection.py:12): the Split is block 3 there
 BIDIRECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("3Y0_0_", "3Y0_1_")]
+# MATollConfig.spawn_roads (envs/marl_envs/marl_tollgate.py:16): the Merge is block 3 there
+TOLLGATE_SPAWN_ROADS = [(">>", ">>>"), negate_road("3y0_0_", "3y0_1_")]
 SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS,
-                   bidirection=BIDIRECTION_SPAWN_ROADS)
+                   bidirection=BIDIRECTION_SPAWN_ROADS, tollgate=TOLLGATE_SPAWN_ROADS)
 # roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
 # bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)
-FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True)
+FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True, tollgate=True)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 
@@ -109,10 +111,25 @@ class RoundaboutScene:
             nv["ck0"], nv["ck1"] = (0, 1) if n > 2 else (0, 0)
             nv["route_len"] = n
         # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
-        self.shape["hl"], self.shape["hw"] = length / 2, width / 2
+        self.shape["hl"][:A], self.shape["hw"][:A] = length / 2, width / 2
         self.param[:] = prm
         for a in range(len(chosen), A):
             self.shape[a]["flags"] = abi.KIND_VEHICLE      # a free agent slot: what the lifecycle hands to the next spawn
+        # static bodies of the map (toll booths): slots from the top, like the props of the single-agent scenes
+        top = cap
+        for blk in pg.blocks:
+            for lane, pos, heading in getattr(blk, "buildings", ()):
+                top -= 1
+                if top < A:
+                    raise ValueError("mover_capacity {} leaves no slot for the map's buildings".format(cap))
+                sh = self.shape[top]
+                h = wrap_to_pi(heading)
+                sh["cx"], sh["cy"], sh["c"], sh["s"] = pos[0], pos[1], math.cos(h), math.sin(h)
+                sh["hl"], sh["hw"] = blk.BUILDING_LENGTH / 2.0, lane.width / 2.0
+                sh["flags"] = abi.KIND_BUILDING | abi.F_ALIVE | abi.F_STATIC
+                sh["aux"] = mt.lane_id[tuple(lane.index)]
+                self.dyn[top]["heading"] = h
+                self.n_props += 1
 
     def trim(self, cap):
         pass

@@ -471,6 +471,149 @@ def section_ma_bottleneck():
                                     split_config={k: float(v) for k, v in dict(split.get_config()).items()}))
 
 
+def section_ma_tollgate():
+    """MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py): the map MATollGateMap._generate builds (FirstPGBlock 70 m x 3
+    lanes + Split to 8 lanes + TollGate 10 m + Merge back to 3), its booths, speed limits and block ids; and its own
+    reward_function / done_function / TollGateObservation toll dims / StayTimeManager bookkeeping, called on a posed vehicle
+    that is walked through the toll block at different speeds (the reference's methods on a bare instance, no engine)."""
+    import types
+    from types import SimpleNamespace
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.bottleneck import Merge, Split
+    from metadrive.component.pgblock.tollgate import TollGate
+    import metadrive.component.pgblock.tollgate as tg
+    from metadrive.component.buildings.tollgate_building import TollGateBuilding
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.component.road_network import Road
+    from metadrive.component.vehicle.base_vehicle import BaseVehicle
+    from metadrive.envs.marl_envs import marl_tollgate as mt
+    from metadrive.envs.marl_envs.multi_agent_metadrive import MultiAgentMetaDrive
+    from metadrive.manager.spawn_manager import SpawnManager
+    from metadrive.utils.math import Vector
+    spawned = []
+
+    def spawn_object(cls, lane=None, position=None, heading_theta=None, **kw):
+        spawned.append((cls.__name__, lane, [float(position[0]), float(position[1])], float(heading_theta)))
+        return MagicMock()
+    tg.get_engine = lambda: MagicMock(spawn_object=spawn_object)
+    mc = mt.MATollConfig["map_config"]
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, mc["lane_num"], MagicMock(), MagicMock(), length=mc["exit_length"])
+    split = Split(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok1 = split.construct_block(MagicMock(), MagicMock(), {"length": 2, "lane_num": mc["toll_lane_num"] - mc["lane_num"],
+                                                           "bottle_len": mt.MATollGateMap.BOTTLE_LENGTH})
+    toll = TollGate(2, split.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok2 = toll.construct_block(MagicMock(), MagicMock(), {"length": mc["toll_length"]})
+    merge = Merge(3, toll.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+    ok3 = merge.construct_from_config(dict(lane_num=mc["toll_lane_num"] - mc["lane_num"], length=mc["exit_length"],
+                                           bottle_len=mt.MATollGateMap.BOTTLE_LENGTH), MagicMock(), MagicMock())
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            for i, l in enumerate(lanes):
+                l.index = (f, t, i)
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, block_id=Road(f, t).block_ID(), lanes=[lane_record(l) for l in lanes],
+                              speed_limit=[float(l.speed_limit) for l in lanes]))
+    spawn_roads = [[r.start_node, r.end_node] for r in mt.MATollConfig["spawn_roads"]]
+    routes = []
+    for sr in mt.MATollConfig["spawn_roads"]:
+        for er in mt.MATollConfig["spawn_roads"]:
+            dest = (-er).end_node
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest,
+                               path=net.shortest_path((sr.start_node, sr.end_node, 0), dest)))
+    buildings = [dict(cls=c, lane=list(l.index), position=p_, heading=h, width=float(l.width),
+                      length=float(TollGateBuilding.BUILDING_LENGTH)) for c, l, p_, h in spawned]
+
+    # ---- the env's own step logic on a posed vehicle walked along the positive route
+    class BareEnv(mt.MultiAgentTollgateEnv):     # properties of BaseEnv that read the engine singleton
+        current_seed = 0
+        agents = property(lambda self: self._agents)
+        engine = None
+
+    cfg = dict(MultiAgentMetaDrive.default_config().get_dict())
+    for k, v in mt.MATollConfig.items():
+        if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+            cfg[k] = dict(cfg[k], **v)
+        else:
+            cfg[k] = v
+    ckpts = net.shortest_path((">>", ">>>", 0), (-mt.MATollConfig["spawn_roads"][1]).end_node)
+    final_lane = net.graph[ckpts[-2]][ckpts[-1]][-1]
+    rng = np.random.RandomState(77)
+    episodes = []
+    # steps spent inside the 10 m toll block: around the 30-step minimum, one far below, one crawling under the 3 km/h limit
+    for ep, n_toll in enumerate((12, 28, 33, 34, 35, 36, 37, 125)):
+        env = object.__new__(BareEnv)
+        env.config = dict(cfg, horizon=1000, crash_done=bool(ep % 2), out_of_road_done=bool(ep % 3 != 1))
+        env.stay_time_manager = mt.StayTimeManager()
+        env.logger = MagicMock()
+        obs = object.__new__(mt.TollGateObservation)
+        obs.in_toll_time = 0
+        obs.state_observe = lambda v: np.zeros(0)
+        obs.lidar_observe = lambda v: []
+        toll_lane = int(rng.choice([0, 2, 4, 6]))            # even lanes are open, odd ones hold a booth
+        d_toll = 10.0 / n_toll + 1e-3
+        k, s_ = 0, 40.0
+        steps = []
+        tstep = 0
+        lat_off = float(rng.uniform(-0.6, 0.6))
+        while tstep < 260 and k < len(ckpts) - 1:
+            cur_lanes = net.graph[ckpts[k]][ckpts[k + 1]]
+            road = Road(ckpts[k], ckpts[k + 1])
+            in_toll = road.block_ID() == TollGate.ID
+            li = min(toll_lane if len(cur_lanes) > 3 else 1, len(cur_lanes) - 1)
+            lane = cur_lanes[li]
+            if s_ > lane.length:
+                s_ -= lane.length
+                k += 1
+                continue
+            adv = d_toll if in_toll else float(rng.uniform(3.0, 5.0))
+            speed = adv / 0.1
+            pos = lane.position(s_, lat_off)
+            heading = float(lane.heading_theta_at(s_))
+            last_pos = lane.position(s_ - adv, lat_off)
+            last_road = (k + 1 == len(ckpts) - 1)
+            nav = SimpleNamespace(current_ref_lanes=cur_lanes, current_road=road, final_lane=final_lane, checkpoints=ckpts,
+                                  get_current_lane_width=lambda lane=lane: lane.width,
+                                  get_current_lane_num=lambda cur_lanes=cur_lanes: len(cur_lanes),
+                                  _target_checkpoints_index=[k, k] if last_road else [k, k + 1])
+            flags = dict(crash_vehicle=bool(rng.rand() < 0.04), crash_object=bool(rng.rand() < 0.02), crash_building=False,
+                         crash_human=False, crash_sidewalk=bool(rng.rand() < 0.02), on_lane=bool(rng.rand() < 0.97),
+                         on_yellow_continuous_line=bool(rng.rand() < 0.03), on_white_continuous_line=bool(rng.rand() < 0.1),
+                         on_broken_line=False)
+            veh = SimpleNamespace(position=Vector((float(pos[0]), float(pos[1]))), last_position=(float(last_pos[0]), float(last_pos[1])),
+                                  heading_theta=heading, speed_km_h=speed * 3.6, max_speed_km_h=80.0, lane=lane, navigation=nav,
+                                  config=dict(cfg["vehicle_config"]), out_of_route=False, **flags)
+            veh.overspeed = bool(lane.speed_limit < veh.speed_km_h)
+            env._agents = {"a": veh}
+            env.episode_lengths = {"a": tstep + 1}
+            done, dinfo = mt.MultiAgentTollgateEnv.done_function(env, "a")
+            reward, rinfo = mt.MultiAgentTollgateEnv.reward_function(env, "a")
+            o = mt.TollGateObservation.observe(obs, veh)
+            env.stay_time_manager.record({"a": veh}, tstep)
+            stm = env.stay_time_manager
+            steps.append(dict(lane=list(lane.index), idx=nav._target_checkpoints_index, pos=[float(pos[0]), float(pos[1])],
+                              heading=heading, last_pos=[float(last_pos[0]), float(last_pos[1])], speed=speed,
+                              flags=[k_ for k_, v in flags.items() if v], block_id=road.block_ID(), overspeed=veh.overspeed,
+                              done=bool(done), done_info=[k_ for k_, v in dinfo.items() if v is True], reward=float(reward),
+                              step_reward=float(rinfo["step_reward"]), toll_obs=[float(x) for x in o[-2:]],
+                              in_toll_time=int(obs.in_toll_time), entry=stm.entry_time.get("a"), exit=stm.exit_time.get("a")))
+            s_ += adv
+            tstep += 1
+        episodes.append(dict(crash_done=env.config["crash_done"], out_of_road_done=env.config["out_of_road_done"],
+                             toll_lane=toll_lane, steps_in_toll=n_toll, steps=steps))
+    keys = ("num_agents", "cross_yellow_line_done", "speed_reward", "overspeed_penalty", "driving_reward", "success_reward",
+            "out_of_road_penalty", "crash_vehicle_penalty", "crash_object_penalty", "use_lateral_reward", "delay_done", "horizon")
+    dump("ma_tollgate.json", dict(no_cross=bool(ok1 and ok2 and ok3), roads=roads, spawn_roads=spawn_roads, routes=routes,
+                                  buildings=buildings, route=ckpts, final_lane=list(final_lane.index),
+                                  max_capacity=int(SpawnManager.max_capacity(mt.MATollConfig["spawn_roads"], mc["exit_length"],
+                                                                             mc["lane_num"])),
+                                  config={k_: cfg[k_] for k_ in keys}, min_pass_steps=int(cfg["vehicle_config"]["min_pass_steps"]),
+                                  vehicle_config={k_: dict(cfg["vehicle_config"][k_]) for k_ in ("lidar", "side_detector", "lane_line_detector")},
+                                  map_config=dict(mc), episodes=episodes))
+
+
 def section_ma_bidirection():
     """Map of MultiAgentBidirectionEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 3 m) +
     Bidirection (one lane shared by both directions, seed 1) + Split (back to 4, exit 60 m) as MABidirectionMap._generate
@@ -1171,7 +1314,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -1,6 +1,7 @@
 """Multi-agent roundabout: map geometry vs the reference, lifecycle invariants on the
 oracle (reference behaviour: tests/test_env/test_ma_roundabout_env.py:13-70), GPU parity."""
 import json
+import math
 import os
 
 import numpy as np
@@ -654,3 +655,174 @@ def test_respawn_known_answers_of_the_reference_test():
         assert (((sh["flags"] & abi.F_ALIVE) != 0).any()) or int(o.state["next_agent_id"][0]) > 2     # never all gone for good
     assert done_count >= 4 and names_seen >= set(range(2 + done_count - 1))      # names agent2, agent3, ... handed out in order
     assert int(o.state["next_agent_id"][0]) == 2 + done_count or int(o.state["next_agent_id"][0]) == 1 + done_count
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py)
+# ------------------------------------------------------------------------------------------------
+def _toll_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentTollgateEnv
+    base = dict(num_envs=2, num_scenarios=2)
+    base.update(kw)
+    return BatchedMultiAgentTollgateEnv(base).config
+
+
+def test_tollgate_map_equals_reference():
+    """MATollGateMap._generate of the reference: every lane, the booths, the speed limits of the toll lanes, Road.block_ID of
+    every road, the spawn roads and the routes between them."""
+    from metadrive_ped_amd.mapgen.pg import MATollGateMap
+    from metadrive_ped_amd.mapgen.tables import MapTables
+    from metadrive_ped_amd.marl import TOLLGATE_SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_tollgate.json")) as f:
+        g = json.load(f)
+    m = MATollGateMap()
+    mt = MapTables(m)
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]
+    for (a, b, lanes), ref in zip(roads, g["roads"]):
+        assert len(lanes) == len(ref["lanes"])
+        rid = mt.road_id[(a, b)]
+        assert chr(int(mt.roads[rid]["block_kind"])) == ref["block_id"]
+        for i, (l, rl) in enumerate(zip(lanes, ref["lanes"])):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+            np.testing.assert_allclose([l.length, *l.start, *l.end], [rl["length"], *rl["start"], *rl["end"]], atol=1e-9)
+            # speed limits: 3 inside the toll block, 20 on the bends and what is built from them, 1000 elsewhere
+            assert float(mt.lanes[mt.lane_id[(a, b, i)]]["speed_limit"]) == ref["speed_limit"][i]
+            assert (ref["speed_limit"][i] == 3.0) == (ref["block_id"] == "$")
+    assert [list(r) for r in TOLLGATE_SPAWN_ROADS] == g["spawn_roads"]
+    for r in g["routes"]:
+        assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    toll = m.blocks[2]
+    assert len(toll.buildings) == len(g["buildings"]) == 8
+    for (lane, pos, h), rb in zip(toll.buildings, g["buildings"]):
+        assert list(lane.index) == rb["lane"] and rb["length"] == toll.BUILDING_LENGTH and rb["width"] == lane.width
+        np.testing.assert_allclose([*pos, h], [*rb["position"], rb["heading"]], atol=1e-9)
+    d = _toll_cfg()
+    assert g["max_capacity"] == 42 and g["config"]["num_agents"] == d["num_agents"] == 40
+    for k in ("cross_yellow_line_done", "speed_reward", "overspeed_penalty", "driving_reward", "success_reward",
+              "out_of_road_penalty", "crash_vehicle_penalty", "crash_object_penalty", "use_lateral_reward", "delay_done", "horizon"):
+        assert d[k] == g["config"][k], k
+    assert d["vehicle_config"]["min_pass_steps"] == g["min_pass_steps"] == 30
+    for k, v in g["vehicle_config"].items():
+        for kk, vv in v.items():
+            assert d["vehicle_config"][k][kk] == vv
+    for k, v in g["map_config"].items():
+        assert d["map_config"][k] == v
+
+
+def test_tollgate_reward_done_obs_and_stay_time_against_reference():
+    """The reference's own MultiAgentTollgateEnv.reward_function / done_function, TollGateObservation.observe (its two toll
+    dims and the in_toll_time counter) and StayTimeManager.record, called step by step on a vehicle walked through the toll block
+    (tests/golden/ma_tollgate.json: eight passes lasting 8 .. 96 steps, 30 being the minimum), against ref_observe on the same poses."""
+    from metadrive_ped_amd.engine import HostScene
+    with open(os.path.join(GOLDEN, "ma_tollgate.json")) as f:
+        g = json.load(f)
+    FLAG_OF = dict(crash_vehicle=abi.FL_CRASH_VEHICLE, crash_object=abi.FL_CRASH_OBJECT, crash_building=abi.FL_CRASH_BUILDING,
+                   crash_human=abi.FL_CRASH_HUMAN, crash_sidewalk=abi.FL_CRASH_SIDEWALK, on_lane=abi.FL_ON_LANE,
+                   on_yellow_continuous_line=abi.FL_ON_YELLOW_CONT, on_white_continuous_line=abi.FL_ON_WHITE_CONT,
+                   on_broken_line=abi.FL_ON_BROKEN)
+    n = stay_rule = toll1 = over = 0
+    for ep in g["episodes"]:
+        cfg = _toll_cfg(num_envs=1, num_scenarios=1, num_agents=1, crash_done=ep["crash_done"], out_of_road_done=ep["out_of_road_done"],
+                        auto_reset=False, horizon=1000, allow_respawn=False)
+        host = HostScene(cfg)
+        t = host.map_tables[0]
+        orc = ob.OracleWorld(host, host.clone_state())
+        st = orc.state
+        st["need_reset"][:] = 0
+        # the lone agent spawns on the first spawn point: route = the reference's positive route
+        assert [t.node_names[i] for i in st["route_nodes"][0, :len(g["route"])]] == g["route"]
+        assert st["final_lane"][0] == t.lane_id[tuple(g["final_lane"])]
+        sh, dy, nv = st["shape"], st["dyn"], st["nav"]
+        nv["toll_state"][0] = nv["toll_entry"][0] = nv["toll_exit"][0] = 0
+        entry0 = None
+        for k, smp in enumerate(ep["steps"]):
+            sh["cx"][0], sh["cy"][0] = smp["pos"]
+            sh["c"][0], sh["s"][0] = math.cos(smp["heading"]), math.sin(smp["heading"])
+            dy["heading"][0], dy["speed"][0] = smp["heading"], smp["speed"]
+            dy["last_x"][0], dy["last_y"][0] = smp["last_pos"]
+            dy["last_c"][0], dy["last_s"][0] = sh["c"][0], sh["s"][0]
+            nv["lane"][0] = t.lane_id[tuple(smp["lane"])]
+            nv["ck0"][0], nv["ck1"][0] = smp["idx"]
+            nv["road0"][0], nv["road1"][0] = st["route_roads"][0, smp["idx"][0]], st["route_roads"][0, smp["idx"][1]]
+            nv["steps"][0] = k                   # episode_lengths = k + 1 after ref_observe's increment
+            nv["done"][0] = 0                    # the reference's done_function is not sticky; the env's bookkeeping around it is
+            fl = 0
+            for name in smp["flags"]:
+                fl |= FLAG_OF[name]
+            st["flags"][0] = fl
+            orc.call("ref_observe")
+            out = int(st["flags"][0])
+            di = set(smp["done_info"])
+            assert bool(out & abi.FL_OUT_OF_ROAD) == ("out_of_road" in di), (k, smp)
+            assert bool(out & abi.FL_ARRIVE_DEST) == ("arrive_dest" in di), (k, smp)
+            assert bool(out & abi.FL_TERMINATED) == smp["done"], (k, smp)
+            assert abs(float(st["reward"][0]) - smp["reward"]) < 2e-4, (k, smp, float(st["reward"][0]))
+            assert abs(float(st["step_info"][0, 0]) - smp["step_reward"]) < 2e-4, (k, smp)
+            assert list(st["obs"][0, -2:]) == smp["toll_obs"], (k, smp)
+            assert int(nv["toll_state"][0]) & 0xffffff == smp["in_toll_time"]
+            assert chr(int(nv["toll_state"][0]) >> 24) == smp["block_id"]
+            # entry / exit: the reference stamps env steps, the device the agent's own steps: same differences
+            assert (int(nv["toll_entry"][0]) != 0) == (smp["entry"] is not None)
+            assert (int(nv["toll_exit"][0]) != 0) == (smp["exit"] is not None)
+            if smp["entry"] is not None and smp["exit"] is not None:
+                assert int(nv["toll_exit"][0]) - int(nv["toll_entry"][0]) == smp["exit"] - smp["entry"]
+            n += 1
+            over += smp["overspeed"]
+            toll1 += smp["toll_obs"][1] == 1.0
+            stay_rule += ("out_of_road" in di and "crash_sidewalk" not in smp["flags"] and
+                          "on_yellow_continuous_line" not in smp["flags"])
+    assert n >= 500 and stay_rule >= 50 and toll1 >= 50 and over >= 100
+
+
+def test_tollgate_env_on_oracle():
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 2, 40
+    host = HostScene(_toll_cfg(num_envs=E, num_scenarios=E))
+    assert host.cap == 48 and host.obs_dim == 72 + 6 + 4 + 72 + 2          # no navigation dims, two toll dims at the end
+    o = ob.OracleWorld(host)
+    o.reset()
+    sh = o.state["shape"].reshape(E, -1)
+    assert ((sh["flags"] & 0xF) == abi.KIND_BUILDING).sum() == 8 * E
+    assert (_counts(o.state, E)[0] == A).all()
+    rng = np.random.RandomState(3)
+    entered = left = 0
+    for t in range(500):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.5
+        a[..., 0] = rng.uniform(-0.05, 0.05, (E, A))
+        o.step(a)
+        nv = o.state["nav"].reshape(E, -1)[:, :A]
+        entered = max(entered, int((nv["toll_entry"] > 0).sum()))
+        left = max(left, int((nv["toll_exit"] > 0).sum()))
+        obs = o.state["obs"].reshape(E, A, -1)
+        assert set(np.unique(obs[..., -2:])) <= {0.0, 1.0}
+    assert entered > 0 and (o.state["next_agent_id"] > A).all()
+    fl = o.state["flags"].reshape(E, -1)
+    assert not (fl[:, A:] != 0).any()
+
+
+@pytest.mark.gpu
+def test_tollgate_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 4, 40
+    eng = BatchedEngine(_toll_cfg(num_envs=E, num_scenarios=E))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="tollgate reset")
+    rng = np.random.RandomState(12)
+    slow = rng.rand(E, A) < 0.5                      # half of the agents crawl, so that some pass the toll block legally
+    for t in range(400):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = np.where(slow, 0.25, 0.7)
+        a[..., 0] = rng.uniform(-0.1, 0.1, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="tollgate step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="tollgate final")
+    nv = orc.state["nav"].reshape(E, -1)[:, :A]
+    assert (orc.state["next_agent_id"] > A).all()
