@@ -1053,6 +1053,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                     nav->timer = 0;
                     nav->steps = 0;
                     nav->done = 0;
+                    nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
                     s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
                     for (int q = 0; q < MD_ROUTE_LEN; ++q) {
                         s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
