@@ -323,6 +323,8 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
         out_of_road = (fl & MD_FL_CRASH_SIDEWALK) != 0;
         if (c->on_continuous_line_done) out_of_road = out_of_road || (fl & MD_FL_ON_YELLOW_CONT);
     }
+    if (c->is_multi_agent && c->ma_kind == MD_MA_PARKING_LOT) /* MultiAgentParkingLotEnv._is_out_of_road (marl_parking_lot.py:257-259) */
+        out_of_road = !(fl & MD_FL_ON_LANE) || (fl & (MD_FL_ON_YELLOW_CONT | MD_FL_CRASH_SIDEWALK));
     if (arrive) fl |= MD_FL_ARRIVE_DEST;
     if (out_of_road) fl |= MD_FL_OUT_OF_ROAD;
 
@@ -969,6 +971,18 @@ MD_HD void md_traffic_respawn_env(const MdWorld* w, const MdLane* lanes, const M
     }
 }
 
+MD_HD int md_popcount32(uint32_t v) {
+    int n = 0;
+    for (; v; v &= v - 1) ++n;
+    return n;
+}
+MD_HD int md_kth_set_bit(uint32_t v, int k) { /* index of the k-th (0-based) set bit, ascending */
+    while (k-- > 0) v &= v - 1;
+    int i = 0;
+    while (!((v >> i) & 1u)) ++i;
+    return i;
+}
+
 #define MD_RESPAWN_HALF_LEN 4.0f  /* RESPAWN_REGION_LONGITUDE / 2 (spawn_manager.py:28) */
 #define MD_RESPAWN_HALF_WID 1.5f  /* RESPAWN_REGION_LATERAL / 2 */
 
@@ -976,6 +990,11 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
     const int A = c->agents_per_env;
     s->env_steps[0] += 1;
     int active = 0, dying = 0;
+    /* MultiAgentParkingLotEnv (marl_parking_lot.py:47-95): a vehicle entering from outside is given a free parking space as its
+     * destination and holds it until it is done (ParkingLotSpawnManager.get_parking_space / after_vehicle_done); the set of
+     * free spaces is therefore what no ACTIVE agent holds -- nav.toll_entry = space + 1 -- and needs no state of its own */
+    const int parking = c->ma_kind == MD_MA_PARKING_LOT;
+    uint32_t reserved = 0;
     for (int a = 0; a < A; ++a) {
         MdShape* sh = &s->shape[a];
         MdNav* nav = &s->nav[a];
@@ -993,6 +1012,7 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
                 s->dyn[a].speed = 0.0f;
             } else {
                 active++;
+                if (parking && nav->toll_entry > 0) reserved |= 1u << (nav->toll_entry - 1);
                 continue;
             }
         }
@@ -1005,12 +1025,15 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
     if (c->allow_respawn && horizon_open && w->spawn_off) {
         const int p0 = w->spawn_off[m], np_ = w->spawn_off[m + 1] - p0;
         uint32_t used = 0; /* spawn_places_used, reset every step */
+        const int n_in = parking ? np_ - c->n_parking : 0; /* places 0 .. n_in-1: the entrances; then one per parking space */
+        uint32_t avail = parking ? (((1u << c->n_parking) - 1u) & ~reserved) : 0u;
         while (active + dying < A) {
             /* safe places: not used this step and no vehicle chassis inside the 8 m x 3 m region */
             int safe[32];
             int n_safe = 0;
             for (int p = 0; p < np_ && p < 32; ++p) {
                 if ((used >> p) & 1u) continue;
+                if (parking && p < n_in && avail == 0u) continue; /* no space to send it to: the entrance stays shut (:103-105) */
                 const float* pl = w->spawn_place + 8 * (size_t)(p0 + p);
                 int hit = 0;
                 for (int j = 0; j < c->cap && !hit; ++j) {
@@ -1032,7 +1055,13 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
                 if (!(s->shape[a].flags & MD_F_ALIVE)) { slot = a; break; }
             if (slot < 0) break;
             const float* pl = w->spawn_place + 8 * (size_t)(p0 + p);
-            const int dest = (int)(md_rng_next(s->rng) % (uint32_t)w->n_dest);
+            int dest = 0, space = 0;
+            if (!parking) dest = (int)(md_rng_next(s->rng) % (uint32_t)w->n_dest);
+            else if (p < n_in) { /* update_destination_for (:80-88): from an entrance to a free space, drawn uniformly */
+                dest = md_kth_set_bit(avail, (int)(md_rng_next(s->rng) % (uint32_t)md_popcount32(avail)));
+                avail &= ~(1u << dest);
+                space = dest + 1;
+            } else dest = c->n_parking + (int)(md_rng_next(s->rng) % (uint32_t)(w->n_dest - c->n_parking)); /* out through an entrance */
             const size_t ri = ((size_t)(p0 + p) * w->n_dest + dest);
             const int32_t* rt = w->spawn_route + ri * 2 * MD_ROUTE_LEN;
             MdShape* sh = &s->shape[slot];
@@ -1061,6 +1090,7 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
             nav->steps = 0;
             nav->done = 0;
             nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
+            nav->toll_entry = space;
             s->final_lane[slot] = w->spawn_route_meta[2 * ri + 1];
             for (int k = 0; k < MD_ROUTE_LEN; ++k) {
                 s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];

@@ -31,7 +31,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
-    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" | "tollgate" (set by the multi-agent env classes)
+    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" | "tollgate" | "parking_lot" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",
@@ -100,6 +100,7 @@ METADRIVE_DEFAULT_CONFIG = dict(
     spawn_roads=None,
     cross_yellow_line_done=True,   # bottleneck / bidirection / tollgate envs (marl_bottleneck.py:17,129-135, marl_tollgate.py:22,241-247)
     overspeed_penalty=0.5,         # tollgate env (marl_tollgate.py:25)
+    parking_space_num=8,           # parking-lot env (marl_parking_lot.py:31): an even number >= 4
     # VaryingDynamicsEnv (envs/varying_dynamics_env.py:14-25): None = off, else {parameter: (min, max) | None}
     random_dynamics=None,
 )
@@ -243,6 +244,12 @@ def make_config(user=None):
         raise ValueError("spawn_roads is a multi-agent env option")
     if cfg["is_multi_agent"] and cfg["marl_map"] is None:
         raise NotImplementedError("multi-agent configs are built through the multi-agent env classes (marl_map)")
+    if cfg["marl_map"] == "parking_lot":
+        n = cfg["parking_space_num"]
+        assert n % 2 == 0, "number of parking spaces must be multiples of 2"          # marl_parking_lot.py:198-199
+        assert n >= 4, "minimal number of parking space is 4"
+        if n > 20:
+            raise ValueError("parking_space_num > 20: the spawn tables hold 32 places")
     if not cfg["cross_yellow_line_done"] and cfg["marl_map"] != "tollgate":
         raise NotImplementedError("cross_yellow_line_done=False is built for the tollgate env only")
     if cfg["step_kernel"] not in ("wg", "wave", "pm"):

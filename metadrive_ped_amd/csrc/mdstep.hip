@@ -963,11 +963,14 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
     int* cnt_active = scratch;      // agents that keep driving
     int* cnt_dying = scratch + 1;   // bodies waiting out delay_done
     int* hit_mask = scratch + 2;    // bit p: spawn place p is occupied
+    int* reserved = scratch + 3;    // parking lot env: bit d: an active agent holds parking space d (md_lifecycle_env)
+    const bool parking = c.ma_kind == MD_MA_PARKING_LOT;
     if (tid == 0) {
         s.env_steps[0] += 1;
         *cnt_active = 0;
         *cnt_dying = 0;
         *hit_mask = 0;
+        *reserved = 0;
     }
     __syncthreads();
     for (int a = tid; a < A; a += nthreads) {
@@ -988,6 +991,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                 }
             } else {
                 atomicAdd(cnt_active, 1);
+                if (parking && nav->toll_entry > 0) atomicOr(reserved, 1 << (nav->toll_entry - 1));
                 count_down = false;
             }
         }
@@ -1015,6 +1019,9 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
         if (tid == 0) {
             const uint32_t all = np_ >= 32 ? 0xFFFFFFFFu : ((1u << np_) - 1u);
             uint32_t safe = ~(uint32_t)(*hit_mask) & all;
+            const int n_in = parking ? np_ - c.n_parking : 0;
+            uint32_t avail = parking ? (((1u << c.n_parking) - 1u) & ~(uint32_t)(*reserved)) : 0u;
+            if (parking && avail == 0u) safe &= ~((1u << n_in) - 1u);   // no free space: the entrances stay shut
             const int n_safe = __popc(safe);
             int slot = -1;
             for (int a = 0; a < A; ++a)
@@ -1025,7 +1032,12 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                 const int p = __ffs((int)safe) - 1;
                 if (slot >= 0) {
                     const float* pl = w.spawn_place + 8 * (size_t)(p0 + p);
-                    const int dest = (int)(md_rng_next(s.rng) % (uint32_t)w.n_dest);
+                    int dest = 0, space = 0;
+                    if (!parking) dest = (int)(md_rng_next(s.rng) % (uint32_t)w.n_dest);
+                    else if (p < n_in) {
+                        dest = md_kth_set_bit(avail, (int)(md_rng_next(s.rng) % (uint32_t)__popc(avail)));
+                        space = dest + 1;
+                    } else dest = c.n_parking + (int)(md_rng_next(s.rng) % (uint32_t)(w.n_dest - c.n_parking));
                     const size_t ri = ((size_t)(p0 + p) * w.n_dest + dest);
                     const int32_t* rt = w.spawn_route + ri * 2 * MD_ROUTE_LEN;
                     MdShape* sh = &s.shape[slot];
@@ -1054,6 +1066,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                     nav->steps = 0;
                     nav->done = 0;
                     nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
+                    nav->toll_entry = space;
                     s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
                     for (int q = 0; q < MD_ROUTE_LEN; ++q) {
                         s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];

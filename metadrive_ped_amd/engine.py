@@ -23,7 +23,8 @@ STATE_ARRAY_SPECS = None  # filled below
 
 def _build_marl(cfg, scene_cfg, uniq):
     """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
-    from metadrive_ped_amd.mapgen.pg import MABidirectionMap, MABottleneckMap, MAIntersectionMap, MARoundaboutMap, MATollGateMap
+    from metadrive_ped_amd.mapgen.pg import (MABidirectionMap, MABottleneckMap, MAIntersectionMap, MAParkingLotMap, MARoundaboutMap,
+                                             MATollGateMap)
     from metadrive_ped_amd.marl import FIXED_DESTINATION, SPAWN_ROADS, RoundaboutScene
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     mc = cfg["map_config"]
@@ -33,6 +34,9 @@ def _build_marl(cfg, scene_cfg, uniq):
     if kind in ("bottleneck", "bidirection"):
         pg = (MABottleneckMap if kind == "bottleneck" else MABidirectionMap)(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                              neck_lane_num=mc["neck_lane_num"], neck_length=mc["neck_length"])
+    elif kind == "parking_lot":
+        pg = MAParkingLotMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+                             parking_space_num=cfg["parking_space_num"])
     elif kind == "tollgate":
         pg = MATollGateMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                            toll_lane_num=mc["toll_lane_num"], toll_length=mc["toll_length"])
@@ -43,8 +47,16 @@ def _build_marl(cfg, scene_cfg, uniq):
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
     fixed = FIXED_DESTINATION[kind]
     roads = _user_spawn_roads(cfg, mt) or SPAWN_ROADS[kind]
-    scenes = {s: RoundaboutScene(s, mt, sc_cfg, roads, fixed) for s in uniq}
-    return mt, scenes, spawn_tables(mt, roads, mc["lane_num"], fixed)
+    parking, dests = None, None
+    if kind == "parking_lot":
+        from metadrive_ped_amd.marl import PARKING_IN_ROADS, parking_lot_roads
+        if cfg.get("spawn_roads"):
+            raise NotImplementedError("spawn_roads: the parking-lot env fills them itself (marl_parking_lot.py:194-203)")
+        roads, dests = parking_lot_roads(cfg["parking_space_num"])
+        assert [tuple(r) for r in pg.parking_space] == [(d[:-2] + "1_", d) for d in dests[:cfg["parking_space_num"]]]
+        parking = (len(PARKING_IN_ROADS), cfg["parking_space_num"], dests)
+    scenes = {s: RoundaboutScene(s, mt, sc_cfg, roads, fixed, parking) for s in uniq}
+    return mt, scenes, spawn_tables(mt, roads, mc["lane_num"], fixed, dests)
 
 
 def _user_spawn_roads(cfg, mt):
@@ -297,6 +309,9 @@ def make_md_config(cfg, E, A, cap, n_beams):
     k.allow_respawn = int(bool(cfg["allow_respawn"]))
     k.crash_done = int(bool(cfg["crash_done"]))
     k.out_of_road_done = int(bool(cfg["out_of_road_done"]))
+    if cfg["is_multi_agent"] and cfg["marl_map"] == "parking_lot":
+        k.ma_kind = abi.MA_PARKING_LOT
+        k.n_parking = int(cfg["parking_space_num"])
     if cfg["is_multi_agent"] and cfg["marl_map"] == "tollgate":
         k.ma_kind = abi.MA_TOLLGATE
         k.min_pass_steps = int(cfg["vehicle_config"]["min_pass_steps"])

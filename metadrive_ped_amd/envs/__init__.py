@@ -1,4 +1,5 @@
 from metadrive_ped_amd.envs.metadrive_env import (BatchedMetaDriveEnv, BatchedSafeMetaDriveEnv,  # noqa: F401
                                                   BatchedVaryingDynamicsEnv)
 from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBidirectionEnv, BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,  # noqa: F401
-                                             BatchedMultiAgentMetaDrive, BatchedMultiAgentRoundaboutEnv, BatchedMultiAgentTollgateEnv)
+                                             BatchedMultiAgentMetaDrive, BatchedMultiAgentParkingLotEnv,
+                                             BatchedMultiAgentRoundaboutEnv, BatchedMultiAgentTollgateEnv)

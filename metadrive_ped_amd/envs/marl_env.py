@@ -246,6 +246,33 @@ class BatchedMultiAgentTollgateEnv(BatchedMultiAgentRoundaboutEnv):
         return info
 
 
+class BatchedMultiAgentParkingLotEnv(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py:22-275): 10 agents on a one-lane road with
+    `parking_space_num` spaces at right angles (ParkingLot block) and a T intersection behind it.  An agent entering from
+    one of the three entrances is sent to a parking space no other active agent is heading for and holds it until it is
+    done; an agent starting in a space leaves through a random entrance; an entrance only lets a new agent in while a space
+    is free.  Reversing is on (`enable_reverse`).  Out of road = off the lanes, the yellow line or the sidewalk.
+    `info["parking_space"]`: the space an agent holds (-1: none)."""
+    MAP_DEFAULTS = dict(marl_map="parking_lot", num_agents=10, parking_space_num=8, map_config=dict(exit_length=20, lane_num=1),
+                        vehicle_config=dict(enable_reverse=True))
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)
+
+    def _info(self):
+        info = super()._info()
+        e, A = self.engine, self.num_agents
+        info._lazy["parking_space"] = lambda: e.nav_i[:, :A, 14] - 1       # MdNav.toll_entry
+        return info
+
+
 class BatchedMultiAgentMetaDrive(BatchedMultiAgentRoundaboutEnv):
     """MultiAgentMetaDrive itself (envs/marl_envs/multi_agent_metadrive.py:12-128): 15 agents on an ordinary procedurally
     generated map (one per scenario seed, 3 blocks, 3 lanes), all spawning on the first block's exit road (5 slots x 3

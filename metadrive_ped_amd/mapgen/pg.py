@@ -366,6 +366,7 @@ class Block:
     def construct(self):
         """construct_block: resample parameters, rebuild the topology, merge into the global net."""
         self.config = sample_parameters(self.rng, self.SPACE)
+        self.config.update(getattr(self, "construct_config", {}))   # construct_block(extra_config=...) of the fixed multi-agent maps
         self.clear()
         self.trials += 1
         ok = self.plug()
@@ -1210,6 +1211,31 @@ class MATollGateMap:
     bfs_route = None  # bound below
 
 
+class MAParkingLotMap:
+    """FirstPGBlock (one lane) + ParkingLot (`parking_space_num` / 2 spaces a side) + TInterSection (t_type 1, 10 m exits): the
+    map of MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py:140-180).  `parking_space`: the lot's destination roads."""
+    def __init__(self, lane_num=1, lane_width=3.5, exit_length=20, parking_space_num=8):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        first = FirstBlock(self.net, lane_width, lane_num, exit_length)
+        lot = ParkingLot(1, list(first.sockets.values())[0], self.net, 1)
+        lot.construct_config = {"one_side_vehicle_number": int(parking_space_num / 2)}
+        lot.construct()
+        t = TInterSection(2, list(lot.sockets.values())[0], self.net, 1)
+        t.EXIT_PART_LENGTH = 10
+        t.construct_config = {"t_type": 1, "change_lane_num": 0}
+        t.construct()
+        self.blocks = [first, lot, t]
+        self.parking_lot = lot
+        self.parking_space = list(lot.dest_roads)
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
 class MABidirectionMap:
     """FirstPGBlock + Merge (over 3 m) + Bidirection + Split: the map of MultiAgentBidirectionEnv
     (envs/marl_envs/marl_bidirection.py:28-73): `bottle_lane_num` lanes narrow to one, which both directions share for
@@ -1368,3 +1394,4 @@ MAIntersectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net,
 MABottleneckMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MABidirectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MATollGateMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+MAParkingLotMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

@@ -265,14 +265,15 @@ class MapTables:
 RESPAWN_REGION_LONGITUDE = 8.0  # manager/spawn_manager.py:28
 
 
-def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False):
+def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False, dests=None):
     """Respawn places (slot 0 of every spawn road x lane) and, for each, the route to every destination
     (end node of the reversed spawn roads): SpawnManager._auto_fill_spawn_roads_randomly /
     get_available_respawn_places (manager/spawn_manager.py:123-209), RoundaboutSpawnManager.
     update_destination_for (envs/marl_envs/marl_inout_roundabout.py:136-141)."""
     from metadrive_ped_amd.mapgen.pg import negate_road
     pg = mt.pg_map
-    dests = [negate_road(*r)[1] for r in spawn_roads]
+    if dests is None:
+        dests = [negate_road(*r)[1] for r in spawn_roads]
     if fixed_destination:   # one destination per place: the default of NodeNetworkNavigation.reset
         dests = [None]
     places, lanes, routes, meta = [], [], [], []

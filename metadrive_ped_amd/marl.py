@@ -33,11 +33,24 @@ PG_SPAWN_ROADS = [(">>", ">>>")]
 BIDIRECTION_SPAWN_ROADS = [(">>", ">>>"), negate_road("3Y0_0_", "3Y0_1_")]
 # MATollConfig.spawn_roads (envs/marl_envs/marl_tollgate.py:16): the Merge is block 3 there
 TOLLGATE_SPAWN_ROADS = [(">>", ">>>"), negate_road("3y0_0_", "3y0_1_")]
+# MAParkingLotConfig.in_spawn_roads (envs/marl_envs/marl_parking_lot.py:22-27): the three ways in; the spaces themselves
+# (out direction, ParkingLot.node(1, i, 5) -> node(1, i, 6), :188-192) follow
+PARKING_IN_ROADS = [(">>", ">>>"), negate_road("2T0_0_", "2T0_1_"), negate_road("2T2_0_", "2T2_1_")]
+
+
+def parking_lot_roads(parking_space_num):
+    """(spawn roads, destination nodes): entrances then spaces; destinations = the spaces (in direction: the lot's
+    dest_roads, node(1, i, 1) -> node(1, i, 2)) then the entrances driven the other way (update_destination_for, :80-88)."""
+    out_roads = [("1P{}_5_".format(i), "1P{}_6_".format(i)) for i in range(1, parking_space_num + 1)]
+    dests = ["1P{}_2_".format(i) for i in range(1, parking_space_num + 1)] + [negate_road(*r)[1] for r in PARKING_IN_ROADS]
+    return PARKING_IN_ROADS + out_roads, dests
+
+
 SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS,
-                   bidirection=BIDIRECTION_SPAWN_ROADS, tollgate=TOLLGATE_SPAWN_ROADS)
+                   bidirection=BIDIRECTION_SPAWN_ROADS, tollgate=TOLLGATE_SPAWN_ROADS, parking_lot=parking_lot_roads(8)[0])
 # roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
 # bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)
-FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True, tollgate=True)
+FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True, tollgate=True, parking_lot=False)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 
@@ -45,7 +58,8 @@ REGION_LONG, REGION_LAT = 8.0, 3.0
 class RoundaboutScene:
     """Per-env arrays (cap == num_agents slots, all agents) for one env seed.  `spawn_roads` selects the map
     family (the roundabout's by default); everything else is SpawnManager's and shared."""
-    def __init__(self, seed, mt, cfg, spawn_roads=None, fixed_destination=False):
+    def __init__(self, seed, mt, cfg, spawn_roads=None, fixed_destination=False, parking=None):
+        """`parking`: (number of entrances, number of parking spaces, destination nodes) of the parking-lot env"""
         ROUNDABOUT_SPAWN_ROADS = spawn_roads if spawn_roads is not None else globals()["ROUNDABOUT_SPAWN_ROADS"]
         A = cfg["agents_per_env"]
         cap = cfg["cap"]
@@ -83,6 +97,7 @@ class RoundaboutScene:
             if A == 1:
                 chosen = np.array([0])   # a lone agent takes the FIRST spawn point, whatever was drawn (spawn_manager.py:85-91)
         dests = [negate_road(*r)[1] for r in ROUNDABOUT_SPAWN_ROADS]
+        free_spaces = list(range(parking[1])) if parking else []     # ParkingLotSpawnManager.parking_space_available
         prm, length, width, vcfg = vehicle_param_record(cfg["agent_vehicle_model"], 0, cfg["physics_world_step_size"])
         for a, k in enumerate(chosen):
             road, li, j = spots[int(k)]
@@ -90,7 +105,18 @@ class RoundaboutScene:
             long = REGION_LONG / 2 + j * REGION_LONG + rng.uniform(-(REGION_LONG - MAX_VEHICLE_LENGTH) / 2,
                                                                    (REGION_LONG - MAX_VEHICLE_LENGTH) / 2)
             lat = rng.uniform(-(REGION_LAT - MAX_VEHICLE_WIDTH) / 2, (REGION_LAT - MAX_VEHICLE_WIDTH) / 2)
-            if fixed_destination:
+            space = 0
+            if parking:
+                # ParkingLotSpawnManager.update_destination_for (marl_parking_lot.py:80-88): from an entrance to a parking
+                # space nobody else is heading for, from a space out through one of the entrances
+                n_in, n_space, park_dests = parking
+                if ROUNDABOUT_SPAWN_ROADS.index(road) < n_in:
+                    d = free_spaces.pop(int(rng.randint(len(free_spaces))))
+                    space = d + 1
+                else:
+                    d = n_space + int(rng.randint(n_in))
+                dest = park_dests[d]
+            elif fixed_destination:
                 from metadrive_ped_amd.mapgen.tables import destination_for
                 dest = destination_for(pg, seed, (road[0], road[1], li))
             else:
@@ -110,6 +136,7 @@ class RoundaboutScene:
             nv["lane"] = mt.lane_id[(road[0], road[1], li)]
             nv["ck0"], nv["ck1"] = (0, 1) if n > 2 else (0, 0)
             nv["route_len"] = n
+            nv["toll_entry"] = space     # parking-lot env: the space this agent holds (+1), see md_lifecycle_env
         # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
         self.shape["hl"][:A], self.shape["hw"][:A] = length / 2, width / 2
         self.param[:] = prm

@@ -614,6 +614,54 @@ def section_ma_tollgate():
                                   map_config=dict(mc), episodes=episodes))
 
 
+def section_ma_parking_lot():
+    """Map of MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py:140-180): FirstPGBlock (20 m, one lane) + ParkingLot
+    (4 spaces a side) + TInterSection (t_type 1, exits 10 m); its parking spaces (destination roads), the spawn roads (three
+    entrances + the eight spaces, out direction) and the shortest path from every spawn road to every destination."""
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.parking_lot import ParkingLot
+    from metadrive.component.pgblock.t_intersection import TInterSection
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs import marl_parking_lot as mp
+    from metadrive.manager.spawn_manager import SpawnManager
+    cfg = mp.MAParkingLotConfig
+    mc = cfg["map_config"]
+    n_space = cfg["parking_space_num"]
+    net = NodeRoadNetwork()
+    first = FirstPGBlock(net, 3.5, mc["lane_num"], MagicMock(), MagicMock(), length=mc["exit_length"])
+    lot = ParkingLot(1, first.get_socket(0), net, 1, ignore_intersection_checking=False)
+    ok1 = lot.construct_block(MagicMock(), MagicMock(), {"one_side_vehicle_number": int(n_space / 2)})
+    old = TInterSection.EXIT_PART_LENGTH
+    TInterSection.EXIT_PART_LENGTH = 10
+    try:
+        t = TInterSection(2, lot.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False)
+        ok2 = t.construct_block(MagicMock(), MagicMock(), extra_config={"t_type": 1, "change_lane_num": 0})
+    finally:
+        TInterSection.EXIT_PART_LENGTH = old
+    roads = []
+    for f, td in net.graph.items():
+        for tt, lanes in td.items():
+            roads.append(dict(start=f, end=tt, lanes=[lane_record(l) for l in lanes]))
+    in_roads = cfg["in_spawn_roads"]
+    out_roads = mp.MultiAgentParkingLotEnv._get_out_spawn_roads(n_space)
+    dests = [r.end_node for r in lot.dest_roads] + [(-r).end_node for r in in_roads]
+    routes = []
+    for sr in in_roads + out_roads:
+        for d in dests:
+            routes.append(dict(start=[sr.start_node, sr.end_node], dest=d,
+                               path=net.shortest_path((sr.start_node, sr.end_node, 0), d)))
+    dump("ma_parking_lot.json", dict(
+        no_cross=bool(ok1 and ok2), roads=roads, in_spawn_roads=[[r.start_node, r.end_node] for r in in_roads],
+        out_spawn_roads=[[r.start_node, r.end_node] for r in out_roads],
+        parking_space=[[r.start_node, r.end_node] for r in lot.dest_roads],
+        in_direction_of_out=[[x.start_node, x.end_node] for x in (ParkingLot.in_direction_parking_space(r) for r in out_roads)],
+        routes=routes, num_agents=int(cfg["num_agents"]), parking_space_num=int(n_space), map_config=dict(mc),
+        enable_reverse=bool(cfg["vehicle_config"]["enable_reverse"]),
+        max_capacity=int(SpawnManager.max_capacity(in_roads + out_roads, mc["exit_length"], mc["lane_num"])),
+        lot_config={k: float(v) for k, v in dict(lot.get_config()).items()},
+        t_config={k: float(v) for k, v in dict(t.get_config()).items()}))
+
+
 def section_ma_bidirection():
     """Map of MultiAgentBidirectionEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 3 m) +
     Bidirection (one lane shared by both directions, seed 1) + Split (back to 4, exit 60 m) as MABidirectionMap._generate
@@ -1314,7 +1362,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

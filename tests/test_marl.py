@@ -826,3 +826,137 @@ def test_tollgate_rollout_parity_gpu():
     assert_state_equal(eng.download_state(), orc.state, where="tollgate final")
     nv = orc.state["nav"].reshape(E, -1)[:, :A]
     assert (orc.state["next_agent_id"] > A).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py)
+# ------------------------------------------------------------------------------------------------
+def _park_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentParkingLotEnv
+    base = dict(num_envs=3, num_scenarios=3)
+    base.update(kw)
+    return BatchedMultiAgentParkingLotEnv(base).config
+
+
+def test_parking_lot_map_equals_reference():
+    """MAParkingLotMap._generate of the reference: every lane of the 106 roads, the parking spaces (destination roads), the
+    spawn roads (entrances + spaces, out direction), and the shortest path from every spawn road to every destination."""
+    from metadrive_ped_amd.mapgen.pg import MAParkingLotMap
+    from metadrive_ped_amd.marl import PARKING_IN_ROADS, parking_lot_roads
+    with open(os.path.join(GOLDEN, "ma_parking_lot.json")) as f:
+        g = json.load(f)
+    m = MAParkingLotMap()
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]
+    for (a, b, lanes), ref in zip(roads, g["roads"]):
+        assert len(lanes) == len(ref["lanes"])
+        for l, rl in zip(lanes, ref["lanes"]):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+            np.testing.assert_allclose([l.length, *l.start, *l.end], [rl["length"], *rl["start"], *rl["end"]], atol=1e-9)
+    spawn_roads, dests = parking_lot_roads(g["parking_space_num"])
+    assert [list(r) for r in PARKING_IN_ROADS] == g["in_spawn_roads"]
+    assert [list(r) for r in spawn_roads] == g["in_spawn_roads"] + g["out_spawn_roads"]
+    assert [list(r) for r in m.parking_space] == g["parking_space"] == g["in_direction_of_out"]
+    assert dests[:8] == [r[1] for r in g["parking_space"]] and len(dests) == 11
+    assert sorted({r["dest"] for r in g["routes"]}) == sorted(dests)
+    for r in g["routes"]:
+        assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    for k, v in g["lot_config"].items():
+        assert float(m.blocks[1].config[k]) == v
+    for k, v in g["t_config"].items():
+        assert float(m.blocks[2].config[k]) == v
+    d = _park_cfg()
+    assert d["num_agents"] == g["num_agents"] == 10 and d["parking_space_num"] == g["parking_space_num"] == 8
+    assert g["max_capacity"] == 11 and d["vehicle_config"]["enable_reverse"] is g["enable_reverse"] is True
+    for k, v in g["map_config"].items():
+        assert d["map_config"][k] == v
+
+
+def test_parking_lot_env_on_oracle():
+    """ParkingLotSpawnManager's bookkeeping (marl_parking_lot.py:47-132) on the oracle: an agent that enters from outside
+    holds a parking space nobody else holds and its route ends in that space; an agent that starts in a space drives out
+    to an entrance; with every space taken the entrances stay shut."""
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 3, 10
+    host = HostScene(_park_cfg(num_envs=E, num_scenarios=E, delay_done=3))
+    assert host.cap == A and host.obs_dim == 19 + 72 and host.spawn["n_dest"] == 11 and len(host.spawn["spawn_lane"]) == 11
+    t = host.map_tables[0]
+    space_end = [t.node_index["1P{}_2_".format(i)] for i in range(1, 9)]
+    exits = {t.node_index[n] for n in ("->>", "2T0_1_", "2T2_1_")}
+    entrance_lanes = {t.lane_id[(">>", ">>>", 0)], t.lane_id[("-2T0_1_", "-2T0_0_", 0)], t.lane_id[("-2T2_1_", "-2T2_0_", 0)]}
+    o = ob.OracleWorld(host)
+    o.reset()
+    rng = np.random.RandomState(4)
+    seen_in = seen_out = 0
+    for step in range(700):
+        nv = o.state["nav"].reshape(E, -1)
+        sh = o.state["shape"].reshape(E, -1)
+        rn = o.state["route_nodes"].reshape(E, A, -1)
+        act = (sh["flags"] & (abi.F_ALIVE | abi.F_STATIC)) == abi.F_ALIVE
+        for e in range(E):
+            held = [int(x) for x, ok in zip(nv["toll_entry"][e], act[e]) if ok and x > 0]
+            assert len(held) == len(set(held)), (step, e, held)
+            for a in range(A):
+                if not act[e, a]:
+                    continue
+                last = int(rn[e, a, nv["route_len"][e, a] - 1])
+                if nv["toll_entry"][e, a] > 0:
+                    assert last == space_end[nv["toll_entry"][e, a] - 1]
+                    seen_in += 1
+                else:
+                    assert last in exits
+                    seen_out += 1
+                if nv["steps"][e, a] == 0 and step > 0:      # just respawned
+                    assert (nv["lane"][e, a] in entrance_lanes) == (nv["toll_entry"][e, a] > 0)
+        a_ = np.zeros((E, A, 2), np.float32)
+        a_[..., 1] = rng.uniform(-0.3, 0.8, (E, A))          # reversing allowed
+        a_[..., 0] = rng.uniform(-0.4, 0.4, (E, A))
+        o.step(a_)
+    assert seen_in > 500 and seen_out > 500 and (o.state["next_agent_id"] > A + 5).all()
+
+    # every space taken -> nobody is let in through an entrance
+    o2 = ob.OracleWorld(host)
+    o2.reset()
+    nv = o2.state["nav"].reshape(E, -1)
+    sh = o2.state["shape"].reshape(E, -1)
+    for e in range(E):
+        for a in range(8):
+            nv["toll_entry"][e, a] = a + 1
+        for a in (8, 9):                                    # two free slots to refill
+            sh["flags"][e, a] &= ~abi.F_ALIVE
+    # park the agents far away from every spawn place so that all 11 places are physically clear
+    for e in range(E):
+        for a in range(8):
+            sh["cx"][e, a], sh["cy"][e, a] = 500.0 + 10 * a, 500.0
+    before = o2.state["next_agent_id"].copy()
+    o2.call("ref_lifecycle")
+    nv = o2.state["nav"].reshape(E, -1)
+    sh = o2.state["shape"].reshape(E, -1)
+    for e in range(E):
+        new = [a for a in (8, 9) if sh["flags"][e, a] & abi.F_ALIVE]
+        assert len(new) == 1 and o2.state["next_agent_id"][e] == before[e] + 1     # one respawn per step
+        assert nv["lane"][e, new[0]] not in entrance_lanes and nv["toll_entry"][e, new[0]] == 0
+
+
+@pytest.mark.gpu
+def test_parking_lot_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 6, 10
+    eng = BatchedEngine(_park_cfg(num_envs=E, num_scenarios=E, delay_done=5))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="parking lot reset")
+    rng = np.random.RandomState(21)
+    for t in range(500):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = rng.uniform(-0.3, 0.8, (E, A))
+        a[..., 0] = rng.uniform(-0.4, 0.4, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="parking lot step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="parking lot final")
+    assert (orc.state["next_agent_id"] > A + 3).all()
