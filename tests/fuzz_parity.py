@@ -45,7 +45,7 @@ def draw(rng):
 
 def draw_marl(rng):
     pick = lambda *xs: xs[int(rng.randint(len(xs)))]
-    kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg")
+    kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg", "tollgate", "parking_lot")
     cfg = dict(num_envs=int(pick(1, 4, 9)), start_seed=int(rng.randint(0, 500)), horizon=int(pick(60, 200, 1000)),
                num_agents=int(pick(1, 3, 8, 12, -1)), delay_done=int(pick(0, 5, 25)), allow_respawn=bool(rng.randint(4) > 0),
                crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0),
@@ -59,6 +59,15 @@ def draw_marl(rng):
         cfg["num_agents"] = min(cfg["num_agents"], 12) if cfg["num_agents"] > 0 else -1
     if kind in ("bottleneck", "bidirection"):
         cfg["map_config"]["lane_num"] = int(pick(3, 4))
+    if kind == "tollgate":
+        cfg["map_config"] = dict(exit_length=int(pick(40, 70)), lane_num=int(pick(2, 3)), toll_lane_num=int(pick(6, 8)))
+        cfg["vehicle_config"]["min_pass_steps"] = int(pick(5, 30))
+        cfg["cross_yellow_line_done"] = bool(rng.randint(2))
+        cfg["overspeed_penalty"] = float(pick(0.5, 2.0))
+    if kind == "parking_lot":
+        cfg["map_config"] = dict(exit_length=int(pick(20, 30)), lane_num=1)
+        cfg["parking_space_num"] = int(pick(4, 8, 12))
+        cfg["num_agents"] = int(pick(1, 3, 6, 10))
     return kind, cfg
 
 
@@ -81,7 +90,8 @@ def main():
                 kind, user = draw_marl(rng)
                 cls = dict(roundabout=M.BatchedMultiAgentRoundaboutEnv, intersection=M.BatchedMultiAgentIntersectionEnv,
                            bottleneck=M.BatchedMultiAgentBottleneckEnv, bidirection=M.BatchedMultiAgentBidirectionEnv,
-                           pg=M.BatchedMultiAgentMetaDrive)[kind]
+                           pg=M.BatchedMultiAgentMetaDrive, tollgate=M.BatchedMultiAgentTollgateEnv,
+                           parking_lot=M.BatchedMultiAgentParkingLotEnv)[kind]
                 cfg = cls(user).config
                 user = dict(user, marl_map=kind)
             else:

@@ -80,11 +80,16 @@ def main_marl():
     from helpers import assert_state_equal
     from metadrive_ped_amd.engine import BatchedEngine
     from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,
-                                                 BatchedMultiAgentRoundaboutEnv)
+                                                 BatchedMultiAgentParkingLotEnv, BatchedMultiAgentRoundaboutEnv,
+                                                 BatchedMultiAgentTollgateEnv)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     E = 48
+    only = os.environ.get("SOAK_ONLY", "")          # e.g. SOAK_ONLY=Tollgate,ParkingLot
     for cls, extra in ((BatchedMultiAgentRoundaboutEnv, {}), (BatchedMultiAgentIntersectionEnv, {}), (BatchedMultiAgentBottleneckEnv, {}),
-                       (BatchedMultiAgentRoundaboutEnv, dict(num_agents=-1, map_config=dict(exit_length=40, lane_num=2)))):
+                       (BatchedMultiAgentRoundaboutEnv, dict(num_agents=-1, map_config=dict(exit_length=40, lane_num=2))),
+                       (BatchedMultiAgentTollgateEnv, {}), (BatchedMultiAgentParkingLotEnv, {})):
+        if only and not any(k in cls.__name__ for k in only.split(",")):
+            continue
         cfg = cls(dict(dict(num_envs=E, num_scenarios=E), **extra)).config
         eng = BatchedEngine(cfg)
         A = eng.A
@@ -110,5 +115,6 @@ def main_marl():
 
 
 if __name__ == "__main__":
-    main()
+    if not os.environ.get("SOAK_ONLY"):
+        main()
     main_marl()
