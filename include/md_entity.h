@@ -46,6 +46,7 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.dyn0 = g->dyn0 ? g->dyn0 + b : 0;
     v.nav0 = g->nav0 ? g->nav0 + b : 0;
     v.pid0 = g->pid0 ? g->pid0 + b : 0;
+    v.param0 = g->param0 ? g->param0 + b : 0;
     v.route_nodes0 = g->route_nodes0 ? g->route_nodes0 + b * MD_ROUTE_LEN : 0;
     v.route_roads0 = g->route_roads0 ? g->route_roads0 + b * MD_ROUTE_LEN : 0;
     v.final_lane0 = g->final_lane0 ? g->final_lane0 + b : 0;
@@ -971,6 +972,16 @@ MD_HD void md_traffic_respawn_env(const MdWorld* w, const MdLane* lanes, const M
     }
 }
 
+/* a (re)spawned agent of a multi-agent env with random_agent_model: one of the vehicle classes, uniformly
+ * (VehicleAgentManager._create_agents -> random_vehicle_type, manager/agent_manager.py:37-43) */
+MD_HD void md_draw_vehicle_class(const MdWorld* w, const MdState* s, int slot) {
+    const float* v = w->vclass + 12 * (size_t)(md_rng_next(s->rng) % (uint32_t)w->n_vclass);
+    float* prm = (float*)&s->param[slot];
+    for (int i = 0; i < 8; ++i) prm[i] = v[i];
+    s->shape[slot].hl = v[8];
+    s->shape[slot].hw = v[9];
+}
+
 MD_HD int md_popcount32(uint32_t v) {
     int n = 0;
     for (; v; v &= v - 1) ++n;
@@ -1091,6 +1102,7 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
             nav->done = 0;
             nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
             nav->toll_entry = space;
+            if (c->random_agent_model && w->n_vclass > 0) md_draw_vehicle_class(w, s, slot);
             s->final_lane[slot] = w->spawn_route_meta[2 * ri + 1];
             for (int k = 0; k < MD_ROUTE_LEN; ++k) {
                 s->route_nodes[(size_t)slot * MD_ROUTE_LEN + k] = rt[k];

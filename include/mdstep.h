@@ -253,7 +253,7 @@ typedef struct MdWorld {
     const int32_t* spawn_route;/* [n_places][n_dest][2][MD_ROUTE_LEN]: checkpoint nodes, then roads */
     const int32_t* spawn_route_meta; /* [n_places][n_dest][2]: route_len, final_lane              */
     int32_t n_dest;            /* destinations per spawn place                                   */
-    int32_t pad0;
+    int32_t n_vclass;          /* entries of vclass (0 = respawned agents keep the slot's vehicle) */
     /* scenario mode (traffic_mode 4; NULL otherwise): polylines per mover slot, the SDC route's checkpoints */
     const int32_t* poly_off;   /* [n_envs * cap + 1] CSR into segs: slot 0 = the SDC's reference trajectory
                                   (ScenarioMapManager.current_sdc_route, manager/scenario_map_manager.py:49-63), slot j = the
@@ -265,13 +265,18 @@ typedef struct MdWorld {
     const int32_t* ckpt_off;   /* [n_envs + 1] CSR into ckpt_xy: TrajectoryNavigation.checkpoints (trajectory_navigation.py:96-103) */
     const float* ckpt_xy;      /* [n_ckpt][2]                                                    */
     const int32_t* track_meta; /* [n_envs * cap][4]: t0, t1, MD_TM_* bits, 0                       */
+    /* multi-agent + random_agent_model: the vehicle classes a (re)spawned agent is drawn from, uniformly
+     * (random_vehicle_type, component/vehicle/vehicle_type.py:269-281): [n_vclass][12] = MdParam (8 floats), half length,
+     * half width, 0, 0 */
+    const float* vclass;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */
 typedef struct MdState {
     MdShape* shape;
     MdDyn* dyn;
-    const MdParam* param;
+    MdParam* param;            /* constant per slot, except multi-agent envs with random_agent_model: a respawn draws a new
+                                  vehicle class (VehicleAgentManager._create_agents, manager/agent_manager.py:37-43) */
     MdNav* nav;
     MdPid* pid;
     float* action;             /* [N][2] steering, throttle_brake in [-1,1] (agents: caller-written) */
@@ -318,6 +323,7 @@ typedef struct MdState {
     /* optional: work space of the phase-per-launch step (MdConfig.step_kernel 2): [2 * N + 4 * n_envs] uint32 owned by the
      * caller like every other array; contents are meaningless between calls.  NULL = that mode is not available. */
     uint32_t* scratch;
+    const MdParam* param0;     /* reset snapshot of `param` (multi-agent + random_agent_model only; NULL otherwise) */
 } MdState;
 
 typedef struct MdConfig {

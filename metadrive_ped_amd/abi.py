@@ -83,8 +83,8 @@ class MdWorld(C.Structure):
         ("node_adj_off", P), ("node_adj", P), ("node_off", P), ("beam_cs", P),
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
-        ("n_dest", C.c_int32), ("pad0", C.c_int32),
-        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P),
+        ("n_dest", C.c_int32), ("n_vclass", C.c_int32),
+        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P),
     ]
 
 
@@ -100,6 +100,7 @@ class MdState(C.Structure):
         ("track_dyn", P),
         ("detected", P),
         ("scratch", P),
+        ("param0", P),
     ]
 
 

@@ -205,9 +205,6 @@ def make_config(user=None):
     if cfg["is_multi_agent"] and abs(cfg["traffic_density"]) >= 1e-2:
         raise NotImplementedError("traffic_density > 0 in a multi-agent env is not built (the reference's multi-agent "
                                   "envs run without traffic: multi_agent_metadrive.py:58)")
-    if cfg["is_multi_agent"] and cfg["random_agent_model"]:
-        raise NotImplementedError("random_agent_model in a multi-agent env is not built (a respawn would have to draw a "
-                                  "new vehicle class on the device)")
     if cfg["is_multi_agent"] and cfg["random_dynamics"]:
         raise NotImplementedError("random_dynamics: 'Only supporting single-agent now!' (varying_dynamics_env.py:46)")
     if cfg["random_dynamics"]:

@@ -1067,6 +1067,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                     nav->done = 0;
                     nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
                     nav->toll_entry = space;
+                    if (c.random_agent_model && w.n_vclass > 0) md_draw_vehicle_class(&w, &s, slot);
                     s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
                     for (int q = 0; q < MD_ROUTE_LEN; ++q) {
                         s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
@@ -1267,6 +1268,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         copy16(l_dyn, gv.dyn0, cap * (int)sizeof(MdDyn), tid, kBlock);
         copy16(l_nav, gv.nav0, cap * (int)sizeof(MdNav), tid, kBlock);
         copy16(l_pid, gv.pid0, cap * (int)sizeof(MdPid), tid, kBlock);
+        if (MULTI && c.random_agent_model && gv.param0)   // respawns drew new vehicle classes: back to the reset ones
+            copy16(l_param, gv.param0, cap * (int)sizeof(MdParam), tid, kBlock);
         for (int j = tid; j < cap; j += kBlock) {
             l_action[2 * j] = 0.0f;
             l_action[2 * j + 1] = 0.0f;
@@ -1489,6 +1492,8 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             return;
         }
         if (PH & (PH_RESET | PH_IDM | PH_INTEGRATE | PH_TRAFFIC | PH_OBSERVE | PH_LIFECYCLE)) copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+        if (MULTI && (PH & (PH_RESET | PH_LIFECYCLE)) && c.random_agent_model && c.is_multi_agent)
+            copy16(gv.param, l_param, cap * (int)sizeof(MdParam), tid, kBlock);   // a respawn / reset rewrote vehicle classes
         if ((PH & (PH_RESET | PH_INTEGRATE | PH_LIFECYCLE)) || respawns) copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
         if ((PH & (PH_RESET | PH_IDM | PH_LOCALIZE | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.nav, l_nav, cap * (int)sizeof(MdNav), tid, kBlock);
         if ((PH & (PH_RESET | PH_IDM | PH_OBSERVE | PH_LIFECYCLE)) || respawns) copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);

@@ -258,6 +258,10 @@ class HostScene:
             st["final_lane0"] = st["final_lane"].copy()
             # xorshift32 needs a non-zero state; derive it from the env's scenario seed
             st["rng"] = np.asarray([((s * 2654435761) ^ 0x9E3779B9) & 0xFFFFFFFF or 1 for s in seeds], np.uint32)
+        if cfg["is_multi_agent"] and cfg["random_agent_model"]:
+            from metadrive_ped_amd.marl import vehicle_class_table
+            st["param0"] = st["param"].copy()
+            self.world.arrays["vclass"] = vehicle_class_table(cfg["physics_world_step_size"])
         if cfg["is_multi_agent"]:
             st["env_steps"] = np.zeros(E, np.int32)
             st["agent_id"] = np.tile(np.arange(cap, dtype=np.int32), E)
@@ -329,6 +333,7 @@ def make_structs(world_arrays, state_arrays, md_config, n_maps, n_envs, ptr_of):
     w.max_lanes = int(np.diff(lane_off).max())
     w.max_roads = int(np.diff(road_off).max())
     w.n_dest = int(world_arrays.get("n_dest_host", 0))
+    w.n_vclass = int(world_arrays.get("n_vclass_host", 0))
     s = abi.MdState()
     abi.fill_struct(s, abi.STATE_FIELDS, state_arrays, ptr_of)
     return w, s, md_config
@@ -386,6 +391,7 @@ class BatchedEngine:
         wd = dict(self.world_dev)
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
         wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else (1 if h.traffic_respawns else 0)
+        wd["n_vclass_host"] = len(h.world.arrays["vclass"]) if "vclass" in h.world.arrays else 0
         self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         self._side_beams = self._to_dev(h.side_beams) if h.side_beams is not None else None
         self._ll_beams = self._to_dev(h.ll_beams) if h.ll_beams is not None else None

@@ -58,7 +58,8 @@ class BatchedMultiAgentRoundaboutEnv:
         n_l = vc["lane_line_detector"]["num_lasers"] if vc["lane_line_detector"]["distance"] > 0 else 0
         n_o = lidar["num_others"] * (8 if lidar["add_others_navi"] else 4) if n > 0 else 0
         toll = self.config["marl_map"] == "tollgate"     # no navigation dims, two toll dims after the cloud
-        self.observation_space = Box(-0.0, 1.0, ((n_s or 2) + 6 + (n_l or 1) + (0 if toll else 10) + n_o + n + (2 if toll else 0), ),
+        base = 2 if self.config["random_agent_model"] else 0     # [length, width] lead the observation (state_obs.py:70-75)
+        self.observation_space = Box(-0.0, 1.0, (base + (n_s or 2) + 6 + (n_l or 1) + (0 if toll else 10) + n_o + n + (2 if toll else 0), ),
                                      np.float32)
         from metadrive_ped_amd.envs.metadrive_env import make_action_space
         self.action_space = make_action_space(self.config)

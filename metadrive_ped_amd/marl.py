@@ -55,6 +55,16 @@ MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / M
 REGION_LONG, REGION_LAT = 8.0, 3.0
 
 
+def vehicle_class_table(dt):
+    """[5][12] float32: MdParam (8 floats), half length, half width, 0, 0 of the classes random_vehicle_type draws from
+    (component/vehicle/vehicle_type.py:269-281), in its order."""
+    rows = []
+    for name in ("s", "m", "l", "xl", "default"):
+        prm, length, width, _ = vehicle_param_record(name, 0, dt)
+        rows.append(list(np.frombuffer(prm.tobytes(), np.float32)) + [length / 2, width / 2, 0.0, 0.0])
+    return np.asarray(rows, np.float32)
+
+
 class RoundaboutScene:
     """Per-env arrays (cap == num_agents slots, all agents) for one env seed.  `spawn_roads` selects the map
     family (the roundabout's by default); everything else is SpawnManager's and shared."""
@@ -99,6 +109,8 @@ class RoundaboutScene:
         dests = [negate_road(*r)[1] for r in ROUNDABOUT_SPAWN_ROADS]
         free_spaces = list(range(parking[1])) if parking else []     # ParkingLotSpawnManager.parking_space_available
         prm, length, width, vcfg = vehicle_param_record(cfg["agent_vehicle_model"], 0, cfg["physics_world_step_size"])
+        classes = vehicle_class_table(cfg["physics_world_step_size"]) if cfg.get("random_agent_model") else None
+        self.param[:] = prm
         for a, k in enumerate(chosen):
             road, li, j = spots[int(k)]
             lane = pg.net.lanes(*road)[li]
@@ -130,6 +142,10 @@ class RoundaboutScene:
             d = self.dyn[a]
             d["heading"], d["last_x"], d["last_y"], d["last_c"], d["last_s"] = h, pos[0], pos[1], sh["c"], sh["s"]
             self.param[a] = prm
+            if classes is not None:     # random_agent_model: every agent its own class (agent_manager.py:41)
+                v = classes[int(rng.randint(len(classes)))]
+                self.param[a] = v[:8].view(abi.PARAM_DT)[0]
+                sh["hl"], sh["hw"] = v[8], v[9]
             nodes, roads, n, fin = route_arrays(mt, (road[0], road[1], li), dest)
             self.route_nodes[a], self.route_roads[a], self.final_lane[a] = nodes, roads, fin
             nv = self.nav[a]
@@ -138,8 +154,8 @@ class RoundaboutScene:
             nv["route_len"] = n
             nv["toll_entry"] = space     # parking-lot env: the space this agent holds (+1), see md_lifecycle_env
         # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
-        self.shape["hl"][:A], self.shape["hw"][:A] = length / 2, width / 2
-        self.param[:] = prm
+        for a in range(len(chosen), A):
+            self.shape["hl"][a], self.shape["hw"][a] = length / 2, width / 2
         for a in range(len(chosen), A):
             self.shape[a]["flags"] = abi.KIND_VEHICLE      # a free agent slot: what the lifecycle hands to the next spawn
         # static bodies of the map (toll booths): slots from the top, like the props of the single-agent scenes

@@ -360,6 +360,8 @@ static void step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int 
             memcpy(&s->route_roads[(size_t)base * MD_ROUTE_LEN], &s->route_roads0[(size_t)base * MD_ROUTE_LEN], sizeof(int32_t) * MD_ROUTE_LEN * c->cap);
             memcpy(&s->final_lane[base], &s->final_lane0[base], sizeof(int32_t) * c->cap);
         }
+        if (c->is_multi_agent && c->random_agent_model && s->param0) /* respawns draw new vehicle classes */
+            memcpy(&s->param[base], &s->param0[base], sizeof(MdParam) * c->cap);
         if (c->is_multi_agent) {
             s->env_steps[e] = 0;
             /* names agent0 .. agent{n-1} are taken by the agents present at reset (all slots, or with num_agents = -1

@@ -48,7 +48,7 @@ def draw_marl(rng):
     kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg", "tollgate", "parking_lot")
     cfg = dict(num_envs=int(pick(1, 4, 9)), start_seed=int(rng.randint(0, 500)), horizon=int(pick(60, 200, 1000)),
                num_agents=int(pick(1, 3, 8, 12, -1)), delay_done=int(pick(0, 5, 25)), allow_respawn=bool(rng.randint(4) > 0),
-               crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0),
+               crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0), random_agent_model=bool(rng.randint(4) == 0),
                map_config=dict(exit_length=int(pick(30, 50, 60)), lane_num=int(pick(2, 3))))
     cfg["num_scenarios"] = int(pick(1, cfg["num_envs"]))
     beams = int(pick(0, 30, 72))

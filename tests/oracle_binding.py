@@ -105,6 +105,7 @@ class OracleWorld:
         wa = dict(host.world.arrays)
         wa["lane_off_host"], wa["road_off_host"] = wa["lane_off"], wa["road_off"]
         wa["n_dest_host"] = host.spawn["n_dest"] if host.spawn is not None else (1 if host.traffic_respawns else 0)
+        wa["n_vclass_host"] = len(host.world.arrays["vclass"]) if "vclass" in host.world.arrays else 0
         self.w, self.s, self.k = make_structs(wa, self.state, host.md_config, host.world.n_maps, host.E, _ptr)
 
     def call(self, name, *extra):

@@ -960,3 +960,76 @@ def test_parking_lot_rollout_parity_gpu():
             assert_state_equal(eng.download_state(), orc.state, where="parking lot step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="parking lot final")
     assert (orc.state["next_agent_id"] > A + 3).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# random_agent_model in the multi-agent envs (manager/agent_manager.py:37-43: every created agent, at reset and at
+# every respawn, is one of the five vehicle classes)
+# ------------------------------------------------------------------------------------------------
+def test_marl_random_agent_model_on_oracle():
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.marl import vehicle_class_table
+    E, A = 2, 8
+    host = HostScene(_marl_cfg(num_envs=E, num_scenarios=E, num_agents=A, random_agent_model=True, delay_done=2))
+    assert host.obs_dim == 2 + 19 + 72               # [length, width] lead the observation
+    table = vehicle_class_table(0.02)
+    dims = {(float(r[8]), float(r[9])) for r in table}
+    assert len(dims) == 5
+    o = ob.OracleWorld(host)
+    o.reset()
+    sh0 = o.state["shape"].reshape(E, -1).copy()
+    p0 = o.state["param"].copy()
+    assert {(float(a), float(b)) for a, b in zip(sh0["hl"].ravel(), sh0["hw"].ravel())} <= dims
+    rng = np.random.RandomState(1)
+    seen = set()
+    for t in range(500):
+        a = rng.uniform(-1, 1, (E, A, 2)).astype(np.float32)
+        a[..., 1] = np.abs(a[..., 1])
+        o.step(a)
+        sh = o.state["shape"].reshape(E, -1)
+        obs = o.state["obs"].reshape(E, A, -1)
+        act = (sh["flags"] & (abi.F_ALIVE | abi.F_STATIC)) == abi.F_ALIVE
+        for e in range(E):
+            for k in range(A):
+                cls = (float(sh["hl"][e, k]), float(sh["hw"][e, k]))
+                assert cls in dims
+                seen.add(cls)
+                if act[e, k]:
+                    # state_obs.py:70-75: LENGTH / MAX_LENGTH, WIDTH / MAX_WIDTH, and the parameters are the class's own
+                    np.testing.assert_allclose(obs[e, k, :2], [2 * cls[0] / 10.0, 2 * cls[1] / 2.5], rtol=1e-6)
+                    row = [r for r in table if (float(r[8]), float(r[9])) == cls][0]
+                    assert np.frombuffer(o.state["param"].reshape(E, -1)[e, k].tobytes(), np.float32).tolist() == row[:8].tolist()
+    assert len(seen) == 5 and (o.state["next_agent_id"] > A + 20).all()
+    # an env reset brings back the classes drawn at reset
+    o.state["need_reset"][:] = 1
+    o.step(np.zeros((E, A, 2), np.float32))
+    sh = o.state["shape"].reshape(E, -1)
+    assert (sh["hl"] == sh0["hl"]).all() and (sh["hw"] == sh0["hw"]).all() and (o.state["param"] == p0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["roundabout", "parking_lot"])
+def test_marl_random_agent_model_rollout_parity_gpu(kind):
+    import torch
+    from helpers import STATE_KEYS_EXACT, assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    keys = STATE_KEYS_EXACT + ["param"]           # respawns rewrite the vehicle parameters too
+    E = 5
+    cfg = _marl_cfg(num_envs=E, num_scenarios=E, num_agents=12, random_agent_model=True, delay_done=3, horizon=150) \
+        if kind == "roundabout" else _park_cfg(num_envs=E, num_scenarios=E, random_agent_model=True, delay_done=3, horizon=150)
+    eng = BatchedEngine(cfg)
+    A = eng.A
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where=kind + " reset")
+    rng = np.random.RandomState(8)
+    for t in range(400):                         # crosses the horizon: the env reset restores the reset-time classes
+        a = rng.uniform(-1, 1, (E, A, 2)).astype(np.float32)
+        a[..., 1] = np.abs(a[..., 1]) * 0.8
+        a[..., 0] *= 0.3
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 20 == 0:
+            assert_state_equal(eng.download_state(), orc.state, keys=keys, where="%s random models step %d" % (kind, t))
+    assert_state_equal(eng.download_state(), orc.state, keys=keys, where=kind + " final")

@@ -388,9 +388,7 @@ def test_random_agent_model_obs_and_types():
     for e, t in enumerate(types):
         if t == "default":
             assert np.array_equal(obs[e, 2:], plain.obs[e, :])
-    with pytest.raises(NotImplementedError):
-        from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
-        BatchedMultiAgentRoundaboutEnv(dict(random_agent_model=True))
+
 
 
 @pytest.mark.parametrize("steering", [-0.01, 0.01])
