@@ -145,28 +145,39 @@ MD_HD void md_traj_locate(const MdPoly* p, float px, float py, MdTrajLoc* o) {
 }
 
 /* the 22 navigation dims.  ckpt = the env's checkpoint table (n_ckpt >= 1 points). */
-MD_HD void md_traj_navi(const float* ckpt, int n_ckpt, const MdTrajLoc* L, float px, float py, float hc, float hs,
-                        float heading, float max_lateral_dist, float* out22) {
+MD_HD int md_traj_next_idx(const MdTrajLoc* L, int n_ckpt) {
     int next_idx = (int)(L->lng / MD_TRAJ_DISCRETE_LEN) + 1;   /* int() truncates towards zero, like the C cast */
     if (next_idx < 0) next_idx = 0;
     if (next_idx > n_ckpt - 1) next_idx = n_ckpt - 1;
-    for (int i = 0; i < MD_TRAJ_NAVI_DIM; ++i) out22[i] = 0.0f;
-    for (int k = 0; k < MD_TRAJ_NUM_WAY_POINT - 1; ++k) {   /* ckpts[1:]: the first of the ten is skipped */
-        int idx = next_idx + 1 + k;
-        if (idx > n_ckpt - 1) idx = n_ckpt - 1;   /* padded with the last checkpoint */
-        float dx = ckpt[2 * idx] - px, dy = ckpt[2 * idx + 1] - py;
-        float dn = md_norm(dx, dy);
-        if (dn > MD_TRAJ_NAVI_POINT_DIST) {
-            dx = dx / dn * MD_TRAJ_NAVI_POINT_DIST;
-            dy = dy / dn * MD_TRAJ_NAVI_POINT_DIST;
-        }
-        float fwd = dx * hc + dy * hs;   /* convert_to_local_coordinates: (forward, left), SURVEY 8a-5 */
-        float a = md_clip((fwd / MD_TRAJ_NAVI_POINT_DIST + 1.0f) / 2.0f, 0.0f, 1.0f);
-        /* trajectory_navigation.py:134: `self._navi_info[start:end], lanes_heading = [a, b]` unpacks the two-element
-         * list, so BOTH slots of the way point receive the heading-projection value a */
-        out22[2 * k] = a;
-        out22[2 * k + 1] = a;
+    return next_idx;
+}
+
+/* way point k (0 .. MD_TRAJ_NUM_WAY_POINT - 2; ckpts[1:]: the first of the ten is skipped): the value BOTH of its slots
+ * receive -- trajectory_navigation.py:134: `self._navi_info[start:end], lanes_heading = [a, b]` unpacks the two-element list */
+MD_HD float md_traj_navi_point(const float* ckpt, int n_ckpt, int next_idx, int k, float px, float py, float hc, float hs) {
+    int idx = next_idx + 1 + k;
+    if (idx > n_ckpt - 1) idx = n_ckpt - 1;   /* padded with the last checkpoint */
+    float dx = ckpt[2 * idx] - px, dy = ckpt[2 * idx + 1] - py;
+    float dn = md_norm(dx, dy);
+    if (dn > MD_TRAJ_NAVI_POINT_DIST) {
+        dx = dx / dn * MD_TRAJ_NAVI_POINT_DIST;
+        dy = dy / dn * MD_TRAJ_NAVI_POINT_DIST;
     }
+    float fwd = dx * hc + dy * hs;   /* convert_to_local_coordinates: (forward, left), SURVEY 8a-5 */
+    return md_clip((fwd / MD_TRAJ_NAVI_POINT_DIST + 1.0f) / 2.0f, 0.0f, 1.0f);
+}
+
+/* with_points = 0: the way points (dims 0..17) are written by the caller (the kernel: one lane per way point) */
+MD_HD void md_traj_navi(const float* ckpt, int n_ckpt, const MdTrajLoc* L, float px, float py, float hc, float hs,
+                        float heading, float max_lateral_dist, float* out22, int with_points) {
+    const int next_idx = md_traj_next_idx(L, n_ckpt);
+    for (int i = with_points ? 0 : 2 * (MD_TRAJ_NUM_WAY_POINT - 1); i < MD_TRAJ_NAVI_DIM; ++i) out22[i] = 0.0f;
+    if (with_points)
+        for (int k = 0; k < MD_TRAJ_NUM_WAY_POINT - 1; ++k) {
+            float a = md_traj_navi_point(ckpt, n_ckpt, next_idx, k, px, py, hc, hs);
+            out22[2 * k] = a;
+            out22[2 * k + 1] = a;
+        }
     out22[18] = md_clip((L->lat / max_lateral_dist + 1.0f) / 2.0f, 0.0f, 1.0f);
     out22[19] = md_clip((md_wrap_to_pi(L->heading_at - heading) / MD_PI_F + 1.0f) / 2.0f, 0.0f, 1.0f);
 }
@@ -174,7 +185,7 @@ MD_HD void md_traj_navi(const float* ckpt, int n_ckpt, const MdTrajLoc* L, float
 /* Observation (state + navi), reward, cost, done of the agent in slot a.  `side_fill`: with the side detector on and
  * no road-line bodies in the scene every beam reports "nothing" (1.0). */
 MD_HD void md_scenario_observe_at(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, int env_just_reset,
-                                  const MdTrajLoc* Lp, float ref_length) {
+                                  const MdTrajLoc* Lp, float ref_length, int with_points) {
     const int n = a;
     float* obs = s->obs + (size_t)a * c->obs_dim;
     float* info = s->step_info + (size_t)a * 8;
@@ -226,7 +237,7 @@ MD_HD void md_scenario_observe_at(const MdWorld* w, const MdState* s, const MdCo
     {
         const int k0 = w->ckpt_off[e], k1 = w->ckpt_off[e + 1];
         md_traj_navi(w->ckpt_xy + 2 * (size_t)k0, k1 - k0, &L, sh->cx, sh->cy, sh->c, sh->s, d->heading, c->max_lateral_dist,
-                     obs + o_navi);
+                     obs + o_navi, with_points);
     }
 
     /* ---- flags from the contact phase ---- */
@@ -323,7 +334,7 @@ MD_HD void md_scenario_observe(const MdWorld* w, const MdState* s, const MdConfi
     const MdPoly ref = md_poly_of(w, (size_t)e * c->cap + a);
     MdTrajLoc L;
     md_traj_locate(&ref, s->shape[a].cx, s->shape[a].cy, &L);
-    md_scenario_observe_at(w, s, c, e, a, env_just_reset, &L, ref.length);
+    md_scenario_observe_at(w, s, c, e, a, env_just_reset, &L, ref.length, 1);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -351,8 +362,10 @@ MD_HD float md_tidm_front_gap(const MdPoly* route, const float* poly_xy, int n_v
 }
 
 /* steering + acceleration once the front object is known (front < 0: none).  Writes action / PID / last action. */
+/* `lane_heading` = route.heading_theta_at(own longitudinal + 1) (idm_policy.py:462-468): the heading of the first piece that ends
+ * beyond that point (md_poly_seg_heading) -- looked up by the caller, serially in the oracle, one lane per piece in the kernel */
 MD_HD void md_tidm_decide(const MdPoly* route, const MdState* s, int slot, int do_speed_control, int front, float front_dist,
-                          float own_long) {
+                          float lane_heading) {
     MdShape* sh = &s->shape[slot];
     MdDyn* d = &s->dyn[slot];
     MdPid* pid = &s->pid[slot];
@@ -369,7 +382,7 @@ MD_HD void md_tidm_decide(const MdPoly* route, const MdState* s, int slot, int d
         }
         acc = md_idm_acceleration(speed_kmh, MD_TIDM_NORMAL_SPEED, front >= 0, front_dist, dv);
     }
-    float lane_heading = route->segs[md_poly_seg_heading(route, own_long + 1.0f)].heading;
+    (void)route;
     float steering = md_pid(&pid->hp, &pid->hi, &pid->hd, 1.2f, 0.1f, 3.5f, -md_wrap_to_pi(lane_heading - d->heading));
     pid->lp = acc;
     s->action[2 * slot] = steering;
@@ -406,7 +419,8 @@ MD_HD void md_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c
             }
         }
     }
-    md_tidm_decide(&route, s, slot, do_speed_control, front, front_dist, cur_long);
+    md_tidm_decide(&route, s, slot, do_speed_control, front, front_dist,
+                   route.segs[md_poly_seg_heading(&route, cur_long + 1.0f)].heading);
 }
 
 /* ------------------------------------------------------------------------------------------

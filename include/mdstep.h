@@ -269,6 +269,11 @@ typedef struct MdWorld {
      * (random_vehicle_type, component/vehicle/vehicle_type.py:269-281): [n_vclass][12] = MdParam (8 floats), half length,
      * half width, 0, 0 */
     const float* vclass;
+    /* scenario mode, optional (NULL = derived in the kernel): per mover slot [8] = the end point of its polyline
+     * (PointLane.end = position(length, 0)), the bounding box xmin, ymin, xmax, ymax of its outline polygon, 0, 0 --
+     * both are functions of the static tables above, kept so that the reactive policy's arrival test and its
+     * "is this object on my path" test need no pass over the polyline */
+    const float* poly_aux;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */

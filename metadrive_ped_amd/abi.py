@@ -84,7 +84,7 @@ class MdWorld(C.Structure):
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
         ("n_dest", C.c_int32), ("n_vclass", C.c_int32),
-        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P),
+        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P),
     ]
 
 

@@ -1900,30 +1900,113 @@ __device__ __forceinline__ void traj_locate_wave(const MdPoly& p, float px, floa
     o->lat_dy = -p.segs[is].dx;
 }
 
-// TrajectoryIDMPolicy.act of the vehicle in `slot` by one wave (md_tidm_vehicle is the serial form)
+// Four points against one polygon in one pass over its edges (lanes = edges): bit c of the result = point c is inside
+// (odd crossing number, md_point_in_polygon).  `want`: the points worth testing (wave-uniform).
+__device__ __forceinline__ int points_in_polygon_wave4(const float* xy, int n, const float* px, const float* py, int want, int lane_id) {
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane_id;
+        const bool v = i < n;
+        const int ii = v ? i : 0;
+        const int j = (ii == 0) ? n - 1 : ii - 1;
+        const float xi = xy[2 * ii], yi = xy[2 * ii + 1], xj = xy[2 * j], yj = xy[2 * j + 1];
+        // md_polygon_edge_crosses, the same expression for each point
+#define MD_CROSS(q) (v && (((yi > py[q]) != (yj > py[q])) && (px[q] < (xj - xi) * (py[q] - yi) / (yj - yi) + xi)))
+        if (want & 1) c0 += __popcll(__ballot(MD_CROSS(0)));
+        if (want & 2) c1 += __popcll(__ballot(MD_CROSS(1)));
+        if (want & 4) c2 += __popcll(__ballot(MD_CROSS(2)));
+        if (want & 8) c3 += __popcll(__ballot(MD_CROSS(3)));
+#undef MD_CROSS
+    }
+    return (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c3 & 1) << 3);
+}
+
+// TrajectoryIDMPolicy.act of the vehicle in `slot` by one wave (md_tidm_vehicle is the serial form).
+// The route's pieces are read ONCE: every lane keeps the end longitudinal and the heading of its (<= 4) pieces in
+// registers, so the look-ahead heading after the projection needs no second pass over memory; the end point and the
+// outline's bounding box come precomputed (MdWorld.poly_aux); the four chassis corners of a candidate are tested in
+// one pass over the outline's edges, and only those inside its bounding box.
 __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
                                   int lane_id) {
     const size_t ng = (size_t)e * c.cap + slot;
-    const MdPoly route = md_poly_of(&w, ng);
+#ifdef MD_STAMP
+    bool st_ = lane_id == 0;   // diagnostic: the scene's first reactive vehicle, apart for its speed-control steps (slots 16.. / 24..)
+    for (int q = c.agents_per_env; q < slot; ++q) st_ = st_ && !(s.nav[q].ck0 == MD_SC_IDM && md_present(s.shape[q].flags));
+    const int so_ = ((k % MD_TIDM_BATCH) == s.nav[slot].timer) ? 8 : 0;
+#endif
+    MD_FINE_STAMP(st_, so_ + 0);
+    MdPoly route;   // md_poly_of without the length: that is a dependent load of the last piece, only the fallback needs it
+    {
+        const int pa = w.poly_off[ng], pb = w.poly_off[ng + 1];
+        route.segs = w.segs + pa;
+        route.n = pb - pa;
+        route.length = 0.0f;
+    }
     const float px = s.shape[slot].cx, py = s.shape[slot].cy;
-    const float length = route.length;
-    const int ie = poly_first_wave(route, lane_id, [length](const MdSeg& g) { return g.cum + g.len + 0.1f >= length; });
-    const MdSeg ge = route.segs[ie];
-    const float end_x = ge.sx + (length - ge.cum) * ge.dx, end_y = ge.sy + (length - ge.cum) * ge.dy;
+    float end_x, end_y, bx0 = -3.0e38f, by0 = -3.0e38f, bx1 = 3.0e38f, by1 = 3.0e38f;
+    if (w.poly_aux) {
+        const float* aux = w.poly_aux + 8 * ng;
+        end_x = aux[0];
+        end_y = aux[1];
+        bx0 = aux[2];
+        by0 = aux[3];
+        bx1 = aux[4];
+        by1 = aux[5];
+    } else {
+        route.length = (route.n > 0) ? route.segs[route.n - 1].cum + route.segs[route.n - 1].len : 0.0f;
+        const float length = route.length;
+        const int ie = poly_first_wave(route, lane_id, [length](const MdSeg& g) { return g.cum + g.len + 0.1f >= length; });
+        const MdSeg ge = route.segs[ie];
+        end_x = ge.sx + (length - ge.cum) * ge.dx;
+        end_y = ge.sy + (length - ge.cum) * ge.dy;
+    }
     if (md_norm(px - end_x, py - end_y) < MD_TIDM_DEST_RADIUS) {
         if (lane_id == 0) s.nav[slot].ck0 = MD_SC_ARRIVED;
         return;
     }
+    MD_FINE_STAMP(st_, so_ + 1);
     const int do_speed_control = (k % MD_TIDM_BATCH) == s.nav[slot].timer;
-    const int best = poly_argmin_wave(route, px, py, lane_id);
+    // ---- projection on the own route; the pieces' end longitudinals / headings stay in registers ----
+    constexpr int kChunks = 4;
+    const bool small = route.n <= 64 * kChunks;   // wave-uniform
+    float ce[kChunks], hd[kChunks];
+    int best;
+    if (small) {
+        float bd = 3.0e38f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const int i = lane_id + 64 * q;
+            ce[q] = -3.0e38f;     // never "ends beyond" anything
+            hd[q] = 0.0f;
+            if (i < route.n) {
+                const MdSeg g = route.segs[i];
+                const float d = md_seg_dist(&g, px, py);
+                if (d < bd) {
+                    bd = d;
+                    bi = i;
+                }
+                ce[q] = g.cum + g.len;
+                hd[q] = g.heading;
+            }
+        }
+        float m = bd;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
+        best = wave_min_i(bi, bd == m, 0x7fffffff);
+    } else {
+        best = poly_argmin_wave(route, px, py, lane_id);
+    }
     float cur_long, tmp;
     md_poly_local_at(&route, best, px, py, &cur_long, &tmp);
     int front = -1;
     float front_dist = MD_TIDM_MAX_DIST;
+    MD_FINE_STAMP(st_, so_ + 2);
     if (do_speed_control) {
-        // md_tidm_front_gap, wave form: lanes = movers for the 20 m filter; the survivors (a handful) one after the other,
-        // each corner of the chassis against the outline with lanes = polygon edges, then the projection on the route
-        // with lanes = segments.  Ascending slot order and a strict < keep the lowest slot among equal gaps.
+        // md_tidm_front_gap, wave form: lanes = movers for the 20 m filter; the survivors one after the other: the chassis
+        // corners inside the outline's bounding box against the outline (lanes = polygon edges, all corners in one pass),
+        // then the projection on the route with lanes = pieces.  Ascending slot order and a strict < keep the lowest
+        // slot among equal gaps.
         const float* pv = w.polyv + 2 * (size_t)w.polyv_off[ng];
         const int n_v = w.polyv_off[ng + 1] - w.polyv_off[ng];
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
@@ -1939,11 +2022,14 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
                 mk &= mk - 1;
                 const MdShape o = s.shape[j];   // wave-uniform
                 const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
-                const bool on = point_in_polygon_wave(pv, n_v, o.cx + ex + fx, o.cy + ey + fy, lane_id) ||
-                                point_in_polygon_wave(pv, n_v, o.cx + ex - fx, o.cy + ey - fy, lane_id) ||
-                                point_in_polygon_wave(pv, n_v, o.cx - ex - fx, o.cy - ey - fy, lane_id) ||
-                                point_in_polygon_wave(pv, n_v, o.cx - ex + fx, o.cy - ey + fy, lane_id);
-                if (!on) continue;
+                const float qx[4] = {o.cx + ex + fx, o.cx + ex - fx, o.cx - ex - fx, o.cx - ex + fx};
+                const float qy[4] = {o.cy + ey + fy, o.cy + ey - fy, o.cy - ey - fy, o.cy - ey + fy};
+                int want = 0;   // a point outside the polygon's bounding box is outside the polygon
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!(qx[q] < bx0 || qx[q] > bx1 || qy[q] < by0 || qy[q] > by1)) want |= 1 << q;
+                if (want == 0) continue;
+                if (points_in_polygon_wave4(pv, n_v, qx, qy, want, lane_id) == 0) continue;
                 const int bo = poly_argmin_wave(route, o.cx, o.cy, lane_id);
                 float lg, lt;
                 md_poly_local_at(&route, bo, o.cx, o.cy, &lg, &lt);
@@ -1955,10 +2041,44 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
             }
         }
     }
-    if (lane_id == 0) md_tidm_decide(&route, &s, slot, do_speed_control, front, front_dist, cur_long);
+    MD_FINE_STAMP(st_, so_ + 3);
+    // heading of the route one metre ahead: the first piece that ends beyond it (md_poly_seg_heading), else the last one
+    const float ahead = cur_long + 1.0f;
+    float lane_heading;
+    if (small) {
+        int ih = route.n - 1;
+        bool found = false;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const unsigned long long m = __ballot(ce[q] > ahead);
+            if (!found && m) {
+                ih = 64 * q + __ffsll((long long)m) - 1;
+                found = true;
+            }
+        }
+        lane_heading = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q)
+            if ((ih >> 6) == q) lane_heading = bcast_f(hd[q], ih & 63);
+    } else {
+        const int ih = poly_first_wave(route, lane_id, [ahead](const MdSeg& g) { return g.cum + g.len > ahead; });
+        lane_heading = route.segs[ih].heading;
+    }
+    MD_FINE_STAMP(st_, so_ + 4);
+    if (lane_id == 0) md_tidm_decide(&route, &s, slot, do_speed_control, front, front_dist, lane_heading);
+    MD_FINE_STAMP(st_, so_ + 5);
 }
 
-__global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, int lidar_stride,
+// Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
+// are then resident at once, one round instead of two (measured 148 vs 173 us at the compiler's own choice)
+#ifndef MD_SC_WAVES_EU
+#define MD_SC_WAVES_EU 8
+#endif
+__global__ __launch_bounds__(256)
+#if MD_SC_WAVES_EU
+__attribute__((amdgpu_waves_per_eu(MD_SC_WAVES_EU, MD_SC_WAVES_EU)))
+#endif
+void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, int lidar_stride,
                                                            int lidar_offset) {
     constexpr int kBlock = 256, kWaves = 4;
     const int e = blockIdx.x;
@@ -1977,6 +2097,7 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
     MdTrajLoc* l_loc = reinterpret_cast<MdTrajLoc*>(l_cfl + ((cap + 3) & ~3));   // [A]
     int* l_count = reinterpret_cast<int*>(l_loc + A);
 
+    MD_STAMP_AT(0);
     const MdState gv = md_env_view(&g, &c, e);
     const int reset_flag = gv.need_reset[0];
     const bool fused_act = gv.agent_action != nullptr;
@@ -2009,15 +2130,54 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
     s.param = l_param;
     s.next_agent_id = l_count;
     __syncthreads();
+    MD_STAMP_AT(1);
     const int just_reset = do_reset ? 1 : 0;
     const int k = just_reset ? 0 : s.nav[0].steps + 1;   // engine.episode_step of this step
     if (!just_reset) {
-        for (int j = A + wave; j < cap; j += kWaves)
-            if (s.nav[j].ck0 == MD_SC_IDM && md_present(s.shape[j].flags)) tidm_vehicle_wave(w, s, c, e, j, k, lane);
+        // Work list of the reactive vehicles, those due for speed control in this step FIRST (their front search makes them
+        // ~2.5x as expensive as the others); the waves then take vehicles off the list one by one through an LDS counter,
+        // so a wave that drew a cheap vehicle moves on instead of waiting at the barrier (every wave leaves the loop as
+        // soon as the counter passes the list's end: no waiting inside).  The decisions are independent of each other,
+        // so the order changes nothing in the results.
+        int* l_list = reinterpret_cast<int*>(l_cfl);   // free until the contacts stage writes its flags
+        int* l_ctr = l_count + 1;
+        int* l_n = l_count + 2;
+        if (wave == 0) {
+            int n = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int j0 = A; j0 < cap; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool take = false;
+                    if (j < cap && s.nav[j].ck0 == MD_SC_IDM && md_present(s.shape[j].flags)) {
+                        const bool sc = (k % MD_TIDM_BATCH) == s.nav[j].timer;
+                        take = (pass == 0) ? sc : !sc;
+                    }
+                    const unsigned long long m = __ballot(take);
+                    if (take) l_list[n + __popcll(m & ((1ull << lane) - 1ull))] = j;
+                    n += __popcll(m);
+                }
+            if (lane == 0) {
+                *l_n = n;
+                *l_ctr = 0;
+            }
+        }
         __syncthreads();
+        const int n_list = __builtin_amdgcn_readfirstlane(*l_n);
+        for (int guard = 0; guard < cap; ++guard) {   // at most cap tickets per wave: the loop ends whatever the counter holds
+            int i = 0;
+            if (lane == 0) i = atomicAdd(l_ctr, 1);
+            i = __builtin_amdgcn_readfirstlane(i);     // lane 0's ticket, in a scalar register
+            if (i < 0 || i >= n_list) break;
+            const int slot = __builtin_amdgcn_readfirstlane(l_list[i]);
+            if (slot < A || slot >= cap) break;        // never index with anything but a mover slot
+            tidm_vehicle_wave(w, s, c, e, slot, k, lane);
+        }
+        __syncthreads();
+        MD_STAMP_AT(2);
         for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
         __syncthreads();
     }
+    MD_STAMP_AT(3);
     // ---- after_step of the traffic manager: lanes = track slots, in slot order ----
     if (wave == 0) {
         for (int j0 = A; j0 < cap; j0 += 64) {
@@ -2033,6 +2193,7 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
         }
     }
     __syncthreads();
+    MD_STAMP_AT(4);
     // ---- the agents: projection on the reference trajectory (wave 0) beside their contacts (wave 1) ----
     for (int a = 0; a < A; ++a) {
         if (wave == 0) {
@@ -2045,14 +2206,30 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
         }
     }
     __syncthreads();
+    MD_STAMP_AT(5);
+    // the nine way points of the navigation vector: one lane each (wave 0), both slots of a way point get the value
+    if (wave == 0 && lane < MD_TRAJ_NUM_WAY_POINT - 1) {
+        const int k0 = w.ckpt_off[e], n_ck = w.ckpt_off[e + 1] - k0;
+        const float* ck = w.ckpt_xy + 2 * (size_t)k0;
+        for (int a = 0; a < A; ++a) {
+            const MdTrajLoc L = l_loc[a];
+            const MdShape sh = s.shape[a];
+            const float v = md_traj_navi_point(ck, n_ck, md_traj_next_idx(&L, n_ck), lane, sh.cx, sh.cy, sh.c, sh.s);
+            float* o = s.obs + (size_t)a * c.obs_dim + md_sc_obs_navi(&c);
+            o[2 * lane] = v;
+            o[2 * lane + 1] = v;
+        }
+    }
     if (tid < A) {
         const int a = tid;
         s.flags[a] = l_cfl[a];
         const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
-        md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], ref.length);
+        md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], ref.length, 0);
     }
+    MD_STAMP_AT(6);
     if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
     __syncthreads();
+    MD_STAMP_AT(7);
     copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
     copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
     copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
@@ -2066,6 +2243,7 @@ __global__ __launch_bounds__(256) void scenario_step_kernel(MdWorld w, MdState g
         gv.next_agent_id[0] = *l_count;
         if (do_reset) gv.need_reset[0] = 0;
     }
+    MD_STAMP_AT(11);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -339,6 +339,32 @@ class _World:
         self.n_envs = n_envs
 
 
+def _poly_aux(poly_off, segs, polyv_off, polyv):
+    """MdWorld.poly_aux: per slot the polyline's end point -- float32 arithmetic in the order of md_poly_position(p, length, 0):
+    the first piece with cum + len + 0.1 >= length, then sx + (length - cum) * dx -- and the bounding box of the outline."""
+    f = np.float32
+    n_slot = len(poly_off) - 1
+    out = np.zeros((n_slot, 8), np.float32)
+    for k in range(n_slot):
+        a, b = int(poly_off[k]), int(poly_off[k + 1])
+        if b > a:
+            g = segs[a:b]
+            length = f(g["cum"][-1]) + f(g["len"][-1])
+            ends = (g["cum"].astype(f) + g["len"].astype(f)) + f(0.1)
+            hit = np.nonzero(ends >= length)[0]
+            ge = g[int(hit[0]) if len(hit) else b - a - 1]
+            along = length - f(ge["cum"])
+            out[k, 0] = f(ge["sx"]) + along * f(ge["dx"])
+            out[k, 1] = f(ge["sy"]) + along * f(ge["dy"])
+        va, vb = int(polyv_off[k]), int(polyv_off[k + 1])
+        if vb > va:
+            v = polyv[va:vb]
+            out[k, 2:6] = v[:, 0].min(), v[:, 1].min(), v[:, 0].max(), v[:, 1].max()
+        else:
+            out[k, 2:6] = 1.0, 1.0, -1.0, -1.0      # empty box: nothing is inside
+    return out
+
+
 class ScenarioHostScene:
     """The HostScene of scenario mode: one scenario description per env (`scenarios[e]` -> env e)."""
     def __init__(self, cfg, scenarios):
@@ -442,6 +468,7 @@ class ScenarioHostScene:
         a["ckpt_off"] = np.asarray(ckpt_off, np.int32)
         a["ckpt_xy"] = np.ascontiguousarray(np.concatenate(ckpts), dtype=np.float32)
         a["track_meta"] = meta
+        a["poly_aux"] = _poly_aux(a["poly_off"], a["segs"], a["polyv_off"], a["polyv"])
         self.world = _World(a, E)
         st = {}
         st["shape0"], st["dyn0"], st["nav0"], st["pid0"], st["param"] = shape0, dyn0, nav0, pid0, param

@@ -625,7 +625,7 @@ EXPORT void ref_traj_navi(const MdSeg* segs, int n, const float* ckpt, int n_ckp
     md_traj_locate(&p, px, py, &L);
     float sn, cs;
     md_sincos(heading, &sn, &cs);
-    md_traj_navi(ckpt, n_ckpt, &L, px, py, cs, sn, heading, max_lateral_dist, out22);
+    md_traj_navi(ckpt, n_ckpt, &L, px, py, cs, sn, heading, max_lateral_dist, out22, 1);
 }
 /* md_scenario_observe of every env's agent on the state as it stands (flags as given: no contact phase) */
 EXPORT int ref_scenario_observe(const MdWorld* w, const MdState* s, const MdConfig* c) {

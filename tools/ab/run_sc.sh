@@ -1,0 +1,15 @@
+#!/bin/bash
+# A/B of library builds on the scenario workload: bash tools/ab/run_sc.sh <out> lib1.so ...
+OUT=$1; shift
+mkdir -p $OUT
+LEAN="--workload scenario --no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --steps 100 --warmup 10"
+python bench.py $LEAN > $OUT/base.json 2> $OUT/base.err || { tail -5 $OUT/base.err; exit 1; }
+python - <<PY
+import json; d=json.loads(open("$OUT/base.json").read().strip().splitlines()[-1]); print("base", d["ms_per_step"], d["value"])
+PY
+for L in "$@"; do
+  MD_LIB_PATH=$PWD/$L python bench.py $LEAN > $OUT/$(basename $L).json 2> $OUT/$(basename $L).err || { tail -5 $OUT/$(basename $L).err; continue; }
+  python - <<PY
+import json; d=json.loads(open("$OUT/$(basename $L).json").read().strip().splitlines()[-1]); print("$L", d["ms_per_step"], d["value"])
+PY
+done
