@@ -41,10 +41,20 @@ def main():
     d["Curve"], d["Straight"] = 0.6, 0.4
     E = int(os.environ.get("ENVS", "4096"))
     cfg = make_config(dict(num_envs=E, num_scenarios=min(E, int(os.environ.get("SCEN", "512"))), mover_capacity=0, horizon=1000))
+    workload = os.environ.get("WORKLOAD", "metadrive")
+    if workload == "marl":        # BASELINE configs[2]: the 40-agent roundabout (ENVS=1024)
+        from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRoundaboutEnv
+        cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, vehicle_config=dict(lidar=dict(num_lasers=240, distance=50)))).config
+        PHASES = ["stage-in", "lifecycle", "idm before integrate", "integrate", "localize (own stage)", "contacts (own stage)",
+                  "traffic", "observe", "lidar", "-", "write-back"]
+    elif workload == "safe":      # BASELINE configs[3]
+        cfg = make_config(dict(num_envs=E, num_scenarios=E, mover_capacity=0, horizon=1000, accident_prob=0.8, traffic_density=0.1,
+                               crash_vehicle_done=False, crash_object_done=False, out_of_road_done=True))
     eng = BatchedEngine(cfg, host=HostScene(cfg))
     eng.reset()
+    A_ = eng.A
     g = torch.Generator().manual_seed(0)
-    acts = torch.rand(16, E, 1, 2, generator=g) * 2 - 1
+    acts = torch.rand(16, E, A_, 2, generator=g) * 2 - 1
     acts[..., 1] = acts[..., 1].abs() * 0.9 + 0.1
     acts[..., 0] *= 0.25
     acts = acts.cuda()
@@ -54,7 +64,7 @@ def main():
         if not lane_follow:
             return acts[i % 16]
         ob_ = eng.obs[:, 0, :]
-        a = torch.zeros(E, 1, 2, device="cuda")
+        a = torch.zeros(E, A_, 2, device="cuda")
         a[:, 0, 0] = (4.0 * (ob_[:, 2] - 0.5) + 2.0 * (ob_[:, 8] - 0.5)).clamp_(-1.0, 1.0)
         a[:, 0, 1] = (ob_[:, 3] < 0.35).to(torch.float32) * 0.5
         return a
@@ -97,6 +107,11 @@ def main():
     flags = eng.shape_f.view(torch.int32)[..., 6]
     drv = (((flags & 0x10) != 0) & ((flags & 0x40) == 0) & ((flags & 0xF) == 1)).sum(dim=1).cpu().numpy()
     print("driving vehicles/env: mean %.2f max %d" % (drv.mean(), drv.max()))
+    life = (raw[:, 13].astype(np.int64) - raw[:, 12].astype(np.int64)) / 100.0
+    t_start = (raw[:, 12].astype(np.int64) - raw[:, 12].astype(np.int64).min()) / 100.0
+    print("workgroup life: mean %.1f  p50 %.1f  p99 %.1f  max %.1f us; launch span %.1f us; workgroups started after 5 us: %d of %d" % (
+        life.mean(), np.median(life), np.percentile(life, 99), life.max(),
+        (raw[:, 13].astype(np.int64).max() - raw[:, 12].astype(np.int64).min()) / 100.0, (t_start > 5).sum(), E))
     idx = np.argsort(tot)[-3:]
     for i in idx:
         print("slow env", i, "drv", drv[i], "phases", d[i].tolist())
