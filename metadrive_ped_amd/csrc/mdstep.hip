@@ -964,6 +964,8 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
     int* cnt_dying = scratch + 1;   // bodies waiting out delay_done
     int* hit_mask = scratch + 2;    // bit p: spawn place p is occupied
     int* reserved = scratch + 3;    // parking lot env: bit d: an active agent holds parking space d (md_lifecycle_env)
+    int* new_slot = scratch + 4;    // slot refilled in this step (-1: none) and its row of the spawn-route table: the
+    int* new_ri = scratch + 5;      //   96 words of its route are copied by the whole workgroup, not by the one thread
     const bool parking = c.ma_kind == MD_MA_PARKING_LOT;
     if (tid == 0) {
         s.env_steps[0] += 1;
@@ -971,6 +973,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
         *cnt_dying = 0;
         *hit_mask = 0;
         *reserved = 0;
+        *new_slot = -1;
     }
     __syncthreads();
     for (int a = tid; a < A; a += nthreads) {
@@ -1069,10 +1072,8 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                     nav->toll_entry = space;
                     if (c.random_agent_model && w.n_vclass > 0) md_draw_vehicle_class(&w, &s, slot);
                     s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
-                    for (int q = 0; q < MD_ROUTE_LEN; ++q) {
-                        s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
-                        s.route_roads[(size_t)slot * MD_ROUTE_LEN + q] = rt[MD_ROUTE_LEN + q];
-                    }
+                    *new_slot = slot;
+                    *new_ri = (int)ri;
                     nav->road0 = rt[MD_ROUTE_LEN + nav->ck0];
                     nav->road1 = rt[MD_ROUTE_LEN + nav->ck1];
                     s.pid[slot].energy = 0.0f;
@@ -1086,6 +1087,14 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
             }
         }
         __syncthreads();
+        if (*new_slot >= 0) {   // block-uniform
+            const int slot = *new_slot;
+            const int32_t* rt = w.spawn_route + (size_t)(*new_ri) * 2 * MD_ROUTE_LEN;
+            for (int q = tid; q < 2 * MD_ROUTE_LEN; q += nthreads) {
+                if (q < MD_ROUTE_LEN) s.route_nodes[(size_t)slot * MD_ROUTE_LEN + q] = rt[q];
+                else s.route_roads[(size_t)slot * MD_ROUTE_LEN + (q - MD_ROUTE_LEN)] = rt[q];
+            }
+        }
     }
     // episode over: nobody left and nobody can come back
     if (tid == 0 && c.auto_reset && *cnt_active == 0 && !(c.allow_respawn && horizon_open)) s.need_reset[0] = 1;
@@ -2715,7 +2724,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
                        (size_t)((c->cap + 3) & ~3) * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
                        (MD_ENV_BLOCK / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
-                       (size_t)c->cap * 8;
+                       (size_t)c->cap * 8 + 32;   // + 32: the lifecycle's 8 scratch words sit at the start of the last region
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
