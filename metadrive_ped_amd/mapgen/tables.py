@@ -40,13 +40,13 @@ def _ccw(q):
     return q if area >= 0 else q[::-1].copy()
 
 
-def _line_box(p0, p1):
+def _line_box(p0, p1, region=None):
     """Ghost box of one lane-line piece as a CCW quad, or None (zero length / outside the map)."""
     p0, p1 = np.asarray(p0, float), np.asarray(p1, float)
     d = p1 - p0
     length = math.sqrt(d[0] ** 2 + d[1] ** 2)
     mid = (p0 + p1) / 2
-    half = MAP_REGION_SIZE / 2
+    half = (MAP_REGION_SIZE if region is None else region) / 2
     if not (-half <= mid[0] <= half and -half <= mid[1] <= half):
         return None
     if length <= 0:
@@ -125,6 +125,25 @@ def road_block_id(start_node, end_node):
         return ord(">")
     m = re.search("[a-zA-Z$]", node)
     return ord(m.group(0)) if m else 0
+
+
+class StaticTables:
+    """The static tables of a map that consists of line bodies only (scenario scenes: their lanes are polylines of
+    their own, nothing is localised on the grid): quads + grid, and placeholders where WorldTables expects a map's
+    lanes / roads / nodes."""
+    _build_grid = None   # bound below
+
+    def __init__(self, quads, kinds):
+        self.respawn = None
+        self.lanes = np.zeros(1, dtype=abi.LANE_DT)
+        self.lanes["x0"], self.lanes["x1"] = 1.0, -1.0          # an empty box: the grid skips it, nothing ever hits it
+        self.hull_xy = np.zeros((1, 2), np.float32)
+        self.roads = np.zeros(1, dtype=abi.ROAD_DT)
+        self.quads = np.asarray(quads, dtype=np.float32).reshape(-1, 8) if len(quads) else np.zeros((0, 8), np.float32)
+        self.quad_kind = np.asarray(kinds, dtype=np.int32)
+        self.node_adj_off = np.zeros(2, dtype=np.int32)
+        self.node_adj = np.zeros((0, 2), np.int32)
+        self._build_grid()
 
 
 class MapTables:
@@ -229,10 +248,19 @@ class MapTables:
         boxes = []  # (x0, y0, x1, y1, item)
         for k in range(len(self.lanes)):
             r = self.lanes[k]
+            if r["x1"] < r["x0"]:
+                continue      # a placeholder lane (scenario scenes: nothing is localised on the grid there)
             boxes.append((r["x0"], r["y0"], r["x1"], r["y1"], k))
         for k in range(len(self.quads)):
             q = self.quads[k].reshape(4, 2)
             boxes.append((q[:, 0].min(), q[:, 1].min(), q[:, 0].max(), q[:, 1].max(), ~k))
+        if not boxes:         # nothing static at all: one empty cell that covers everything
+            self.grid = np.zeros(1, dtype=abi.GRID_DT)
+            self.grid[0]["x0"], self.grid[0]["y0"], self.grid[0]["inv_cell"] = -1.0e7, -1.0e7, 5.0e-8
+            self.grid[0]["nx"], self.grid[0]["ny"] = 1, 1
+            self.cell_start = np.zeros(2, dtype=np.int32)
+            self.cell_items = np.zeros(0, dtype=np.int32)
+            return
         b = np.asarray([bb[:4] for bb in boxes], dtype=np.float64)
         x0 = math.floor(b[:, 0].min() - 1.0)
         y0 = math.floor(b[:, 1].min() - 1.0)
@@ -261,6 +289,8 @@ class MapTables:
             self.cell_start[i + 1] = len(items)
         self.cell_items = np.asarray(items, dtype=np.int32)
 
+
+StaticTables._build_grid = MapTables._build_grid
 
 RESPAWN_REGION_LONGITUDE = 8.0  # manager/spawn_manager.py:28
 

@@ -34,6 +34,7 @@ SCENARIO_DEFAULT_CONFIG = dict(
     crash_vehicle_cost=1.0, crash_object_cost=1.0, out_of_road_cost=1.0, crash_human_cost=1.0,
     out_of_route_done=False, crash_vehicle_done=False, crash_object_done=False, crash_human_done=False,
     relax_out_of_road_done=True, allowed_more_steps=None,
+    map_region_size=512,          # envs/scenario_env.py:40: line bodies exist within +-256 m of the origin
 )
 SCENARIO_VEHICLE_CONFIG = dict(lidar=dict(num_lasers=120, distance=50), lane_line_detector=dict(num_lasers=0, distance=50),
                                side_detector=dict(num_lasers=12, distance=50))
@@ -99,11 +100,11 @@ class PolyLine:
         self.start = np.asarray(starts)
         self.end = np.asarray(ends)
         d = self.end - self.start
-        self.seg_len = np.hypot(d[:, 0], d[:, 1])
+        self.seg_len = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2)       # utils/math.py norm: sqrt(x**2 + y**2)
         self.direction = d / self.seg_len[:, None]
         self.heading = np.arctan2(d[:, 1], d[:, 0])
         self.cum = np.concatenate([[0.0], np.cumsum(self.seg_len)[:-1]])
-        self.length = float(self.seg_len.sum())
+        self.length = float(sum(self.seg_len.tolist()))           # the reference's left-to-right sum (int(length / 1.5) reads it)
         # lateral_direction = get_vertical_vector(end - start)[1] = (dy, -dx); the never-moving one-piece line has (0, 1)
         # hard-wired (interpolating_line.py:118-131) -- the device derives (dy, -dx) from the direction in every case,
         # which only differs for that degenerate line (a parked SDC: the episode ends at once, route length < 2)
@@ -226,11 +227,67 @@ def vehicle_class_for(length, counters):
     return ["l", "xl"][counters[2] % 2]
 
 
+STRIPE_LENGTH = 1.5          # PGDrivableAreaProperty.STRIPE_LENGTH (constants.py:313)
+_CONT_WHITE = ("UNKNOWN_LINE", "ROAD_LINE_SOLID_SINGLE_WHITE", "ROAD_LINE_SOLID_DOUBLE_WHITE",
+               "UNKNOWN", "ROAD_EDGE_BOUNDARY", "ROAD_EDGE_MEDIAN")          # is_road_boundary_line -> continuous, grey
+_CONT_YELLOW = ("ROAD_LINE_SOLID_SINGLE_YELLOW", "ROAD_LINE_SOLID_DOUBLE_YELLOW", "ROAD_LINE_PASSING_DOUBLE_YELLOW")
+_BROKEN = ("ROAD_LINE_BROKEN_SINGLE_WHITE", "ROAD_LINE_BROKEN_SINGLE_YELLOW", "ROAD_LINE_BROKEN_DOUBLE_YELLOW")
+
+
+def line_pieces(polyline, broken):
+    """The stripes ScenarioBlock.construct_continuous_line / construct_broken_line cut a road line into
+    (component/scenario_block/scenario_block.py:74-99): [(start, end)] in order."""
+    line = PolyLine(polyline)
+    out = []
+    if broken:
+        n = int(line.length / (2 * STRIPE_LENGTH))
+        for k in range(n):
+            a = line.position(k * STRIPE_LENGTH * 2)
+            b = line.position(k * STRIPE_LENGTH * 2 + STRIPE_LENGTH)
+            if k == n - 1:
+                b = line.position(line.length - STRIPE_LENGTH)
+            out.append((a, b))
+    else:
+        n = int(line.length / STRIPE_LENGTH)
+        for k in range(n):
+            a = line.position(STRIPE_LENGTH * k)
+            b = line.position(line.length) if k == n - 1 else line.position((k + 1) * STRIPE_LENGTH)
+            out.append((a, b))
+    return out
+
+
+def scene_line_quads(map_features, map_region_size):
+    """Line bodies of a scenario map (ScenarioBlock.create_in_world, scenario_block.py:45-72): every road line / road
+    boundary feature with at least two points, cut into stripes, each a box LANE_LINE_WIDTH / 2 wide; pieces whose
+    middle lies outside the map region are not built (block/base_block.py:481).  Sidewalk / crosswalk POLYGONS are not
+    turned into bodies here."""
+    from metadrive_ped_amd.mapgen.tables import _line_box
+    quads, kinds = [], []
+    for fid, f in (map_features or {}).items():
+        typ = f.get("type")
+        if "polyline" not in f or len(f["polyline"]) <= 1:
+            continue
+        if typ in _BROKEN:
+            kind, broken = abi.Q_LINE_BROKEN, True
+        elif typ in _CONT_YELLOW:
+            kind, broken = abi.Q_LINE_YELLOW_CONT, False
+        elif typ in _CONT_WHITE:
+            kind, broken = abi.Q_LINE_WHITE_CONT, False
+        else:
+            continue
+        for a, b in line_pieces(np.asarray(f["polyline"], dtype=np.float64)[:, :2], broken):
+            q = _line_box(a, b, region=map_region_size)
+            if q is not None:
+                quads.append(q)
+                kinds.append(kind)
+    return quads, kinds
+
+
 def _build_scene(job):
     """One scenario description -> the per-scene arrays (module-level so that a fork pool can run it)."""
     from metadrive_ped_amd.scene import vehicle_param_record
     from metadrive_ped_amd.rng import get_np_random
-    e, sc, cap, T, seed, dt, no_traffic = job
+    e, sc, cap, T, seed, dt, no_traffic, region = job
     shape0 = np.zeros(cap, dtype=abi.SHAPE_DT)
     shape0["aux"] = -1
     dyn0 = np.zeros(cap, dtype=abi.DYN_DT)
@@ -328,7 +385,10 @@ def _build_scene(job):
         segs.append(pl.records() if pl is not None else np.zeros(0, dtype=abi.SEG_DT))
         want_outline = j > 0 and pl is not None and (meta[j, 2] & abi.TM_MOVING) and (meta[j, 2] & abi.TM_LENGTH_OK)
         verts.append(pl.outline() if want_outline else np.zeros((0, 2)))
-    return dict(shape0=shape0, dyn0=dyn0, param=param, fshape=fshape, fdyn=fdyn, meta=meta, order=order, segs=segs, verts=verts, ckpt=ck)
+    from metadrive_ped_amd.mapgen.tables import StaticTables
+    static = StaticTables(*scene_line_quads(sc.get("map_features"), region))      # road-line bodies + their grid
+    return dict(shape0=shape0, dyn0=dyn0, param=param, fshape=fshape, fdyn=fdyn, meta=meta, order=order, segs=segs, verts=verts, ckpt=ck,
+                static=static)
 
 
 
@@ -401,8 +461,8 @@ class ScenarioHostScene:
 
         # vehicle parameters are sampled from a stream seeded by the scenario's OWN seed where it carries one, so that a
         # scene behaves the same in whatever batch (slot, shard) it is loaded
-        jobs = [(e, scenarios[e], cap, T, int(scenarios[e]["metadata"].get("seed", self.seeds[e])), dt, bool(cfg["no_traffic"]))
-                for e in range(E)]
+        jobs = [(e, scenarios[e], cap, T, int(scenarios[e]["metadata"].get("seed", self.seeds[e])), dt, bool(cfg["no_traffic"]),
+                 float(cfg["map_region_size"])) for e in range(E)]
         workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
         try:
             import torch
@@ -441,25 +501,11 @@ class ScenarioHostScene:
                 polyv_off.append(polyv_off[-1] + len(v))
             ckpts.append(b_["ckpt"])
             ckpt_off.append(ckpt_off[-1] + len(b_["ckpt"]))
-        a = {}
-        a["env_map"] = np.zeros(E, np.int32)
-        a["lane_off"] = np.asarray([0, 1], np.int32)
-        a["lanes"] = np.zeros(1, dtype=abi.LANE_DT)
-        a["hull_xy"] = np.zeros((1, 2), np.float32)
-        a["road_off"] = np.asarray([0, 1], np.int32)
-        a["roads"] = np.zeros(1, dtype=abi.ROAD_DT)
-        a["quad_off"] = np.asarray([0, 0], np.int32)
-        a["quads"] = np.zeros((1, 8), np.float32)
-        a["quad_kind"] = np.zeros(1, np.int32)
-        g = np.zeros(1, dtype=abi.GRID_DT)      # one empty cell that covers everything: no static bodies in these scenes
-        g["x0"], g["y0"], g["inv_cell"], g["nx"], g["ny"], g["cell_base"] = -1.0e7, -1.0e7, 5.0e-8, 1, 1, 0
-        a["grid"] = g
-        a["cell_start"] = np.asarray([0, 0], np.int32)
-        a["cell_items"] = np.zeros(1, np.int32)
-        a["node_adj_off"] = np.asarray([0, 0], np.int32)
-        a["node_adj"] = np.zeros((1, 2), np.int32)
-        a["node_off"] = np.asarray([0, 1], np.int32)
-        a["beam_cs"] = beam_table(self.n_beams)
+        # static bodies: one map per scene (its road lines + their grid); the lane / road / node tables are placeholders
+        from metadrive_ped_amd.mapgen.tables import WorldTables
+        self.map_tables = [b_["static"] for b_ in built]
+        self.world = WorldTables(self.map_tables, list(range(E)), beam_table(self.n_beams))
+        a = self.world.arrays
         a["poly_off"] = np.asarray(poly_off, np.int32)
         a["segs"] = np.concatenate(segs) if sum(len(x) for x in segs) else np.zeros(1, dtype=abi.SEG_DT)
         a["polyv_off"] = np.asarray(polyv_off, np.int32)
@@ -469,7 +515,6 @@ class ScenarioHostScene:
         a["ckpt_xy"] = np.ascontiguousarray(np.concatenate(ckpts), dtype=np.float32)
         a["track_meta"] = meta
         a["poly_aux"] = _poly_aux(a["poly_off"], a["segs"], a["polyv_off"], a["polyv"])
-        self.world = _World(a, E)
         st = {}
         st["shape0"], st["dyn0"], st["nav0"], st["pid0"], st["param"] = shape0, dyn0, nav0, pid0, param
         st["route_nodes"] = np.full((N, abi.MD_ROUTE_LEN), -1, np.int32)
@@ -558,6 +603,10 @@ def synthetic_scenario(seed, T=200, n_vehicles=18, n_parked=3, n_pedestrians=2, 
     ego_v = rng.uniform(6.0, 11.0)
     ego_s0 = 600.0
     ego_s = ego_s0 + ego_v * t + 0.5 * rng.uniform(-0.15, 0.15) * t * t
+    # coordinates relative to the SDC's first position, as the dataset converters deliver them: ScenarioEnv only builds
+    # the line bodies whose middle lies within map_region_size / 2 (= 256 m) of the origin (block/base_block.py:481)
+    x0_, y0_, _ = _sample(s_axis, xy, heading, np.asarray([ego_s0]), 0.0)
+    xy = xy - np.array([float(x0_[0]), float(y0_[0])])
     x, y, h = _sample(s_axis, xy, heading, ego_s, 0.0)
     sp = np.gradient(ego_s, 0.1)
     tracks["0"] = _track_dict("0", "VEHICLE", T, np.ones(T, bool), x, y, h, sp, 4.5, 1.85, 1.5)
@@ -599,11 +648,29 @@ def synthetic_scenario(seed, T=200, n_vehicles=18, n_parked=3, n_pedestrians=2, 
             valid[10:] = False                                 # a noise object: fewer than MIN_VALID_FRAME_LEN frames
         tracks[str(oid)] = _track_dict(oid, "TRAFFIC_CONE", T, valid, x, y, h, np.zeros(T), 0.4, 0.4, 1.0)
         oid += 1
+    # the road itself: three lanes 3.5 m wide around the centre line, solid white edges, broken white separators, a
+    # road boundary 0.75 m outside each edge, and (odd seeds) a solid yellow line instead of the right-hand edge
+    feats = {}
+    s_road = np.arange(ego_s0 - 80.0, ego_s0 + 260.0, 2.0)
+
+    def offset_line(lateral):
+        px, py, _ = _sample(s_axis, xy, heading, s_road, lateral)
+        return np.stack([px, py, np.zeros_like(px)], 1).astype(np.float32)
+    for i, lat in enumerate((-3.5, 0.0, 3.5)):
+        feats["lane%d" % i] = {"type": "LANE_SURFACE_STREET", "polyline": offset_line(lat), "entry_lanes": [], "exit_lanes": [],
+                               "left_neighbor": [], "right_neighbor": []}
+    feats["line_left"] = {"type": "ROAD_LINE_SOLID_SINGLE_WHITE", "polyline": offset_line(-5.25)}
+    feats["line_right"] = {"type": "ROAD_LINE_SOLID_SINGLE_YELLOW" if seed % 2 else "ROAD_LINE_SOLID_SINGLE_WHITE",
+                           "polyline": offset_line(5.25)}
+    feats["sep_left"] = {"type": "ROAD_LINE_BROKEN_SINGLE_WHITE", "polyline": offset_line(-1.75)}
+    feats["sep_right"] = {"type": "ROAD_LINE_BROKEN_SINGLE_WHITE", "polyline": offset_line(1.75)}
+    feats["edge_left"] = {"type": "ROAD_EDGE_BOUNDARY", "polyline": offset_line(-6.0)}
+    feats["edge_right"] = {"type": "ROAD_EDGE_BOUNDARY", "polyline": offset_line(6.0)}
     return {"id": "synthetic-%d" % seed, "version": "metadrive_ped_amd synthetic (MetaDrive v0.4.2.2 scenario format)",
             "length": int(T),
             "metadata": {"ts": t.astype(np.float32), "metadrive_processed": False, "coordinate": "metadrive",
                          "dataset": "synthetic", "seed": int(seed), "sdc_id": "0", "scenario_id": "synthetic-%d" % seed},
-            "tracks": tracks, "dynamic_map_states": {}, "map_features": {}}
+            "tracks": tracks, "dynamic_map_states": {}, "map_features": feats}
 
 
 def synthetic_scenarios(n, seed0=0, **kw):

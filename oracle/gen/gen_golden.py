@@ -662,6 +662,47 @@ def section_ma_parking_lot():
         t_config={k: float(v) for k, v in dict(t.get_config()).items()}))
 
 
+def section_scenario_lines():
+    """Road lines of a scenario map (component/scenario_block/scenario_block.py:45-99): which map-feature types become line
+    bodies, continuous or broken, white or yellow, and the stripe pieces ScenarioBlock.construct_continuous_line /
+    construct_broken_line cut a polyline into (the Bullet boxes themselves are recorded, not built: their end points)."""
+    from metadrive.component.scenario_block.scenario_block import ScenarioBlock
+    from metadrive.constants import PGLineColor, PGLineType, PGDrivableAreaProperty
+    from metadrive.type import MetaDriveType
+    names = ["UNKNOWN_LINE", "ROAD_LINE_BROKEN_SINGLE_WHITE", "ROAD_LINE_SOLID_SINGLE_WHITE", "ROAD_LINE_SOLID_DOUBLE_WHITE",
+             "ROAD_LINE_BROKEN_SINGLE_YELLOW", "ROAD_LINE_BROKEN_DOUBLE_YELLOW", "ROAD_LINE_SOLID_SINGLE_YELLOW",
+             "ROAD_LINE_SOLID_DOUBLE_YELLOW", "ROAD_LINE_PASSING_DOUBLE_YELLOW", "UNKNOWN", "ROAD_EDGE_BOUNDARY", "ROAD_EDGE_MEDIAN",
+             "ROAD_EDGE_SIDEWALK", "CROSSWALK", "LANE_SURFACE_STREET", "LANE_SURFACE_UNSTRUCTURE", "STOP_SIGN", "SPEED_BUMP"]
+    types = {n: dict(road_line=bool(MetaDriveType.is_road_line(n)), broken=bool(MetaDriveType.is_broken_line(n)),
+                     yellow=bool(MetaDriveType.is_yellow_line(n)), boundary=bool(MetaDriveType.is_road_boundary_line(n)),
+                     lane=bool(MetaDriveType.is_lane(n))) for n in names}
+    rng = np.random.RandomState(5)
+    cases = []
+    for ci in range(7):
+        n = int(rng.choice([2, 3, 12, 40]))
+        step = float(rng.choice([0.4, 1.0, 2.7]))
+        ang = np.cumsum(rng.uniform(-0.08, 0.08, n)) + rng.uniform(-3, 3)
+        pts = np.concatenate([[[0.0, 0.0]], np.cumsum(np.stack([np.cos(ang), np.sin(ang)], 1) * step, 0)]) + rng.uniform(-50, 50, 2)
+        rec = []
+
+        class Bare(ScenarioBlock):
+            def _construct_lane_line_segment(self, start, end, color, line_type):
+                rec.append([[float(start[0]), float(start[1])], [float(end[0]), float(end[1])],
+                            "yellow" if color == PGLineColor.YELLOW else "grey",
+                            "broken" if line_type == PGLineType.BROKEN else "continuous"])
+                return []
+        b = object.__new__(Bare)
+        b._node_path_list = []
+        out = {}
+        for fn, color in (("construct_continuous_line", PGLineColor.GREY), ("construct_broken_line", PGLineColor.YELLOW)):
+            rec.clear()
+            getattr(Bare, fn)(b, np.asarray(pts), color)
+            out[fn] = [list(r) for r in rec]
+        cases.append(dict(polyline=[[float(a), float(c)] for a, c in pts], **out))
+    dump("scenario_lines.json", dict(types=types, stripe_length=float(PGDrivableAreaProperty.STRIPE_LENGTH),
+                                     line_width=float(PGDrivableAreaProperty.LANE_LINE_WIDTH), cases=cases))
+
+
 def section_ma_bidirection():
     """Map of MultiAgentBidirectionEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 3 m) +
     Bidirection (one lane shared by both directions, seed 1) + Split (back to 4, exit 60 m) as MABidirectionMap._generate
@@ -1362,7 +1403,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -440,3 +440,74 @@ def test_scenario_full_size_properties_and_env_api():
         o.step(used[t])
     got = runs[0][0][idx]
     assert got.tobytes() == o.obs.tobytes()
+
+
+def test_road_line_pieces_against_reference():
+    """ScenarioBlock.construct_continuous_line / construct_broken_line (component/scenario_block/scenario_block.py:74-99) on
+    seven polylines, and MetaDriveType's classification of every map-feature type: tests/golden/scenario_lines.json."""
+    import json
+    import os
+    from metadrive_ped_amd import abi
+    from metadrive_ped_amd import scenario as S
+    with open(os.path.join(os.path.dirname(__file__), "golden", "scenario_lines.json")) as f:
+        g = json.load(f)
+    assert g["stripe_length"] == S.STRIPE_LENGTH
+    n = 0
+    for c in g["cases"]:
+        for fn, broken in (("construct_continuous_line", False), ("construct_broken_line", True)):
+            mine = S.line_pieces(np.asarray(c["polyline"]), broken)
+            assert len(mine) == len(c[fn])
+            for (a, b), ref in zip(mine, c[fn]):
+                np.testing.assert_allclose([*a, *b], [*ref[0], *ref[1]], atol=1e-9)
+                assert ref[3] == ("broken" if broken else "continuous")
+                n += 1
+    assert n > 150
+    for name, t in g["types"].items():
+        quads, kinds = S.scene_line_quads({"f": {"type": name, "polyline": [[0.0, 0.0], [10.0, 0.0]]}}, 512)
+        if t["road_line"] and t["broken"]:
+            assert kinds == [abi.Q_LINE_BROKEN] * 3
+        elif t["road_line"]:
+            assert kinds == [abi.Q_LINE_YELLOW_CONT if t["yellow"] else abi.Q_LINE_WHITE_CONT] * 6
+        elif t["boundary"]:
+            assert kinds == [abi.Q_LINE_WHITE_CONT] * 6          # road boundaries are continuous grey lines (:69-70)
+        else:
+            assert kinds == []
+    # a piece whose middle lies outside the map region is not built (block/base_block.py:481)
+    assert S.scene_line_quads({"f": {"type": "ROAD_LINE_SOLID_SINGLE_WHITE", "polyline": [[300.0, 0.0], [310.0, 0.0]]}}, 512)[1] == []
+    assert len(S.scene_line_quads({"f": {"type": "ROAD_LINE_SOLID_SINGLE_WHITE", "polyline": [[250.0, 0.0], [262.0, 0.0]]}}, 512)[1]) == 4
+
+
+def test_road_lines_raise_flags_and_end_episodes_on_oracle():
+    """The scene's road lines are bodies: an agent steered off the road touches the solid edge line -> on_white / on_yellow
+    continuous line -> with relax_out_of_road_done off that is ScenarioEnv's out of road (scenario_env.py:380-401) and the
+    step's reward is -on_lane_line_penalty... then -out_of_road_penalty; the side detector sees the lines."""
+    from metadrive_ped_amd import abi
+    from metadrive_ped_amd.scenario import ScenarioHostScene, make_scenario_config, synthetic_scenarios
+    import oracle_binding as ob
+    E = 4
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, relax_out_of_road_done=False, auto_reset=False, no_traffic=True,
+                                    out_of_road_penalty=7.0, on_lane_line_penalty=3.0, horizon=400))
+    host = ScenarioHostScene(cfg, synthetic_scenarios(E, 100))
+    w = host.world.arrays
+    assert host.world.n_maps == E and (np.diff(w["quad_off"]) > 300).all()
+    kinds = set(np.unique(w["quad_kind"]).tolist())
+    assert {abi.Q_LINE_WHITE_CONT, abi.Q_LINE_BROKEN, abi.Q_LINE_YELLOW_CONT} <= kinds
+    o = _oracle(host)
+    o.reset()
+    obs0 = o.state["obs"].reshape(E, -1)
+    assert (obs0[:, :12] < 1.0).any(axis=1).all()          # the side detector (12 beams, 50 m) sees the edge lines
+    done_step = np.full(E, -1)
+    for t in range(120):
+        a = np.zeros((E, 1, 2), np.float32)
+        a[:, 0, 0] = np.where(np.arange(E) % 2 == 0, -0.35, 0.35)      # half of them to each side
+        a[:, 0, 1] = 0.4
+        o.step(a)
+        fl = o.state["flags"].reshape(E, -1)[:, 0]
+        for e in range(E):
+            if done_step[e] < 0 and fl[e] & abi.FL_TERMINATED:
+                done_step[e] = t
+                assert fl[e] & abi.FL_OUT_OF_ROAD and fl[e] & (abi.FL_ON_WHITE_CONT | abi.FL_ON_YELLOW_CONT)
+                assert float(o.state["reward"].reshape(E, -1)[e, 0]) == -7.0
+                assert float(o.state["step_info"].reshape(E, -1, 8)[e, 0, 0]) == -3.0          # step_reward = -on_lane_line_penalty
+    assert (done_step >= 0).all() and (done_step > 5).all()
+    # crossing a BROKEN separator earlier raised no termination: every env drove more than one lane width before it ended
