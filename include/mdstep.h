@@ -274,6 +274,16 @@ typedef struct MdWorld {
      * both are functions of the static tables above, kept so that the reactive policy's arrival test and its
      * "is this object on my path" test need no pass over the polyline */
     const float* poly_aux;
+    /* optional: beam tables ([n][2] cos, sin; the fans start 90 deg off the heading, SideDetector.__init__
+     * distance_detector.py:197) of the side detector (MdConfig.n_side beams) and the lane-line detector (n_lane_line).
+     * Where set, md_step fills those observation dims itself (scenario mode: on waves that would otherwise idle) and a
+     * separate md_line_detector call is not needed; NULL = the caller runs md_line_detector after md_step. */
+    const float* side_beam_cs;
+    const float* ll_beam_cs;
+    /* optional, derived from `quads` / `quad_kind`: [n_quads][4] = centre x, y, radius of a circle that contains the quad,
+     * and its MD_Q_* kind (the integer's bit pattern in the float) -- the detectors cull on these 16 bytes and read the
+     * 32-byte quad only for the few (quad, beam) pairs that can meet.  NULL = they derive the circle from the quad. */
+    const float* quad_ball;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */
@@ -395,6 +405,8 @@ typedef struct MdConfig {
     int32_t min_pass_steps;    /* vehicle_config.min_pass_steps (marl_tollgate.py:28)                     */
     float overspeed_penalty;   /* marl_tollgate.py:25                                                     */
     int32_t n_parking;         /* parking lot env: number of parking spaces (destinations 0..n_parking-1 of the spawn tables) */
+    float side_range, ll_range;     /* detector ranges in m (vehicle_config.side_detector / lane_line_detector "distance") */
+    uint32_t side_mask, ll_mask;    /* which MD_Q_* kinds each detector sees (bit k = kind k), as md_line_detector's kind_mask */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

@@ -84,7 +84,7 @@ class MdWorld(C.Structure):
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
         ("n_dest", C.c_int32), ("n_vclass", C.c_int32),
-        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P),
+        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P), ("side_beam_cs", P), ("ll_beam_cs", P), ("quad_ball", P),
     ]
 
 
@@ -134,6 +134,7 @@ class MdConfig(C.Structure):
         ("scenario_length", C.c_int32),
         ("step_kernel", C.c_int32),
         ("ma_kind", C.c_int32), ("min_pass_steps", C.c_int32), ("overspeed_penalty", C.c_float), ("n_parking", C.c_int32),
+        ("side_range", C.c_float), ("ll_range", C.c_float), ("side_mask", C.c_uint32), ("ll_mask", C.c_uint32),
     ]
 
 

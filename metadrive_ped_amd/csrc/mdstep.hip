@@ -205,6 +205,32 @@ __device__ __forceinline__ void phase_lidar(const MdWorld& w, const MdState& s, 
     }
 }
 
+// The detectors' cull record of quad q: centre, radius of a circle around it, kind -- from MdWorld.quad_ball (16 bytes) or,
+// without that table, from the quad itself.
+struct QuadBall { float mx, my, rr; int kind; };
+__device__ __forceinline__ QuadBall quad_ball_of(const MdWorld& w, int q) {
+    QuadBall b;
+    if (w.quad_ball) {
+        const float4 t = reinterpret_cast<const float4*>(w.quad_ball)[q];
+        b.mx = t.x;
+        b.my = t.y;
+        b.rr = t.z;
+        b.kind = __float_as_int(t.w);
+    } else {
+        const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
+        const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
+        b.mx = 0.25f * (lo.x + lo.z + hi.x + hi.z);
+        b.my = 0.25f * (lo.y + lo.w + hi.y + hi.w);
+        const float r2 = md_max(md_max((lo.x - b.mx) * (lo.x - b.mx) + (lo.y - b.my) * (lo.y - b.my),
+                                       (lo.z - b.mx) * (lo.z - b.mx) + (lo.w - b.my) * (lo.w - b.my)),
+                                md_max((hi.x - b.mx) * (hi.x - b.mx) + (hi.y - b.my) * (hi.y - b.my),
+                                       (hi.z - b.mx) * (hi.z - b.mx) + (hi.w - b.my) * (hi.w - b.my)));
+        b.rr = md_sqrt(r2) * 1.01f + 1.0e-3f;
+        b.kind = w.quad_kind[q];
+    }
+    return b;
+}
+
 // Side / lane-line detector: beams vs static quads of the env's map.  One workgroup per env.  Per agent, the map's quads
 // go through LDS in chunks: first the quads that can be reached at all -- kind wanted, box within `range` of the agent (a hit
 // closer than `range` cannot lie on a quad whose box is farther away) -- are compacted into a list, then the (quad,
@@ -238,12 +264,11 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
             __syncthreads();
             const int ce = min(cb + kLdChunk, q1);
             for (int q = cb + tid; q < ce; q += kBlock) {
-                if (!((kind_mask >> w.quad_kind[q]) & 1u)) continue;
-                const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
-                const float bx0 = md_min(md_min(lo.x, lo.z), md_min(hi.x, hi.z)), bx1 = md_max(md_max(lo.x, lo.z), md_max(hi.x, hi.z));
-                const float by0 = md_min(md_min(lo.y, lo.w), md_min(hi.y, hi.w)), by1 = md_max(md_max(lo.y, lo.w), md_max(hi.y, hi.w));
-                const float ddx = md_max(md_max(bx0 - me.cx, me.cx - bx1), 0.0f), ddy = md_max(md_max(by0 - me.cy, me.cy - by1), 0.0f);
-                if (ddx * ddx + ddy * ddy > reach * reach) continue;
+                const QuadBall qb_ = quad_ball_of(w, q);
+                if (!((kind_mask >> qb_.kind) & 1u)) continue;
+                const float far = reach + qb_.rr;
+                const float px = qb_.mx - me.cx, py = qb_.my - me.cy;
+                if (px * px + py * py > far * far) continue;
                 l_list[atomicAdd(l_cnt, 1)] = q;
             }
             __syncthreads();
@@ -251,19 +276,15 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
             for (int it = tid; it < n * n_beams; it += kBlock) {
                 const int qi = it / n_beams, i = it - qi * n_beams;
                 const int q = l_list[qi];
-                const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
                 const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
                 const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;   // the beam's direction, |u| = 1 up to rounding
                 // conservative pre-test: the quad's bounding circle against the beam's line and extent
-                const float mx = 0.25f * (lo.x + lo.z + hi.x + hi.z), my = 0.25f * (lo.y + lo.w + hi.y + hi.w);
-                const float r2 = md_max(md_max((lo.x - mx) * (lo.x - mx) + (lo.y - my) * (lo.y - my),
-                                               (lo.z - mx) * (lo.z - mx) + (lo.w - my) * (lo.w - my)),
-                                        md_max((hi.x - mx) * (hi.x - mx) + (hi.y - my) * (hi.y - my),
-                                               (hi.z - mx) * (hi.z - mx) + (hi.w - my) * (hi.w - my)));
-                const float rr = md_sqrt(r2) * 1.01f + 1.0e-3f;
-                const float px = mx - me.cx, py = my - me.cy;
+                const QuadBall qb_ = quad_ball_of(w, q);
+                const float rr = qb_.rr;
+                const float px = qb_.mx - me.cx, py = qb_.my - me.cy;
                 const float perp = ux * py - uy * px, along = ux * px + uy * py;
                 if (md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr) continue;
+                const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
                 const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
                 if (t < 1.0f) atomicMin(&l_best[a * n_beams + i], __float_as_int(t));
@@ -2123,6 +2144,33 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     MD_FINE_STAMP(st_, so_ + 5);
 }
 
+// One detector fan of one agent against the quads [qa, qb) of its map by ONE wave: lanes = quads; a lane whose quad is of
+// a wanted kind and within reach tries every beam on it, behind the bounding-circle pre-test; hits go to `best` (LDS, bit
+// patterns of the fractions, initialised to 1.0) through atomicMin.  The wave-level form of line_detector_kernel for
+// kernels that have waves to spare (same arithmetic, same minima).
+__device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& me, int qa, int qb, const float* beam_cs, int n_beams,
+                              float range, uint32_t kind_mask, int* best, int lane_id) {
+    const float reach = range * 1.001f;
+    const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
+    for (int q = qa + lane_id; q < qb; q += 64) {
+        const QuadBall b = quad_ball_of(w, q);
+        if (!((kind_mask >> b.kind) & 1u)) continue;
+        const float far = reach + b.rr;
+        const float px = b.mx - me.cx, py = b.my - me.cy;
+        if (px * px + py * py > far * far) continue;
+        for (int i = 0; i < n_beams; ++i) {
+            const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+            const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+            const float perp = ux * py - uy * px, along = ux * px + uy * py;
+            if (md_fabs(perp) > b.rr * 1.001f + 1.0e-3f || along < -b.rr || along > reach + b.rr) continue;
+            const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
+            if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
+        }
+    }
+}
+
 // Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
 // are then resident at once, one round instead of two (measured 148 vs 173 us at the compiler's own choice)
 #ifndef MD_SC_WAVES_EU
@@ -2150,6 +2198,9 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     uint32_t* l_cfl = l_flags + cap;
     MdTrajLoc* l_loc = reinterpret_cast<MdTrajLoc*>(l_cfl + ((cap + 3) & ~3));   // [A]
     int* l_count = reinterpret_cast<int*>(l_loc + A);
+    int* l_dbest = l_count + 4;   // [A][n_side + n_lane_line] detector fractions (bit patterns), when md_step runs the detectors
+    const bool fused_det = (w.side_beam_cs != nullptr && c.n_side > 0) || (w.ll_beam_cs != nullptr && c.n_lane_line > 0);
+    const int n_det = (w.side_beam_cs ? c.n_side : 0) + (w.ll_beam_cs ? c.n_lane_line : 0);
 
     MD_STAMP_AT(0);
     const MdState gv = md_env_view(&g, &c, e);
@@ -2249,6 +2300,9 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     __syncthreads();
     MD_STAMP_AT(4);
     // ---- the agents: projection on the reference trajectory (wave 0) beside their contacts (wave 1) ----
+    if (fused_det)
+        for (int it = tid; it < A * n_det; it += kBlock) l_dbest[it] = __float_as_int(1.0f);
+    if (fused_det) __syncthreads();
     for (int a = 0; a < A; ++a) {
         if (wave == 0) {
             const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
@@ -2257,6 +2311,22 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             if (lane == 0) l_loc[a] = L;
         } else if (wave == 1) {
             contacts_vehicle(w, s, c, e, a, lane, l_cfl);
+        } else if (fused_det) {
+            // waves 2 and 3 have nothing to do in this stage and the next: the side / lane-line detectors of the agent,
+            // each wave one half of the scene's line pieces (the poses are final here)
+            const MdShape me = s.shape[a];
+            if (md_present(me.flags)) {
+                const int mq = w.env_map[e];
+                const int q0 = w.quad_off[mq], q1 = w.quad_off[mq + 1];
+                const int half = (q1 - q0 + 1) >> 1;
+                const int qa = q0 + (wave - 2) * half, qb = min(qa + half, q1);
+                int* best = l_dbest + a * n_det;
+                if (w.side_beam_cs && c.n_side > 0)
+                    detector_wave(w, me, qa, qb, w.side_beam_cs, c.n_side, c.side_range, c.side_mask, best, lane);
+                if (w.ll_beam_cs && c.n_lane_line > 0)
+                    detector_wave(w, me, qa, qb, w.ll_beam_cs, c.n_lane_line, c.ll_range, c.ll_mask,
+                                  best + (w.side_beam_cs ? c.n_side : 0), lane);
+            }
         }
     }
     __syncthreads();
@@ -2284,6 +2354,15 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
     __syncthreads();
     MD_STAMP_AT(7);
+    if (fused_det) {   // after the observation (whose lane 0 filled these dims with "nothing seen")
+        const int ns = w.side_beam_cs ? c.n_side : 0;
+        for (int it = tid; it < A * n_det; it += kBlock) {
+            const int a = it / n_det, i = it - a * n_det;
+            float* o = s.obs + (size_t)a * c.obs_dim;
+            if (i < ns) o[md_obs_base(&c) + i] = __int_as_float(l_dbest[it]);
+            else o[md_obs_ll(&c) + (i - ns)] = __int_as_float(l_dbest[it]);
+        }
+    }
     copy16(gv.shape, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
     copy16(gv.dyn, l_dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
     copy16(gv.pid, l_pid, cap * (int)sizeof(MdPid), tid, kBlock);
@@ -3114,7 +3193,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
             return MD_EINVAL;
         }
         const size_t lds = (size_t)c->cap * (4 * 32 + 64 + 8 + 4) + (size_t)((c->cap + 3) & ~3) * 4 +
-                           (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16;
+                           (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
+                           (size_t)c->agents_per_env * (size_t)(c->n_side + c->n_lane_line) * sizeof(int);
         if (lds > 64 * 1024) {
             snprintf(g_err, sizeof g_err, "scenario mode: LDS image needs %zu B (cap=%d)", lds, c->cap);
             return MD_EINVAL;

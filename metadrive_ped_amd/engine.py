@@ -392,9 +392,21 @@ class BatchedEngine:
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
         wd["n_dest_host"] = h.spawn["n_dest"] if h.spawn is not None else (1 if h.traffic_respawns else 0)
         wd["n_vclass_host"] = len(h.world.arrays["vclass"]) if "vclass" in h.world.arrays else 0
-        self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         self._side_beams = self._to_dev(h.side_beams) if h.side_beams is not None else None
         self._ll_beams = self._to_dev(h.ll_beams) if h.ll_beams is not None else None
+        # scenario mode: md_step runs the side / lane-line detectors itself (MdWorld.side_beam_cs / ll_beam_cs) on waves that
+        # idle while the agent is observed; the other modes call md_line_detector after md_step
+        self._fused_detectors = bool(self.cfg.get("scenario_mode")) and (h.n_side > 0 or h.n_ll > 0)
+        if self._fused_detectors:
+            vc = self.cfg["vehicle_config"]
+            if self._side_beams is not None:
+                wd["side_beam_cs"] = self._side_beams
+            if self._ll_beams is not None:
+                wd["ll_beam_cs"] = self._ll_beams
+            h.md_config.side_range = float(vc["side_detector"]["distance"])
+            h.md_config.ll_range = float(vc["lane_line_detector"]["distance"])
+            h.md_config.side_mask, h.md_config.ll_mask = self.SIDE_MASK, self.LANE_LINE_MASK
+        self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
         sd = self.state_dev
         # typed views for the env API
         self.obs = sd["obs"].view(torch.float32).view(self.E, self.A, self.obs_dim)
@@ -441,10 +453,12 @@ class BatchedEngine:
     def _step_raw(self):
         self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
         h = self.host
-        if h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
+        if self._fused_detectors:
+            pass
+        elif h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
             self.line_detector(self._side_beams, h.n_side, float(self.cfg["vehicle_config"]["side_detector"]["distance"]),
                                self.SIDE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base)
-        if h.n_ll:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
+        if h.n_ll and not self._fused_detectors:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
             self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
                                self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base + (h.n_side or 2) + 6)
         self._lidar_noise()

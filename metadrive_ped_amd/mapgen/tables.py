@@ -429,6 +429,15 @@ class WorldTables:
         a["quad_off"] = np.asarray(quad_off, dtype=np.int32)
         a["quads"] = np.concatenate(quads).astype(np.float32).reshape(-1, 8)
         a["quad_kind"] = np.concatenate(qk).astype(np.int32)
+        # bounding circles of the quads (MdWorld.quad_ball): centre = mean of the vertices, radius rounded up
+        q4 = a["quads"].astype(np.float64).reshape(-1, 4, 2)
+        ctr = q4.mean(axis=1)
+        rad = np.sqrt(((q4 - ctr[:, None, :]) ** 2).sum(axis=2)).max(axis=1) * 1.0001 + 1.0e-3
+        ball = np.zeros((len(q4), 4), np.float32)
+        ball[:, 0:2] = ctr
+        ball[:, 2] = rad
+        ball[:, 3] = a["quad_kind"].view(np.float32) if len(q4) == len(a["quad_kind"]) else 0.0
+        a["quad_ball"] = ball
         a["grid"] = np.concatenate(grids)
         a["cell_start"] = np.concatenate(cstart).astype(np.int32)
         a["cell_items"] = np.concatenate(citems).astype(np.int32)
@@ -447,7 +456,7 @@ class WorldTables:
                 a[k] = np.ascontiguousarray(np.concatenate([m.respawn[k] for m in maps]))
             self.n_dest = 1
         # guard: padding arrays that may legitimately be empty
-        for k in ("quads", "quad_kind", "cell_items", "node_adj", "hull_xy"):
+        for k in ("quads", "quad_kind", "quad_ball", "cell_items", "node_adj", "hull_xy"):
             if a[k].size == 0:
                 a[k] = np.zeros((1, ) + a[k].shape[1:], dtype=a[k].dtype)
 
