@@ -249,6 +249,8 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
     int* l_best = l_ld;                    // [A * n_beams] bit patterns of the closest fractions
     int* l_list = l_ld + A * n_beams;      // [kLdChunk] reachable quads of the current chunk
     int* l_cnt = l_list + kLdChunk;
+    float* l_bm = reinterpret_cast<float*>(l_cnt + 4);   // [n_beams][2] the beam table (read once per (quad, beam) pair)
+    for (int it = threadIdx.x; it < 2 * n_beams; it += kBlock) l_bm[it] = beam_cs[it];
     const int e = blockIdx.x, tid = threadIdx.x;
     const int m = w.env_map[e];
     const int q0 = w.quad_off[m], q1 = w.quad_off[m + 1];
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
             for (int it = tid; it < n * n_beams; it += kBlock) {
                 const int qi = it / n_beams, i = it - qi * n_beams;
                 const int q = l_list[qi];
-                const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+                const float bc = l_bm[2 * i], bs = l_bm[2 * i + 1];
                 const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;   // the beam's direction, |u| = 1 up to rounding
                 // conservative pre-test: the quad's bounding circle against the beam's line and extent
                 const QuadBall qb_ = quad_ball_of(w, q);
@@ -2158,13 +2160,15 @@ __device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& m
         const float far = reach + b.rr;
         const float px = b.mx - me.cx, py = b.my - me.cy;
         if (px * px + py * py > far * far) continue;
+        // the quad itself is fetched HERE, once and by all reachable lanes together: inside the beam loop it would be a
+        // cold read per beam for the whole wave as soon as one lane's circle is met (measured: 80 k instead of 7 k cycles)
+        const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         for (int i = 0; i < n_beams; ++i) {
             const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
             const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
             const float perp = ux * py - uy * px, along = ux * px + uy * py;
             if (md_fabs(perp) > b.rr * 1.001f + 1.0e-3f || along < -b.rr || along > reach + b.rr) continue;
-            const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
-            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
             const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
             if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
         }
@@ -2300,9 +2304,14 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     __syncthreads();
     MD_STAMP_AT(4);
     // ---- the agents: projection on the reference trajectory (wave 0) beside their contacts (wave 1) ----
-    if (fused_det)
+    float* l_beams = reinterpret_cast<float*>(l_dbest + A * n_det);   // [n_det][2]: the beam tables, read n_beams times per quad
+    if (fused_det) {
+        const int ns = w.side_beam_cs ? c.n_side : 0;
         for (int it = tid; it < A * n_det; it += kBlock) l_dbest[it] = __float_as_int(1.0f);
-    if (fused_det) __syncthreads();
+        for (int it = tid; it < 2 * n_det; it += kBlock)
+            l_beams[it] = (it < 2 * ns) ? w.side_beam_cs[it] : w.ll_beam_cs[it - 2 * ns];
+        __syncthreads();
+    }
     for (int a = 0; a < A; ++a) {
         if (wave == 0) {
             const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
@@ -2321,11 +2330,11 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
                 const int half = (q1 - q0 + 1) >> 1;
                 const int qa = q0 + (wave - 2) * half, qb = min(qa + half, q1);
                 int* best = l_dbest + a * n_det;
+                const int ns = w.side_beam_cs ? c.n_side : 0;
                 if (w.side_beam_cs && c.n_side > 0)
-                    detector_wave(w, me, qa, qb, w.side_beam_cs, c.n_side, c.side_range, c.side_mask, best, lane);
+                    detector_wave(w, me, qa, qb, l_beams, c.n_side, c.side_range, c.side_mask, best, lane);
                 if (w.ll_beam_cs && c.n_lane_line > 0)
-                    detector_wave(w, me, qa, qb, w.ll_beam_cs, c.n_lane_line, c.ll_range, c.ll_mask,
-                                  best + (w.side_beam_cs ? c.n_side : 0), lane);
+                    detector_wave(w, me, qa, qb, l_beams + 2 * ns, c.n_lane_line, c.ll_range, c.ll_mask, best + ns, lane);
             }
         }
     }
@@ -3045,7 +3054,7 @@ __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, co
                  out_offset, (double)range);
         return MD_EINVAL;
     }
-    const size_t lds_ld = ((size_t)c->agents_per_env * (size_t)n_beams + kLdChunk + 4) * sizeof(int);
+    const size_t lds_ld = ((size_t)c->agents_per_env * (size_t)n_beams + kLdChunk + 8 + 2 * (size_t)n_beams) * sizeof(int);
     if (lds_ld > 60 * 1024) {
         snprintf(g_err, sizeof g_err, "md_line_detector: %d agents x %d beams do not fit the LDS", c->agents_per_env, n_beams);
         return MD_EINVAL;
@@ -3194,7 +3203,7 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
         }
         const size_t lds = (size_t)c->cap * (4 * 32 + 64 + 8 + 4) + (size_t)((c->cap + 3) & ~3) * 4 +
                            (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
-                           (size_t)c->agents_per_env * (size_t)(c->n_side + c->n_lane_line) * sizeof(int);
+                           (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int);
         if (lds > 64 * 1024) {
             snprintf(g_err, sizeof g_err, "scenario mode: LDS image needs %zu B (cap=%d)", lds, c->cap);
             return MD_EINVAL;
