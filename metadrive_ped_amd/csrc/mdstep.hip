@@ -2146,33 +2146,69 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     MD_FINE_STAMP(st_, so_ + 5);
 }
 
-// One detector fan of one agent against the quads [qa, qb) of its map by ONE wave: lanes = quads; a lane whose quad is of
-// a wanted kind and within reach tries every beam on it, behind the bounding-circle pre-test; hits go to `best` (LDS, bit
-// patterns of the fractions, initialised to 1.0) through atomicMin.  The wave-level form of line_detector_kernel for
-// kernels that have waves to spare (same arithmetic, same minima).
-__device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& me, int qa, int qb, const float* beam_cs, int n_beams,
-                              float range, uint32_t kind_mask, int* best, int lane_id) {
-    const float reach = range * 1.001f;
+// One detector fan of one agent against the quads [qa, qb) of its map by ONE wave, in two phases so that the expensive
+// slab tests run on full wavefronts: (1) lanes = quads: kind, reach, then every beam against the quad's bounding circle
+// (a dozen instructions); the (quad, beam) pairs that survive -- a few per hundred -- are appended to `pairs` (LDS,
+// kDetPairs ints of this wave) through ballot prefix counts; (2) lanes = pairs: fetch the quad, cast, atomicMin on the
+// fraction's bit pattern in `best` (initialised to 1.0).  The list is drained whenever a pass could overflow it.  Same
+// arithmetic and the same minima as line_detector_kernel and the oracle's serial loop.
+constexpr int kDetPairs = 512;
+__device__ __forceinline__ void detector_drain(const MdWorld& w, const MdShape& me, const float* beam_cs, float range, const int* pairs, int n,
+                               int qa, int* best, int lane_id) {   // a pair = (quad - qa) << 8 | beam
     const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
-    for (int q = qa + lane_id; q < qb; q += 64) {
-        const QuadBall b = quad_ball_of(w, q);
-        if (!((kind_mask >> b.kind) & 1u)) continue;
-        const float far = reach + b.rr;
-        const float px = b.mx - me.cx, py = b.my - me.cy;
-        if (px * px + py * py > far * far) continue;
-        // the quad itself is fetched HERE, once and by all reachable lanes together: inside the beam loop it would be a
-        // cold read per beam for the whole wave as soon as one lane's circle is met (measured: 80 k instead of 7 k cycles)
+    for (int k = lane_id; k < n; k += 64) {
+        const int pr = pairs[k];
+        const int q = qa + (pr >> 8), i = pr & 255;
         const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
         const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+        const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+        const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
+        if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
+    }
+}
+
+__device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& me, int qa, int qb, const float* beam_cs, int n_beams,
+                              float range, uint32_t kind_mask, int* best, int* pairs, int lane_id) {
+    const float reach = range * 1.001f;
+    int cnt = 0;   // wave-uniform
+    for (int q0 = qa; q0 < qb; q0 += 64) {
+        const int q = q0 + lane_id;
+        bool near = false;
+        float px = 0.0f, py = 0.0f, rr = 0.0f;
+        if (q < qb) {
+            const QuadBall b = quad_ball_of(w, q);
+            px = b.mx - me.cx;
+            py = b.my - me.cy;
+            rr = b.rr;
+            const float far = reach + rr;
+            near = ((kind_mask >> b.kind) & 1u) && !(px * px + py * py > far * far);
+        }
+        if (__ballot(near) == 0ull) continue;
         for (int i = 0; i < n_beams; ++i) {
             const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
             const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
             const float perp = ux * py - uy * px, along = ux * px + uy * py;
-            if (md_fabs(perp) > b.rr * 1.001f + 1.0e-3f || along < -b.rr || along > reach + b.rr) continue;
-            const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
-            if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
+            const bool pass = near && !(md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr);
+            const unsigned long long m = __ballot(pass);
+            if (m == 0ull) continue;
+            if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
+                __builtin_amdgcn_wave_barrier();
+                cnt = 0;
+            }
+            if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q - qa) << 8) | i;
+            cnt += __popcll(m);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
@@ -2331,10 +2367,11 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
                 const int qa = q0 + (wave - 2) * half, qb = min(qa + half, q1);
                 int* best = l_dbest + a * n_det;
                 const int ns = w.side_beam_cs ? c.n_side : 0;
+                int* pairs = reinterpret_cast<int*>(l_beams + 2 * n_det) + (wave - 2) * kDetPairs;   // this wave's pair list
                 if (w.side_beam_cs && c.n_side > 0)
-                    detector_wave(w, me, qa, qb, l_beams, c.n_side, c.side_range, c.side_mask, best, lane);
+                    detector_wave(w, me, qa, qb, l_beams, c.n_side, c.side_range, c.side_mask, best, pairs, lane);
                 if (w.ll_beam_cs && c.n_lane_line > 0)
-                    detector_wave(w, me, qa, qb, l_beams + 2 * ns, c.n_lane_line, c.ll_range, c.ll_mask, best + ns, lane);
+                    detector_wave(w, me, qa, qb, l_beams + 2 * ns, c.n_lane_line, c.ll_range, c.ll_mask, best + ns, pairs, lane);
             }
         }
     }
@@ -3203,7 +3240,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
         }
         const size_t lds = (size_t)c->cap * (4 * 32 + 64 + 8 + 4) + (size_t)((c->cap + 3) & ~3) * 4 +
                            (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
-                           (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int);
+                           (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int) +
+                           ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0);
         if (lds > 64 * 1024) {
             snprintf(g_err, sizeof g_err, "scenario mode: LDS image needs %zu B (cap=%d)", lds, c->cap);
             return MD_EINVAL;
