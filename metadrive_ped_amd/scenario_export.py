@@ -63,6 +63,37 @@ def _lane_features(mt):
             "width": np.full((len(poly), 2), float(rec["width"]) / 2.0, dtype=np.float32),
         }
     assert len(feats) == n
+    feats.update(_line_features(mt))
+    return feats
+
+
+def _line_features(mt, interval=2.0):
+    """PGMap.get_boundary_line_vector (component/map/pg_map.py:130-167): the left line of every lane and the right line of the
+    last lane of each road, typed by PGLineType / colour (SIDE lines are solid white), sampled every `interval` m at +-
+    width / 2 -- the features ScenarioBlock turns into line bodies when the export is loaded as a scenario."""
+    from metadrive_ped_amd.mapgen.lanes import COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_NONE, LINE_SIDE
+    feats = {}
+    for k, lane in enumerate(mt.lane_objs):
+        rec = mt.lanes[k]
+        last = int(rec["idx"]) + 1 == int(rec["n_in_road"])
+        decoration = tuple(lane.index[:2]) == ("decoration", "decoration_")
+        for side in range(2 if (last or decoration) else 1):
+            lt, color = lane.line_types[side], lane.line_colors[side]
+            if lt == LINE_NONE:
+                continue
+            yellow = color == COLOR_YELLOW
+            if lt == LINE_CONTINUOUS:
+                typ = "ROAD_LINE_SOLID_SINGLE_YELLOW" if yellow else "ROAD_LINE_SOLID_SINGLE_WHITE"
+            elif lt == LINE_BROKEN:
+                typ = "ROAD_LINE_BROKEN_SINGLE_YELLOW" if yellow else "ROAD_LINE_BROKEN_SINGLE_WHITE"
+            elif lt == LINE_SIDE:
+                typ = "ROAD_LINE_SOLID_SINGLE_WHITE"
+            else:
+                typ = "UNKNOWN_LINE"
+            lateral = float(lane.width) / 2.0 * (-1.0 if side == 0 else 1.0)
+            ss = list(np.arange(0.0, lane.length, interval)) + [lane.length]
+            poly = np.asarray([lane.position(float(x), lateral) for x in ss], dtype=np.float32)
+            feats["lane_%d_%d" % (k, side)] = {"type": typ, "polyline": poly, "speed_limit_kmh": float(getattr(lane, "speed_limit", 1000.0))}
     return feats
 
 

@@ -52,7 +52,8 @@ def _sanity(sc):
             assert abs(np.sum(a[~valid])) < 1e-2, (oid, k)
         assert tr["metadata"]["object_id"] == oid and "type" in tr["metadata"]
     for f in sc["map_features"].values():
-        assert f["type"].startswith("LANE_") and isinstance(f["polyline"], np.ndarray) and f["polyline"].shape[1] == 2
+        assert f["type"].startswith(("LANE_", "ROAD_LINE_", "UNKNOWN_LINE")) and isinstance(f["polyline"], np.ndarray)
+        assert f["polyline"].shape[1] == 2
 
 
 def test_export_matches_the_reference_summaries_of_the_same_episode():
@@ -101,8 +102,13 @@ def test_tracks_equal_the_recorded_frames_and_lanes_cover_the_map():
             d = np.hypot(polys[:, 0] - ego["state"]["position"][t, 0], polys[:, 1] - ego["state"]["position"][t, 1]).min()
             assert d < 4.0
         mt = host.map_tables[int(host.world.arrays["env_map"][e])]
-        assert len(sc["map_features"]) == len(mt.lane_objs)
-        for k, f in sc["map_features"].items():
+        lanes_f = {k: f for k, f in sc["map_features"].items() if f["type"].startswith("LANE_")}
+        lines_f = {k: f for k, f in sc["map_features"].items() if not f["type"].startswith("LANE_")}
+        assert len(lanes_f) == len(mt.lane_objs)
+        # PGMap.get_boundary_line_vector: the left line of every lane that has one, plus the right line of each road's last lane
+        assert len(lines_f) >= len(mt.roads) and {f["type"] for f in lines_f.values()} >= {"ROAD_LINE_SOLID_SINGLE_WHITE",
+                                                                                         "ROAD_LINE_BROKEN_SINGLE_WHITE"}
+        for k, f in lanes_f.items():
             for other in f["exit_lanes"] + f["entry_lanes"] + f["left_neighbor"] + f["right_neighbor"]:
                 assert other in sc["map_features"]
             seg = np.hypot(*np.diff(f["polyline"], axis=0).T)
