@@ -238,22 +238,24 @@ def line_pieces(polyline, broken):
     """The stripes ScenarioBlock.construct_continuous_line / construct_broken_line cut a road line into
     (component/scenario_block/scenario_block.py:74-99): [(start, end)] in order."""
     line = PolyLine(polyline)
-    out = []
     if broken:
         n = int(line.length / (2 * STRIPE_LENGTH))
-        for k in range(n):
-            a = line.position(k * STRIPE_LENGTH * 2)
-            b = line.position(k * STRIPE_LENGTH * 2 + STRIPE_LENGTH)
-            if k == n - 1:
-                b = line.position(line.length - STRIPE_LENGTH)
-            out.append((a, b))
+        k = np.arange(n, dtype=np.float64)
+        sa = k * STRIPE_LENGTH * 2
+        sb = k * STRIPE_LENGTH * 2 + STRIPE_LENGTH
+        if n:
+            sb[-1] = line.length - STRIPE_LENGTH
     else:
         n = int(line.length / STRIPE_LENGTH)
-        for k in range(n):
-            a = line.position(STRIPE_LENGTH * k)
-            b = line.position(line.length) if k == n - 1 else line.position((k + 1) * STRIPE_LENGTH)
-            out.append((a, b))
-    return out
+        k = np.arange(n, dtype=np.float64)
+        sa = STRIPE_LENGTH * k
+        sb = (k + 1) * STRIPE_LENGTH
+        if n:
+            sb[-1] = line.length
+    if n == 0:
+        return []
+    pa, pb = line.positions(sa), line.positions(sb)      # get_point for all stripes at once (same piece rule)
+    return [(pa[i], pb[i]) for i in range(n)]
 
 
 def scene_line_quads(map_features, map_region_size):
