@@ -703,6 +703,61 @@ def section_scenario_lines():
                                      line_width=float(PGDrivableAreaProperty.LANE_LINE_WIDTH), cases=cases))
 
 
+def section_others():
+    """The "others" block of LidarStateObservation (obs/state_obs.py:172-183 -> Lidar.get_surrounding_vehicles_info,
+    component/sensors/lidar.py:93-138): the num_others nearest DETECTED vehicles, four dims each (relative position /
+    perceive_distance, relative velocity / max_speed, in the ego's frame), padded with zeros; non-vehicles among the detected
+    objects are dropped first (get_surrounding_vehicles, :76-83).  Fake vehicles (a BaseVehicle subclass with plain attributes);
+    convert_to_local_coordinates is supplied as (forward, left), as in agent_step."""
+    from metadrive.component.sensors.lidar import Lidar
+    from metadrive.component.vehicle.base_vehicle import BaseVehicle
+    from metadrive.utils.math import Vector
+
+    class FakeVehicle(BaseVehicle):     # plain attributes instead of the Panda-backed properties
+        position = None
+        velocity_km_h = None
+        max_speed_km_h = 80.0
+        navigation = None
+        heading = None
+
+        def convert_to_local_coordinates(self, vec, origin):
+            hx, hy = self.heading
+            dx, dy = vec[0] - origin[0], vec[1] - origin[1]
+            return np.array([dx * hx + dy * hy, dy * hx - dx * hy])
+
+    def make(pos, heading, speed):
+        v = object.__new__(FakeVehicle)
+        v.position = Vector((float(pos[0]), float(pos[1])))
+        v.heading = (math.cos(heading), math.sin(heading))
+        v.velocity_km_h = Vector((speed * 3.6 * math.cos(heading), speed * 3.6 * math.sin(heading)))
+        return v
+    rng = np.random.RandomState(31)
+    lidar = object.__new__(Lidar)
+    cases = []
+    for ci in range(40):
+        ego_h = float(rng.uniform(-3.1, 3.1))
+        ego = make(rng.uniform(-50, 50, 2), ego_h, float(rng.uniform(0, 22)))
+        n = int(rng.randint(0, 9))
+        others, objs = [], []
+        for k in range(n):
+            d, a = float(rng.uniform(3, 70)), float(rng.uniform(-3.1, 3.1))    # some beyond the 50 m perceive distance
+            pos = (ego.position[0] + d * math.cos(a), ego.position[1] + d * math.sin(a))
+            h, sp = float(rng.uniform(-3.1, 3.1)), float(rng.uniform(0, 25))
+            is_vehicle = bool(rng.rand() < 0.8)
+            if is_vehicle:
+                objs.append(make(pos, h, sp))
+            else:
+                objs.append(MagicMock())      # a cone / pedestrian body: not a BaseVehicle
+            others.append(dict(pos=[float(pos[0]), float(pos[1])], heading=h, speed=sp, vehicle=is_vehicle))
+        num_others = int(rng.choice([1, 2, 4, 6]))
+        dist = float(rng.choice([30.0, 50.0]))
+        res = Lidar.get_surrounding_vehicles_info(lidar, ego, set(objs), dist, num_others, False)
+        cases.append(dict(ego=dict(pos=[float(ego.position[0]), float(ego.position[1])], heading=ego_h,
+                                   speed=float(math.hypot(*ego.velocity_km_h) / 3.6)),
+                          others=others, num_others=num_others, perceive_distance=dist, info=[float(x) for x in res]))
+    dump("others.json", dict(frame_supplied_by_generator="(forward, left)", cases=cases))
+
+
 def section_ma_bidirection():
     """Map of MultiAgentBidirectionEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 3 m) +
     Bidirection (one lane shared by both directions, seed 1) + Split (back to 4, exit 60 m) as MABidirectionMap._generate
@@ -1403,7 +1458,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -635,6 +635,15 @@ EXPORT int ref_scenario_observe(const MdWorld* w, const MdState* s, const MdConf
     }
     return MD_OK;
 }
+/* probe: the "others" block of agent a of env e for a given detected set (Lidar.get_surrounding_vehicles_info) */
+EXPORT int ref_others_block(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int a, uint64_t det_lo, uint64_t det_hi,
+                            float* out) {
+    MdState v = md_env_view(s, c, e);
+    const int m = w->env_map[e];
+    md_others_block(w->lanes + w->lane_off[m], w->roads + w->road_off[m], &v, c, a, det_lo, det_hi, out);
+    return MD_OK;
+}
+
 /* TrajectoryIDMPolicy.act of one slot at episode step k */
 EXPORT int ref_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, int k) {
     MdState v = md_env_view(s, c, e);
