@@ -91,7 +91,8 @@ def main():
               (name, x.mean(), np.median(x), np.percentile(x, 99), x.max(), 100.0 * x.sum() / tot.sum()))
     ok = (fine[:, 0] > 0) & (fine[:, 3] > 0)
     lf = fine[ok]
-    print("localize(agent) fine: grid+cell loads %.0f | items+AABB %.0f | hull tests+frenet %.0f  (p50 cycles); candidates p50 %d, cell items p50 %d" % (
+    if len(lf):
+      print("localize(agent) fine: grid+cell loads %.0f | items+AABB %.0f | hull tests+frenet %.0f  (p50 cycles); candidates p50 %d, cell items p50 %d" % (
         np.median(lf[:, 1] - lf[:, 0]), np.median(lf[:, 2] - lf[:, 1]), np.median(lf[:, 3] - lf[:, 2]),
         np.median(lf[:, 15] & 0xffffffff), np.median(lf[:, 15] >> 32)))
     ok = (fine[:, 4] > 0) & (fine[:, 7] > fine[:, 4])
