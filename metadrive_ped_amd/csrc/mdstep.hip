@@ -231,67 +231,132 @@ __device__ __forceinline__ QuadBall quad_ball_of(const MdWorld& w, int q) {
     return b;
 }
 
-// Side / lane-line detector: beams vs static quads of the env's map.  One workgroup per env.  Per agent, the map's quads
-// go through LDS in chunks: first the quads that can be reached at all -- kind wanted, box within `range` of the agent (a hit
-// closer than `range` cannot lie on a quad whose box is farther away) -- are compacted into a list, then the (quad,
-// beam) pairs of that list are dealt evenly to the threads.  A pair is only cast when the beam's line passes the
-// quad's bounding circle (a dozen instructions against the ~150 of the slab test: with ~400 reachable line pieces and
-// 12 beams per scene the full tests alone were VALU-bound at ~37 us for 2048 scenes).  The closest fractions meet in LDS
-// through atomicMin on the bit patterns (fractions are positive floats, whose order is that of their bits).  Same
-// minima as the oracle's serial loop over all quads; one thread per beam walking all of them took 1 ms.
-constexpr int kLdChunk = 2048;
+// One detector fan of one agent against the quads [qa, qb) of its map by ONE wave, in two phases so that the expensive
+// slab tests run on full wavefronts: (1) lanes = quads: kind, reach, then every beam against the quad's bounding circle
+// (a dozen instructions); the (quad, beam) pairs that survive -- a few per hundred -- are appended to `pairs` (LDS,
+// kDetPairs ints of this wave) through ballot prefix counts; (2) lanes = pairs: fetch the quad, cast, atomicMin on the
+// fraction's bit pattern in `best` (initialised to 1.0).  The list is drained whenever a pass could overflow it.  Same
+// arithmetic and the same minima as line_detector_kernel and the oracle's serial loop.
+constexpr int kDetPairs = 512;
+__device__ __forceinline__ void detector_drain(const MdWorld& w, const MdShape& me, const float* beam_cs, float range, const int* pairs, int n,
+                               int qa, int* best, int lane_id) {   // a pair = (quad - qa) << 8 | beam
+    const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
+    for (int k = lane_id; k < n; k += 64) {
+        const int pr = pairs[k];
+        const int q = qa + (pr >> 8), i = pr & 255;
+        const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+        const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+        const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
+        if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
+    }
+}
+
+__device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& me, int qa, int qb, const float* beam_cs, int n_beams,
+                              float range, uint32_t kind_mask, int* best, int* pairs, int lane_id) {
+    const float reach = range * 1.001f;
+    // is the table a uniform fan?  beam i = (cos, sin)(phase0 + i 2 pi / n): one lane per beam compares
+    const float phase0 = atan2f(beam_cs[1], beam_cs[0]);
+    const float dphi = 6.283185307179586f / (float)n_beams, inv_dphi = 1.0f / dphi;
+    bool fan_ok = true;
+    for (int i = lane_id; i < n_beams; i += 64) {
+        float sn, cs;
+        sincosf(phase0 + (float)i * dphi, &sn, &cs);
+        fan_ok = fan_ok && md_fabs(cs - beam_cs[2 * i]) < 1.0e-3f && md_fabs(sn - beam_cs[2 * i + 1]) < 1.0e-3f;
+    }
+    const bool uniform_fan = __ballot(!fan_ok) == 0ull && n_beams >= 4;
+    int cnt = 0;   // wave-uniform
+    for (int q0 = qa; q0 < qb; q0 += 64) {
+        const int q = q0 + lane_id;
+        bool near = false;
+        float px = 0.0f, py = 0.0f, rr = 0.0f;
+        if (q < qb) {
+            const QuadBall b = quad_ball_of(w, q);
+            px = b.mx - me.cx;
+            py = b.my - me.cy;
+            rr = b.rr;
+            const float far = reach + rr;
+            near = ((kind_mask >> b.kind) & 1u) && !(px * px + py * py > far * far);
+        }
+        if (__ballot(near) == 0ull) continue;
+        // Which beams can meet this quad at all?  For a uniform fan (beam i at phase0 + i dphi from the heading -- every
+        // detector table is one; checked below, else all beams are tried) only those within asin(r / d) of the direction
+        // to the quad's centre: a handful instead of all 12 ... 72.  Hardware atan2 / asin are good enough here, a margin
+        // covers them and the exact circle test follows anyway.
+        int i_lo = 0, n_try = n_beams;
+        if (uniform_fan && near) {
+            const float d2 = px * px + py * py;
+            if (d2 > rr * rr * 1.0201f) {
+                const float lx = px * me.c + py * me.s, ly = py * me.c - px * me.s;   // the centre in the agent's frame
+                const float half = asinf(md_min(rr * 1.01f * rsqrtf(d2), 1.0f)) + 0.02f;
+                float rel = atan2f(ly, lx) - phase0;
+                const float lo = (rel - half) * inv_dphi, hi = (rel + half) * inv_dphi;
+                i_lo = (int)floorf(lo);
+                n_try = min((int)ceilf(hi) - i_lo + 1, n_beams);
+                i_lo = ((i_lo % n_beams) + n_beams) % n_beams;
+            }
+        }
+        int max_try = near ? n_try : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) max_try = max(max_try, __shfl_xor(max_try, off, 64));
+        for (int k = 0; k < max_try; ++k) {
+            int i = i_lo + k;
+            if (i >= n_beams) i -= n_beams;
+            const bool mine_ = near && k < n_try;
+            const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+            const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+            const float perp = ux * py - uy * px, along = ux * px + uy * py;
+            const bool pass = mine_ && !(md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr);
+            const unsigned long long m = __ballot(pass);
+            if (m == 0ull) continue;
+            if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
+                __builtin_amdgcn_wave_barrier();
+                cnt = 0;
+            }
+            if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q - qa) << 8) | i;
+            cnt += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Side / lane-line detector as an entry point of its own (md_line_detector): one workgroup per env, one WAVE per (agent,
+// part of the map's quads) item running detector_wave above -- four agents at a time without a workgroup barrier between
+// them; with fewer than four agents the quads are split four ways instead.  One thread per beam walking all quads, the
+// first form of this kernel, took 1 ms on a scenario scene's ~1100 line pieces; a workgroup-wide compaction per agent
+// 100 us per launch on the 40-agent tollgate env.
 __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdState s, MdConfig c,
                                                                const float* __restrict__ beam_cs, int n_beams,
                                                                float range, uint32_t kind_mask, float* out,
                                                                int out_stride, int out_offset) {
     extern __shared__ int l_ld[];
     const int A = c.agents_per_env;
-    int* l_best = l_ld;                    // [A * n_beams] bit patterns of the closest fractions
-    int* l_list = l_ld + A * n_beams;      // [kLdChunk] reachable quads of the current chunk
-    int* l_cnt = l_list + kLdChunk;
-    float* l_bm = reinterpret_cast<float*>(l_cnt + 4);   // [n_beams][2] the beam table (read once per (quad, beam) pair)
-    for (int it = threadIdx.x; it < 2 * n_beams; it += kBlock) l_bm[it] = beam_cs[it];
-    const int e = blockIdx.x, tid = threadIdx.x;
+    int* l_best = l_ld;                                              // [A * n_beams] bit patterns of the closest fractions
+    float* l_bm = reinterpret_cast<float*>(l_ld + A * n_beams);      // [n_beams][2] the beam table
+    int* l_pairs = reinterpret_cast<int*>(l_bm + 2 * n_beams);       // [kBlock / 64][kDetPairs]
+    const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = w.env_map[e];
     const int q0 = w.quad_off[m], q1 = w.quad_off[m + 1];
     for (int it = tid; it < A * n_beams; it += kBlock) l_best[it] = __float_as_int(1.0f);
-    const float reach = range * 1.001f;    // |beam| = range up to rounding
-    const float4* quads4 = reinterpret_cast<const float4*>(w.quads);   // [n][8] floats: two 16-byte halves per quad
-    for (int a = 0; a < A; ++a) {
+    for (int it = tid; it < 2 * n_beams; it += kBlock) l_bm[it] = beam_cs[it];
+    __syncthreads();
+    const int parts = (A >= kBlock / 64) ? 1 : kBlock / 64;
+    const int per = (q1 - q0 + parts - 1) / parts;
+    for (int it = wave; it < A * parts; it += kBlock / 64) {
+        const int a = it / parts, part = it - a * parts;
         const MdShape me = s.shape[e * c.cap + a];
-        if (!md_present(me.flags)) continue;   // block-uniform
-        for (int cb = q0; cb < q1; cb += kLdChunk) {
-            __syncthreads();
-            if (tid == 0) *l_cnt = 0;
-            __syncthreads();
-            const int ce = min(cb + kLdChunk, q1);
-            for (int q = cb + tid; q < ce; q += kBlock) {
-                const QuadBall qb_ = quad_ball_of(w, q);
-                if (!((kind_mask >> qb_.kind) & 1u)) continue;
-                const float far = reach + qb_.rr;
-                const float px = qb_.mx - me.cx, py = qb_.my - me.cy;
-                if (px * px + py * py > far * far) continue;
-                l_list[atomicAdd(l_cnt, 1)] = q;
-            }
-            __syncthreads();
-            const int n = *l_cnt;
-            for (int it = tid; it < n * n_beams; it += kBlock) {
-                const int qi = it / n_beams, i = it - qi * n_beams;
-                const int q = l_list[qi];
-                const float bc = l_bm[2 * i], bs = l_bm[2 * i + 1];
-                const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;   // the beam's direction, |u| = 1 up to rounding
-                // conservative pre-test: the quad's bounding circle against the beam's line and extent
-                const QuadBall qb_ = quad_ball_of(w, q);
-                const float rr = qb_.rr;
-                const float px = qb_.mx - me.cx, py = qb_.my - me.cy;
-                const float perp = ux * py - uy * px, along = ux * px + uy * py;
-                if (md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr) continue;
-                const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
-                if (t < 1.0f) atomicMin(&l_best[a * n_beams + i], __float_as_int(t));
-            }
-        }
+        if (!md_present(me.flags)) continue;
+        const int qa = q0 + part * per, qb = min(qa + per, q1);
+        detector_wave(w, me, qa, qb, l_bm, n_beams, range, kind_mask, l_best + a * n_beams, l_pairs + wave * kDetPairs, lane);
     }
     __syncthreads();
     for (int it = tid; it < A * n_beams; it += kBlock) {
@@ -2146,71 +2211,6 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     MD_FINE_STAMP(st_, so_ + 5);
 }
 
-// One detector fan of one agent against the quads [qa, qb) of its map by ONE wave, in two phases so that the expensive
-// slab tests run on full wavefronts: (1) lanes = quads: kind, reach, then every beam against the quad's bounding circle
-// (a dozen instructions); the (quad, beam) pairs that survive -- a few per hundred -- are appended to `pairs` (LDS,
-// kDetPairs ints of this wave) through ballot prefix counts; (2) lanes = pairs: fetch the quad, cast, atomicMin on the
-// fraction's bit pattern in `best` (initialised to 1.0).  The list is drained whenever a pass could overflow it.  Same
-// arithmetic and the same minima as line_detector_kernel and the oracle's serial loop.
-constexpr int kDetPairs = 512;
-__device__ __forceinline__ void detector_drain(const MdWorld& w, const MdShape& me, const float* beam_cs, float range, const int* pairs, int n,
-                               int qa, int* best, int lane_id) {   // a pair = (quad - qa) << 8 | beam
-    const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
-    for (int k = lane_id; k < n; k += 64) {
-        const int pr = pairs[k];
-        const int q = qa + (pr >> 8), i = pr & 255;
-        const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
-        const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
-        const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
-        if (t < 1.0f) atomicMin(&best[i], __float_as_int(t));
-    }
-}
-
-__device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& me, int qa, int qb, const float* beam_cs, int n_beams,
-                              float range, uint32_t kind_mask, int* best, int* pairs, int lane_id) {
-    const float reach = range * 1.001f;
-    int cnt = 0;   // wave-uniform
-    for (int q0 = qa; q0 < qb; q0 += 64) {
-        const int q = q0 + lane_id;
-        bool near = false;
-        float px = 0.0f, py = 0.0f, rr = 0.0f;
-        if (q < qb) {
-            const QuadBall b = quad_ball_of(w, q);
-            px = b.mx - me.cx;
-            py = b.my - me.cy;
-            rr = b.rr;
-            const float far = reach + rr;
-            near = ((kind_mask >> b.kind) & 1u) && !(px * px + py * py > far * far);
-        }
-        if (__ballot(near) == 0ull) continue;
-        for (int i = 0; i < n_beams; ++i) {
-            const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
-            const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
-            const float perp = ux * py - uy * px, along = ux * px + uy * py;
-            const bool pass = near && !(md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr);
-            const unsigned long long m = __ballot(pass);
-            if (m == 0ull) continue;
-            if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
-                __builtin_amdgcn_wave_barrier();
-                cnt = 0;
-            }
-            if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q - qa) << 8) | i;
-            cnt += __popcll(m);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    detector_drain(w, me, beam_cs, range, pairs, cnt, qa, best, lane_id);
-    __builtin_amdgcn_wave_barrier();
-}
-
 // Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
 // are then resident at once, one round instead of two (measured 148 vs 173 us at the compiler's own choice)
 #ifndef MD_SC_WAVES_EU
@@ -3091,7 +3091,11 @@ __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, co
                  out_offset, (double)range);
         return MD_EINVAL;
     }
-    const size_t lds_ld = ((size_t)c->agents_per_env * (size_t)n_beams + kLdChunk + 8 + 2 * (size_t)n_beams) * sizeof(int);
+    const size_t lds_ld = ((size_t)c->agents_per_env * (size_t)n_beams + 2 * (size_t)n_beams + (kBlock / 64) * (size_t)kDetPairs) * sizeof(int);
+    if (n_beams > 255) {   // a (quad, beam) pair keeps the beam in eight bits
+        snprintf(g_err, sizeof g_err, "md_line_detector: n_beams=%d > 255", n_beams);
+        return MD_EINVAL;
+    }
     if (lds_ld > 60 * 1024) {
         snprintf(g_err, sizeof g_err, "md_line_detector: %d agents x %d beams do not fit the LDS", c->agents_per_env, n_beams);
         return MD_EINVAL;
