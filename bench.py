@@ -445,7 +445,7 @@ def main():
         dt_api = time.perf_counter() - t0
         env_api = dict(value=round(n_api * E / dt_api, 1), unit="agent-steps/s", ms_per_step=round(dt_api / n_api * 1e3, 4),
                        steps=n_api, surface="BatchedMetaDriveEnv.step -> (obs, reward, terminated, truncated, LazyInfo): "
-                                            "one md_step launch + one fused flag test per step, info values on demand")
+                                            "one md_step launch per step and no other device op (terminated / truncated are written by the kernel: MdState.done_out), info values on demand")
         env.close()
 
     # ---- second operating point (N=1, single-agent workloads): a scripted lane-following driver instead of random

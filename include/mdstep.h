@@ -339,6 +339,10 @@ typedef struct MdState {
      * caller like every other array; contents are meaningless between calls.  NULL = that mode is not available. */
     uint32_t* scratch;
     const MdParam* param0;     /* reset snapshot of `param` (multi-agent + random_agent_model only; NULL otherwise) */
+    /* optional: [n_envs * agents_per_env][2] bytes = (terminated, truncated) of the step, i.e. the MD_FL_TERMINATED /
+     * MD_FL_TRUNCATED bits of the agent's flag word as the two booleans step() returns (envs/base_env.py:586-612),
+     * so that the caller needs no kernel of its own to extract them */
+    uint8_t* done_out;
 } MdState;
 
 typedef struct MdConfig {

@@ -101,6 +101,7 @@ class MdState(C.Structure):
         ("detected", P),
         ("scratch", P),
         ("param0", P),
+        ("done_out", P),
     ]
 
 

@@ -248,6 +248,7 @@ class HostScene:
         st["reward"] = np.zeros(E * A, np.float32)
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
+        st["done_out"] = np.zeros((E * A, 2), np.uint8)          # (terminated, truncated) straight from the kernel
         st["need_reset"] = np.ones(E, np.int32)
         st["scratch"] = np.zeros(2 * N + 4 * E, np.uint32)      # work space of the phase-per-launch step kernels
         self.traffic_respawns = "spawn_off" in self.world.arrays and not cfg["is_multi_agent"]
@@ -415,6 +416,7 @@ class BatchedEngine:
         self.flags = sd["flags"].view(torch.int32).view(self.E, self.cap)
         self.action = sd["action"].view(torch.float32).view(self.E, self.cap, 2)
         self.step_info = sd["step_info"].view(torch.float32).view(self.E, self.A, 8)
+        self.done_tt = sd["done_out"].view(torch.bool).view(self.E, self.A, 2) if "done_out" in sd else None
         self.need_reset = sd["need_reset"].view(torch.int32)
         self.shape_f = sd["shape"].view(torch.float32).view(self.E, self.cap, 8)
         self.dyn_f = sd["dyn"].view(torch.float32).view(self.E, self.cap, 8)

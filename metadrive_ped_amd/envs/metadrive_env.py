@@ -140,6 +140,10 @@ class BatchedMetaDriveEnv:
         """(terminated, truncated) as two views of ONE [E, 2] bool tensor: every extra device op of an eager loop costs
         about as much as a tenth of the step itself on this GPU, so the two bits are tested in one go."""
         e = self.engine
+        if e.done_tt is not None:
+            # written by md_step itself (MdState.done_out): no device op at all.  Like obs and reward these are views of
+            # the engine's buffers: the next step() overwrites them -- .clone() what has to outlive it
+            return e.done_tt[:, 0, 0], e.done_tt[:, 0, 1]
         if getattr(self, "_tt_mask", None) is None or self._tt_mask.device != e.device:
             self._tt_mask = e.torch.tensor([abi.FL_TERMINATED, abi.FL_TRUNCATED], dtype=e.flags.dtype, device=e.device)
         tt = (e.flags[:, 0:1] & self._tt_mask) != 0

@@ -65,6 +65,9 @@ class BatchedScenarioEnv:
             raise ValueError("actions must have shape [{}, 2], got {}".format(self.num_envs, tuple(a.shape)))
         self.engine.step(a)
         fl = self.engine.flags[:, 0]
+        if self.engine.done_tt is not None:      # (terminated, truncated) written by md_step itself
+            return self.engine.obs[:, 0, :], self.engine.reward[:, 0], self.engine.done_tt[:, 0, 0], self.engine.done_tt[:, 0, 1], \
+                self._info()
         return self.engine.obs[:, 0, :], self.engine.reward[:, 0], (fl & abi.FL_TERMINATED) != 0, (fl & abi.FL_TRUNCATED) != 0, \
             self._info()
 

@@ -531,6 +531,7 @@ class ScenarioHostScene:
         st["reward"] = np.zeros(E * A, np.float32)
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
+        st["done_out"] = np.zeros((E * A, 2), np.uint8)
         st["need_reset"] = np.ones(E, np.int32)
         st["next_agent_id"] = np.zeros(E, np.int32)     # ScenarioTrafficManager.idm_policy_count
         self.state = st

@@ -29,6 +29,13 @@ def test_env_api_contract(cs_dist):
     assert int(info["episode_length"].max()) <= 40
     with pytest.raises(ValueError):
         env.step(torch.zeros(E + 1, 2))
+    # terminated / truncated come straight from the kernel (MdState.done_out): they are the two bits of the flag word
+    from metadrive_ped_amd import abi
+    for t in range(45):
+        o_, r_, tm_, tr_, inf_ = env.step(torch.from_numpy(scripted_actions(E, 1, t)[:, 0]).cuda())
+        fl_ = env.engine.flags[:, 0]
+        assert tm_.dtype == torch.bool and tr_.dtype == torch.bool
+        assert torch.equal(tm_, (fl_ & abi.FL_TERMINATED) != 0) and torch.equal(tr_, (fl_ & abi.FL_TRUNCATED) != 0)
     obs2, _ = env.reset(seed=5)                          # re-base scenarios: maps regenerate
     assert env.current_seeds[0] == 5 and env.current_seed == 5 and env.num_scenarios == E
     assert tuple(env.episode_step.shape) == (E, ) and int(env.episode_step.max()) == 0
