@@ -97,8 +97,13 @@ class BatchedMultiAgentRoundaboutEnv:
         A = self.num_agents
         fl = self.engine.flags[:, :A]
         info = self._info()
-        terminated = ((fl & abi.FL_TERMINATED) != 0) & info["active"]
-        truncated = ((fl & abi.FL_TRUNCATED) != 0) & info["active"]
+        if self.engine.done_tt is not None:
+            # written by md_step itself (MdState.done_out), zero for slots without a live agent: no device op here.
+            # Views of the engine's buffers, like obs and reward: .clone() what has to outlive the next step()
+            terminated, truncated = self.engine.done_tt[:, :A, 0], self.engine.done_tt[:, :A, 1]
+        else:
+            terminated = ((fl & abi.FL_TERMINATED) != 0) & info["active"]
+            truncated = ((fl & abi.FL_TRUNCATED) != 0) & info["active"]
         active = info["active"]
         info._lazy["terminated_all"] = lambda: (terminated | ~active).all(dim=1)
         info._lazy["truncated_all"] = lambda: (truncated | ~active).all(dim=1)

@@ -144,6 +144,10 @@ def test_marl_env_api_gpu():
         act = torch.zeros(E, 40, 2, device="cuda")
         act[..., 1] = 0.8
         obs, r, tm, tc, info = env.step(act)
+        # terminated / truncated come from the kernel (MdState.done_out): the flag bits of the slots that hold a live agent
+        fl = env.engine.flags[:, :40]
+        assert torch.equal(tm, ((fl & abi.FL_TERMINATED) != 0) & info["active"])
+        assert torch.equal(tc, ((fl & abi.FL_TRUNCATED) != 0) & info["active"])
     assert tuple(r.shape) == (E, 40) and tm.dtype == torch.bool
     assert int(info["agent_id"].max()) >= 40                            # someone respawned under a new name
     o, rr, tmd, tcd = env.to_dicts(0, obs, r, tm, tc, info)
