@@ -113,6 +113,11 @@ def main():
     print("workgroup life: mean %.1f  p50 %.1f  p99 %.1f  max %.1f us; launch span %.1f us; workgroups started after 5 us: %d of %d" % (
         life.mean(), np.median(life), np.percentile(life, 99), life.max(),
         (raw[:, 13].astype(np.int64).max() - raw[:, 12].astype(np.int64).min()) / 100.0, (t_start > 5).sum(), E))
+    for k_ in range(1, int(drv.max()) + 1):
+        m_ = drv == k_
+        if m_.sum() >= 5:
+            print("driving %2d: %5d envs  life %.1f us | locate %6.0f | observe||idm %6.0f | wait idm %6.0f | total %6.0f cycles (means)" % (
+                k_, m_.sum(), life[m_].mean(), d[m_, 5].mean(), d[m_, 7].mean(), d[m_, 9].mean(), tot[m_].mean()))
     idx = np.argsort(tot)[-3:]
     for i in idx:
         print("slow env", i, "drv", drv[i], "phases", d[i].tolist())
