@@ -298,7 +298,8 @@ MD_HD void md_scenario_observe_at(const MdWorld* w, const MdState* s, const MdCo
     else if ((fl & MD_FL_CRASH_BUILDING) && c->crash_object_done) done = 1;
     else if (max_step) {
         if (c->truncate_as_terminate) done = 1;
-    } else if (c->allowed_more_steps > 0 && nav->steps >= c->scenario_length + c->allowed_more_steps) {
+    } else if (c->allowed_more_steps > 0 &&   /* this scene's own length: track_meta[slot 0][1] (<= c->scenario_length, the batch's) */
+               nav->steps >= w->track_meta[4 * ((size_t)e * c->cap) + 1] + c->allowed_more_steps) {
         if (c->truncate_as_terminate) done = 1;
         max_step = 1;
     }

@@ -1,7 +1,7 @@
 """BatchedScenarioEnv: the reset()/step() surface of the reference's ScenarioEnv (envs/scenario_env.py) for E
-lock-stepped scenes on one MI355X.  Scene e replays scenario description e of the list handed in (the reference reads
-them from `data_directory`; here they are passed as dicts in the same format, e.g. from BatchedMetaDriveEnv.
-export_scenarios() or metadrive_ped_amd.scenario.synthetic_scenarios()).
+lock-stepped scenes on one MI355X.  Scene e replays scenario description e: read from `data_directory` (a ScenarioNet
+dataset folder, as the reference's ScenarioDataManager reads it: metadrive_ped_amd/scenario_data.py), or handed in as dicts
+of the same format (e.g. from BatchedMetaDriveEnv.export_scenarios()), or metadrive_ped_amd.scenario.synthetic_scenarios().
 
 Returns like the single-agent env: obs [E, obs_dim] (side cloud | state | 22 navigation dims | lidar), reward [E],
 terminated [E], truncated [E], info = dict of [E] tensors with ScenarioEnv's keys (route_completion, cost, crash_*,
@@ -30,6 +30,9 @@ class BatchedScenarioEnv:
     def __init__(self, config=None, scenarios=None):
         self.config = make_scenario_config(config)
         self.num_envs = self.config["num_envs"]
+        if scenarios is None and self.config["data_directory"] is not None:
+            from metadrive_ped_amd.scenario_data import load_scenarios
+            scenarios = load_scenarios(self.config)   # scene e = scenario start_scenario_index + (offset + e) % num_scenarios
         if scenarios is None:
             scenarios = synthetic_scenarios(self.num_envs, self.config["start_scenario_index"] + self.config["env_seed_offset"])
         self.scenarios = scenarios

@@ -25,6 +25,7 @@ from metadrive_ped_amd.mapgen.tables import beam_table
 
 # ScenarioEnv's own defaults (envs/scenario_env.py:21-95); keys not listed keep BaseEnv's
 SCENARIO_DEFAULT_CONFIG = dict(
+    data_directory=None,          # a ScenarioNet dataset folder (scenario_data.py); None: descriptions are handed in / synthetic
     start_scenario_index=0, num_scenarios=3, sequential_seed=False,
     no_traffic=False, no_static_vehicles=False, no_light=False, reactive_traffic=False, filter_overlapping_car=True,
     even_sample_vehicle_class=True, default_vehicle_in_traffic=False, static_traffic_object=True,
@@ -38,7 +39,7 @@ SCENARIO_DEFAULT_CONFIG = dict(
 )
 SCENARIO_VEHICLE_CONFIG = dict(lidar=dict(num_lasers=120, distance=50), lane_line_detector=dict(num_lasers=0, distance=50),
                                side_detector=dict(num_lasers=12, distance=50))
-_ONLY_SCENARIO_KEYS = ("start_scenario_index", "sequential_seed", "no_traffic", "no_static_vehicles", "no_light",
+_ONLY_SCENARIO_KEYS = ("data_directory", "start_scenario_index", "sequential_seed", "no_traffic", "no_static_vehicles", "no_light",
                        "reactive_traffic", "filter_overlapping_car", "even_sample_vehicle_class",
                        "default_vehicle_in_traffic", "on_lane_line_penalty", "crash_human_penalty",
                        "steering_range_penalty", "heading_penalty", "lateral_penalty", "max_lateral_dist",
@@ -285,6 +286,16 @@ def scene_line_quads(map_features, map_region_size):
     return quads, kinds
 
 
+def _to_frames(a, T):
+    """first T frames of a per-frame array, zero / False padded"""
+    a = np.asarray(a)
+    if len(a) >= T:
+        return a[:T]
+    out = np.zeros((T, ) + a.shape[1:], dtype=a.dtype)
+    out[:len(a)] = a
+    return out
+
+
 def _build_scene(job):
     """One scenario description -> the per-scene arrays (module-level so that a fork pool can run it)."""
     from metadrive_ped_amd.scene import vehicle_param_record
@@ -312,13 +323,16 @@ def _build_scene(job):
         pos = np.asarray(st["position"], dtype=np.float64)[:, :2]
         heading = np.asarray(st["heading"], dtype=np.float64)
         vel = np.asarray(st["velocity"], dtype=np.float64)
+        own_len = len(pos)
+        if own_len != T:   # a batch of scenes of different lengths: shorter ones end with invalid frames
+            valid, pos, heading, vel = (_to_frames(a, T) for a in (valid, pos, heading, vel))
         n = j
         run = _first_run(valid)
         if j == 0:
             # the agent: default vehicle at the SDC's first frame (scenario_map_manager.py:55-75); its route =
             # the whole track up to the first > 100 m jump (parse_full_trajectory, parse_object_state.py:77-90)
-            cut = len(pos)
-            for t in range(len(pos) - 1):
+            cut = own_len
+            for t in range(own_len - 1):
                 if math.hypot(*(pos[t] - pos[t + 1])) > 100:
                     cut = t
                     break
@@ -335,7 +349,7 @@ def _build_scene(job):
             d["heading"], d["speed"] = h, float(vel[0, 0] * math.cos(h) + vel[0, 1] * math.sin(h))
             d["last_x"], d["last_y"], d["last_c"], d["last_s"] = pos[0, 0], pos[0, 1], math.cos(h), math.sin(h)
             dyn0[n] = d
-            meta[n] = (0, len(pos), abi.TM_NEVER, 0)
+            meta[n] = (0, int(sc.get("length", own_len)), abi.TM_NEVER, 0)   # [1] = this scene's current_scenario_length
             ck = polys[0].checkpoints()
             continue
         kind = _KIND_OF_TYPE.get(tr["type"])
@@ -437,9 +451,7 @@ class ScenarioHostScene:
         E = cfg["num_envs"]
         if len(scenarios) != E:
             raise ValueError("need one scenario per env: got {} for {} envs".format(len(scenarios), E))
-        T = int(scenarios[0]["length"])
-        if any(int(sc["length"]) != T for sc in scenarios):
-            raise ValueError("all scenarios of a batch must have the same number of frames")
+        T = max(int(sc["length"]) for sc in scenarios)   # frames of the batch; a shorter scene is over (all invalid) after its own
         n_tracks = max(len(sc["tracks"]) for sc in scenarios)
         cap = cfg["mover_capacity"] or min(abi.MD_MAX_CAP, max(8, (n_tracks + 7) // 8 * 8))
         if n_tracks > cap:
@@ -626,9 +638,9 @@ def synthetic_scenario(seed, T=200, n_vehicles=18, n_parked=3, n_pedestrians=2, 
         valid = np.ones(T, bool)
         r = rng.rand()
         if r < 0.15:
-            valid[:int(rng.randint(5, 60))] = False          # appears later
+            valid[:int(rng.randint(5, 60 if T > 85 else max(6, T // 3)))] = False          # appears later
         elif r < 0.3:
-            valid[int(rng.randint(80, T - 5)):] = False       # vanishes
+            valid[int(rng.randint(80 if T > 85 else T // 2, T - 5)):] = False       # vanishes
         length = float(rng.choice([3.9, 4.6, 5.2, 6.0]))
         tracks[str(oid)] = _track_dict(oid, "VEHICLE", T, valid, x, y, h, np.full(T, v), length, 1.9, 1.6)
         oid += 1
