@@ -59,6 +59,10 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.agent_action = g->agent_action ? g->agent_action + (size_t)e * c->agents_per_env * 2 : 0;
     v.track_shape = g->track_shape ? g->track_shape + b : 0;   /* + t * n_envs * cap per frame */
     v.track_dyn = g->track_dyn ? g->track_dyn + 2 * b : 0;
+    v.route_n = g->route_n ? g->route_n + 4 * b : 0;
+    v.route_segs = g->route_segs ? g->route_segs + b * (size_t)c->route_seg_cap : 0;
+    v.route_verts = g->route_verts ? g->route_verts + 2 * b * (size_t)c->route_vert_cap : 0;
+    v.route_aux = g->route_aux ? g->route_aux + 8 * b : 0;
     return v;
 }
 

@@ -343,6 +343,219 @@ MD_HD void md_scenario_observe(const MdWorld* w, const MdState* s, const MdConfi
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The route a reactive vehicle follows: the slot's static polyline (its track's first valid run, host-built), or -- after a
+ * spawn at any other frame -- the route md_build_route cut at the spawn frame (MdState.route_*; `s` is the env view).
+ * -----------------------------------------------------------------------------------------*/
+typedef struct MdRoute {
+    MdPoly poly;          /* poly.length is NOT filled (md_route_length) */
+    const float* verts;   /* outline polygon */
+    int n_verts;
+    const float* aux;     /* [8] end point, outline bounding box; NULL = derive */
+} MdRoute;
+
+MD_HD int md_route_is_dynamic(const MdState* s, int slot) { return s->route_n && s->route_n[4 * slot] > 0; }
+
+MD_HD MdRoute md_route_of(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot) {
+    MdRoute r;
+    if (md_route_is_dynamic(s, slot)) {
+        r.poly.segs = s->route_segs + (size_t)slot * c->route_seg_cap;
+        r.poly.n = s->route_n[4 * slot];
+        r.verts = s->route_verts + 2 * (size_t)slot * c->route_vert_cap;
+        r.n_verts = s->route_n[4 * slot + 1];
+        r.aux = s->route_aux + 8 * (size_t)slot;
+    } else {
+        const size_t ng = (size_t)e * c->cap + slot;
+        const int a = w->poly_off[ng], b = w->poly_off[ng + 1];
+        r.poly.segs = w->segs + a;
+        r.poly.n = b - a;
+        r.verts = w->polyv + 2 * (size_t)w->polyv_off[ng];
+        r.n_verts = w->polyv_off[ng + 1] - w->polyv_off[ng];
+        r.aux = w->poly_aux ? w->poly_aux + 8 * ng : 0;
+    }
+    r.poly.length = 0.0f;
+    return r;
+}
+
+MD_HD float md_route_length(const MdPoly* p) { return (p->n > 0) ? p->segs[p->n - 1].cum + p->segs[p->n - 1].len : 0.0f; }
+
+/* the valid run [t0, t1) of the track in slot n_global that contains frame k (get_max_valid_indicis gives [k, t1)); 0 if none */
+MD_HD int md_track_run_end(const MdWorld* w, size_t n_global, int k) {
+    if (!w->run_off || !w->runs) return 0;
+    for (int r = w->run_off[n_global]; r < w->run_off[n_global + 1]; ++r)
+        if (w->runs[2 * r] <= k && k < w->runs[2 * r + 1]) return w->runs[2 * r + 1];
+    return 0;
+}
+
+/* PointLane(points, width 2) for a route cut at a spawn frame (get_idm_route): InterpolatingLine._get_properties
+ * (utils/interpolating_line.py:104-146: from a kept point, the next kept one is the first farther than 1 m, else the last point;
+ * pieces shorter than 1e-6 are dropped; a path that never moves is one 0.1 m piece along +x), PointLane.auto_generate_polygon
+ * (component/lane/point_lane.py:58-106: the strip sampled every metre, one metre beyond both ends), and the aux record
+ * (MdWorld.poly_aux).  Geometry in double like the host's numpy (+, -, *, /, sqrt are correctly rounded on both the CPU and the GPU:
+ * the oracle and the kernel agree bit for bit), stored as float; the heading is md_atan2 of the stored direction.
+ * Points: x = xy[i * stride], y = xy[i * stride + 1], i < n_pts.
+ * The element functions below are what both forms are made of: md_build_route walks them serially (oracle); the kernel runs the
+ * chain with lanes = candidate points, the pieces with lanes = pieces, the running length on one lane (a sum in a fixed order)
+ * and the outline with lanes = vertices. */
+
+/* from kept point i: the first point farther than 1 m (squared distance > 1), else the last point */
+MD_HD int md_route_far(const float* xy, size_t stride, int i, int q) {
+    const double ux = (double)xy[(size_t)i * stride] - (double)xy[(size_t)q * stride];
+    const double uy = (double)xy[(size_t)i * stride + 1] - (double)xy[(size_t)q * stride + 1];
+    return ux * ux + uy * uy > 1.0;
+}
+
+/* the piece from point i to point j, everything but `cum`; returns its length in double, negative when the piece is dropped */
+MD_HD double md_route_piece(const float* xy, size_t stride, int i, int j, MdSeg* g) {
+    const double xi = xy[(size_t)i * stride], yi = xy[(size_t)i * stride + 1];
+    const double ex = xy[(size_t)j * stride], ey = xy[(size_t)j * stride + 1];
+    const double ddx = ex - xi, ddy = ey - yi;
+    const double L = __builtin_sqrt(ddx * ddx + ddy * ddy);
+    if (L < 1e-6) return -1.0;
+    g->sx = (float)xi;
+    g->sy = (float)yi;
+    g->ex = (float)ex;
+    g->ey = (float)ey;
+    g->dx = (float)(ddx / L);
+    g->dy = (float)(ddy / L);
+    g->len = (float)L;
+    g->heading = md_atan2(g->dy, g->dx);
+    g->cum = 0.0f;
+    g->spare[0] = g->spare[1] = g->spare[2] = 0.0f;
+    return L;
+}
+
+/* a path that never moved: one 0.1 m piece along +x (its lateral direction is hard-wired to (0, 1), interpolating_line.py:137-144) */
+MD_HD void md_route_still_piece(const float* xy, MdSeg* g) {
+    g->sx = xy[0];
+    g->sy = xy[1];
+    g->ex = (float)((double)xy[0] + 0.1);
+    g->ey = xy[1];
+    g->dx = 1.0f;
+    g->dy = 0.0f;
+    g->len = 0.1f;
+    g->heading = 0.0f;
+    g->cum = 0.0f;
+    g->spare[0] = g->spare[1] = g->spare[2] = 0.0f;
+}
+
+/* number of outline samples: len(arange(0, length + 1, 1)) = ceil(length + 1) */
+MD_HD int md_route_n_long(double length) {
+    int n_long = (int)length + 1;
+    if ((double)(n_long - 1) < length) n_long += 1;
+    if ((double)(n_long - 1) >= length + 1.0) n_long -= 1;
+    return n_long;
+}
+
+/* Vertex o of the outline, 0 <= o < 2 * (n_long + 2): the right side (lateral -1) with the samples ascending, then the left side
+ * descending; the first and the last sample of a side are flanked by a point one metre further along the end piece's direction.  A
+ * sample's piece = the first whose accumulated end + 0.1 reaches it, else the last (InterpolatingLine.get_point), found by
+ * bisection (the ends ascend); the geometry is recomputed in double from the stored floats -- the host keeps doubles, the
+ * difference is below the float resolution of the result. */
+MD_HD void md_route_outline_vertex(const MdSeg* segs, int ns, int never_moved, int n_long, int o, float* fx, float* fy) {
+    const int per_side = n_long + 2;
+    const int side = o >= per_side ? 1 : 0;
+    const int r = o - side * per_side;
+    int t = r - 1;
+    if (t < 0) t = 0;
+    if (t > n_long - 1) t = n_long - 1;
+    const int li = side == 0 ? t : n_long - 1 - t;
+    const double sv = (double)li, lat = side == 0 ? -1.0 : 1.0;
+    int lo = 0, hi = ns - 1;   /* first piece with end + 0.1 >= sv, else the last */
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((double)segs[mid].cum + (double)segs[mid].len + 0.1 >= sv) hi = mid;
+        else lo = mid + 1;
+    }
+    const MdSeg* g = &segs[lo];
+    const double along = sv - (double)g->cum;
+    const double lx = never_moved ? 0.0 : (double)g->dy, ly = never_moved ? 1.0 : -(double)g->dx;
+    double x = (double)g->sx + along * (double)g->dx + lat * lx;
+    double y = (double)g->sy + along * (double)g->dy + lat * ly;
+    /* the flanking points: before the route's start (-d0) at sample 0, beyond its end (+d1) at the last sample */
+    const int extra = (r == 0) || (r == per_side - 1);
+    if (extra) {
+        if (li == 0) {
+            x -= (double)segs[0].dx;
+            y -= (double)segs[0].dy;
+        } else {
+            x += (double)segs[ns - 1].dx;
+            y += (double)segs[ns - 1].dy;
+        }
+    }
+    *fx = (float)x;
+    *fy = (float)y;
+}
+
+/* aux[0..1]: PointLane.end = position(length, 0) in the float arithmetic of md_poly_position */
+MD_HD void md_route_end_point(const MdSeg* segs, int ns, float* aux) {
+    const float flen = segs[ns - 1].cum + segs[ns - 1].len;
+    int ie = ns - 1;
+    for (int q = 0; q < ns; ++q)
+        if (segs[q].cum + segs[q].len + 0.1f >= flen) {
+            ie = q;
+            break;
+        }
+    aux[0] = segs[ie].sx + (flen - segs[ie].cum) * segs[ie].dx;
+    aux[1] = segs[ie].sy + (flen - segs[ie].cum) * segs[ie].dy;
+}
+
+/* serial form.  counts[0] = pieces, counts[1] = vertices; returns 0, or -1 when the buffers are too small (counts[0] = 0). */
+MD_HD int md_build_route(const float* xy, size_t stride, int n_pts, MdSeg* segs, int seg_cap, float* verts, int vert_cap,
+                         float* aux, int32_t* counts) {
+    int ns = 0;
+    double cum = 0.0;
+    int i = 0;
+    counts[0] = 0;
+    counts[1] = 0;
+    while (i < n_pts - 1) {
+        int j = n_pts - 1;
+        for (int q = i + 1; q < n_pts; ++q)
+            if (md_route_far(xy, stride, i, q)) {
+                j = q;
+                break;
+            }
+        if (ns >= seg_cap) return -1;
+        const double L = md_route_piece(xy, stride, i, j, &segs[ns]);
+        if (!(L < 0.0)) {
+            segs[ns].cum = (float)cum;
+            cum += L;
+            ++ns;
+        }
+        i = j;
+    }
+    int never_moved = 0;
+    if (ns == 0) {
+        if (seg_cap < 1 || n_pts < 1) return -1;
+        never_moved = 1;
+        md_route_still_piece(xy, &segs[ns++]);
+        cum = 0.1;
+    }
+    const int n_long = md_route_n_long(cum);
+    const int nv = 2 * (n_long + 2);
+    if (nv > vert_cap) return -1;
+    float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;
+    for (int o = 0; o < nv; ++o) {
+        float fx, fy;
+        md_route_outline_vertex(segs, ns, never_moved, n_long, o, &fx, &fy);
+        verts[2 * o] = fx;
+        verts[2 * o + 1] = fy;
+        bx0 = md_min(bx0, fx);
+        by0 = md_min(by0, fy);
+        bx1 = md_max(bx1, fx);
+        by1 = md_max(by1, fy);
+    }
+    md_route_end_point(segs, ns, aux);
+    aux[2] = bx0;
+    aux[3] = by0;
+    aux[4] = bx1;
+    aux[5] = by1;
+    aux[6] = aux[7] = 0.0f;
+    counts[0] = ns;
+    counts[1] = nv;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * TrajectoryIDMPolicy (policy/idm_policy.py:426-493) for the vehicle in `slot`, decided BEFORE the integration of
  * episode step k (ScenarioTrafficManager.before_step, scenario_traffic_manager.py:67-76).
  * Slot state: MdNav.ck0 = MD_SC_IDM, MdNav.timer = policy_index; MdPid: hp / hi / hd = heading PID (1.2, 0.1, 3.5),
@@ -399,8 +612,9 @@ MD_HD void md_tidm_decide(const MdPoly* route, const MdState* s, int slot, int d
 MD_HD void md_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int slot, int k) {
     MdNav* nav = &s->nav[slot];
     const MdShape* sh = &s->shape[slot];
-    const size_t ng = (size_t)e * c->cap + slot;
-    const MdPoly route = md_poly_of(w, ng);
+    const MdRoute rt = md_route_of(w, s, c, e, slot);
+    MdPoly route = rt.poly;
+    route.length = md_route_length(&route);
     float end_x, end_y;
     md_poly_position(&route, route.length, 0.0f, &end_x, &end_y);   /* PointLane.end = position(length, 0) */
     if (md_norm(sh->cx - end_x, sh->cy - end_y) < MD_TIDM_DEST_RADIUS) {
@@ -413,8 +627,8 @@ MD_HD void md_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c
     float cur_long, tmp;
     md_poly_local(&route, sh->cx, sh->cy, &cur_long, &tmp);
     if (do_speed_control) {
-        const float* pv = w->polyv + 2 * (size_t)w->polyv_off[ng];
-        const int n_v = w->polyv_off[ng + 1] - w->polyv_off[ng];
+        const float* pv = rt.verts;
+        const int n_v = rt.n_verts;
         for (int j = 0; j < c->cap; ++j) {
             if (j == slot) continue;
             float g = md_tidm_front_gap(&route, pv, n_v, cur_long, sh->cx, sh->cy, &s->shape[j]);
@@ -437,8 +651,8 @@ MD_HD void md_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c
  *   ABSENT   spawned when frame k is valid and the filters pass: replay, or -- reactive_traffic, a moving track
  *            starting behind the ego within 15 m sideways and heading its way, longer than 5 m -- TrajectoryIDMPolicy
  *            at rest on its own path with policy_index = idm_policy_count % 5 (counter: MdState.next_agent_id[0]).
- * Deviation: the IDM route is the track's first valid run; a track that is (re)spawned later in that run is
- * replayed instead of getting a route cut at the spawn frame.
+ * The IDM route of a track spawned at the start of its first valid run is host-built (MdWorld.segs); spawned at any other
+ * frame it is cut at that frame and built here (md_build_route) -- without MdWorld.runs / MdState.route_* such a spawn is replayed.
  * The decision for one slot given the running IDM count; returns 1 when an IDM policy was created.
  * -----------------------------------------------------------------------------------------*/
 MD_HD int md_scenario_slot_after_step(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int j, int k, int idm_count,
@@ -479,7 +693,7 @@ MD_HD int md_scenario_slot_after_step(const MdWorld* w, const MdState* s, const 
     }
     if (nav->ck0 != MD_SC_ABSENT) return 0;   /* IDM: drives */
     if (!valid || (tm[2] & MD_TM_NEVER)) return 0;
-    int idm = 0;
+    int idm = 0, late_pts = 0;
     if (kind == MD_KIND_VEHICLE) {
         const int moving = (tm[2] & MD_TM_MOVING) != 0;
         if (c->no_static_vehicles && !moving) return 0;
@@ -491,9 +705,32 @@ MD_HD int md_scenario_slot_after_step(const MdWorld* w, const MdState* s, const 
         const float fr_heading = s->track_dyn[2 * at];
         const int heading_ok = md_fabs(md_wrap_to_pi(s->dyn[0].heading - fr_heading)) < MD_HALF_PI_F;
         const int idm_ok = heading_dist < -1.0f && md_fabs(side_dist) < 15.0f && heading_ok;
-        idm = c->reactive_traffic && moving && idm_ok && (tm[2] & MD_TM_LENGTH_OK) && k == tm[0];
+        idm = c->reactive_traffic && moving && idm_ok;
+        if (idm) {
+            if (k == tm[0]) {
+                idm = (tm[2] & MD_TM_LENGTH_OK) != 0;    /* the first run from its start: the host-built route */
+            } else {
+                /* any other frame (a later run, a spawn the overlap filter held back, a respawn after an arrival): the route is
+                 * cut at this frame -- get_max_valid_indicis(track, k), IDM_CREATE_MIN_LENGTH on ITS two ends */
+                idm = 0;
+                if (s->route_n && c->route_seg_cap > 0) {
+                    const int t1 = md_track_run_end(w, ng, k);
+                    if (t1 > k) {
+                        const MdShape last = s->track_shape[(size_t)(t1 - 1) * (size_t)c->n_envs * (size_t)c->cap + (size_t)j];
+                        idm = md_norm(fr.cx - last.cx, fr.cy - last.cy) > 5.0f;
+                        late_pts = t1 - k;
+                    }
+                }
+            }
+        }
     }
     if (dry) return idm;
+    if (s->route_n) {
+        s->route_n[4 * j] = 0;
+        s->route_n[4 * j + 1] = 0;
+        s->route_n[4 * j + 2] = k;
+        s->route_n[4 * j + 3] = (idm && late_pts > 0) ? late_pts : 0;   /* > 0: md_scenario_build_pending has a route to build */
+    }
     *sh = fr;
     d->heading = s->track_dyn[2 * at];
     d->last_x = fr.cx;
@@ -521,10 +758,33 @@ MD_HD int md_scenario_slot_after_step(const MdWorld* w, const MdState* s, const 
     return 0;
 }
 
+/* The route of a slot that md_scenario_slot_after_step just gave a reactive policy at a frame other than its first run's start
+ * (route_n[4j+3] = number of frames left in the run): PointLane(positions[k : k + that]) into the slot's route buffers.  `xy` /
+ * `stride`: the positions (NULL = the frames in MdState.track_shape; the kernel hands in a staged copy).  When the buffers are too
+ * small the slot keeps following its static polyline (route_n[4j] stays 0). */
+MD_HD void md_scenario_build_pending(const MdState* s, const MdConfig* c, int j, const float* xy, size_t stride) {
+    if (!s->route_n || s->route_n[4 * j + 3] <= 0) return;
+    const int k = s->route_n[4 * j + 2];
+    const int n_pts = s->route_n[4 * j + 3] < c->route_seg_cap ? s->route_n[4 * j + 3] : c->route_seg_cap;   /* (the host sizes the cap
+                                                                                        by the longest run: never cut) */
+    if (!xy) {
+        xy = &s->track_shape[(size_t)k * (size_t)c->n_envs * (size_t)c->cap + (size_t)j].cx;
+        stride = (size_t)c->n_envs * (size_t)c->cap * (sizeof(MdShape) / sizeof(float));
+    }
+    int32_t counts[2];
+    md_build_route(xy, stride, n_pts, s->route_segs + (size_t)j * c->route_seg_cap, c->route_seg_cap,
+                   s->route_verts + 2 * (size_t)j * c->route_vert_cap, c->route_vert_cap, s->route_aux + 8 * (size_t)j, counts);
+    s->route_n[4 * j] = counts[0];
+    s->route_n[4 * j + 1] = counts[1];
+    s->route_n[4 * j + 3] = 0;
+}
+
 /* serial form (oracle) */
 MD_HD void md_scenario_after_step_env(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int k) {
-    for (int j = c->agents_per_env; j < c->cap; ++j)
+    for (int j = c->agents_per_env; j < c->cap; ++j) {
         s->next_agent_id[0] += md_scenario_slot_after_step(w, s, c, e, j, k, s->next_agent_id[0], 0);
+        md_scenario_build_pending(s, c, j, 0, 0);
+    }
 }
 
 #endif /* MD_SCENARIO_H */

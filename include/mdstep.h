@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 8
+#define MD_ABI_VERSION 9
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -284,6 +284,12 @@ typedef struct MdWorld {
      * and its MD_Q_* kind (the integer's bit pattern in the float) -- the detectors cull on these 16 bytes and read the
      * 32-byte quad only for the few (quad, beam) pairs that can meet.  NULL = they derive the circle from the quad. */
     const float* quad_ball;
+    /* scenario mode, optional: ALL valid runs of every track -- run_off [n_envs * cap + 1] CSR into runs [n_runs][2] = [t0, t1)
+     * (get_max_valid_indicis at any frame of the run, scenario/parse_object_state.py:8-16).  track_meta holds the first run only;
+     * with these tables (and MdState.route_*) a vehicle spawned at a frame other than its first run's start gets its reactive
+     * policy on a route cut at the spawn frame, as scenario_traffic_manager.py:216-236 does; NULL = such spawns are replayed. */
+    const int32_t* run_off;
+    const int32_t* runs;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */
@@ -343,6 +349,18 @@ typedef struct MdState {
      * MD_FL_TRUNCATED bits of the agent's flag word as the two booleans step() returns (envs/base_env.py:586-612),
      * so that the caller needs no kernel of its own to extract them */
     uint8_t* done_out;
+    /* scenario mode, optional (all four or none; needs MdWorld.run_off / runs and MdConfig.route_seg_cap / route_vert_cap):
+     * routes built on the device when a track is (re)spawned with a reactive policy at a frame k that is not the start of its
+     * first valid run -- PointLane(positions[k:end of the run]) (get_idm_route, scenario/parse_object_state.py:19-21), built by
+     * md_step right after the spawn:
+     *   route_n     [n_envs * cap][4]  pieces (0 = the slot follows its static polyline MdWorld.segs), outline vertices, k, 0
+     *   route_segs  [n_envs * cap][route_seg_cap]      the pieces
+     *   route_verts [n_envs * cap][route_vert_cap][2]  the outline at width 2
+     *   route_aux   [n_envs * cap][8]                  as MdWorld.poly_aux */
+    int32_t* route_n;
+    MdSeg* route_segs;
+    float* route_verts;
+    float* route_aux;
 } MdState;
 
 typedef struct MdConfig {
@@ -411,6 +429,8 @@ typedef struct MdConfig {
     int32_t n_parking;         /* parking lot env: number of parking spaces (destinations 0..n_parking-1 of the spawn tables) */
     float side_range, ll_range;     /* detector ranges in m (vehicle_config.side_detector / lane_line_detector "distance") */
     uint32_t side_mask, ll_mask;    /* which MD_Q_* kinds each detector sees (bit k = kind k), as md_line_detector's kind_mask */
+    int32_t route_seg_cap;     /* pieces per slot in MdState.route_segs (>= the longest valid run's frames - 1)          */
+    int32_t route_vert_cap;    /* vertices per slot in MdState.route_verts (>= 2 * ceil(longest run's path length + 1) + 4) */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

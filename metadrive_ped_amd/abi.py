@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 8
+MD_ABI_VERSION = 9
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -84,7 +84,7 @@ class MdWorld(C.Structure):
         ("max_lanes", C.c_int32), ("max_roads", C.c_int32),
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
         ("n_dest", C.c_int32), ("n_vclass", C.c_int32),
-        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P), ("side_beam_cs", P), ("ll_beam_cs", P), ("quad_ball", P),
+        ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P), ("side_beam_cs", P), ("ll_beam_cs", P), ("quad_ball", P), ("run_off", P), ("runs", P),
     ]
 
 
@@ -102,6 +102,7 @@ class MdState(C.Structure):
         ("scratch", P),
         ("param0", P),
         ("done_out", P),
+        ("route_n", P), ("route_segs", P), ("route_verts", P), ("route_aux", P),
     ]
 
 
@@ -136,6 +137,7 @@ class MdConfig(C.Structure):
         ("step_kernel", C.c_int32),
         ("ma_kind", C.c_int32), ("min_pass_steps", C.c_int32), ("overspeed_penalty", C.c_float), ("n_parking", C.c_int32),
         ("side_range", C.c_float), ("ll_range", C.c_float), ("side_mask", C.c_uint32), ("ll_mask", C.c_uint32),
+        ("route_seg_cap", C.c_int32), ("route_vert_cap", C.c_int32),
     ]
 
 

@@ -2070,24 +2070,20 @@ __device__ __forceinline__ int points_in_polygon_wave4(const float* xy, int n, c
 // one pass over the outline's edges, and only those inside its bounding box.
 __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
                                   int lane_id) {
-    const size_t ng = (size_t)e * c.cap + slot;
 #ifdef MD_STAMP
     bool st_ = lane_id == 0;   // diagnostic: the scene's first reactive vehicle, apart for its speed-control steps (slots 16.. / 24..)
     for (int q = c.agents_per_env; q < slot; ++q) st_ = st_ && !(s.nav[q].ck0 == MD_SC_IDM && md_present(s.shape[q].flags));
     const int so_ = ((k % MD_TIDM_BATCH) == s.nav[slot].timer) ? 8 : 0;
 #endif
     MD_FINE_STAMP(st_, so_ + 0);
-    MdPoly route;   // md_poly_of without the length: that is a dependent load of the last piece, only the fallback needs it
-    {
-        const int pa = w.poly_off[ng], pb = w.poly_off[ng + 1];
-        route.segs = w.segs + pa;
-        route.n = pb - pa;
-        route.length = 0.0f;
-    }
+    // the slot's static polyline or the route cut at its spawn frame (md_route_of); without the length: that is a dependent
+    // load of the last piece, only the fallback needs it
+    const MdRoute rt = md_route_of(&w, &s, &c, e, slot);
+    MdPoly route = rt.poly;
     const float px = s.shape[slot].cx, py = s.shape[slot].cy;
     float end_x, end_y, bx0 = -3.0e38f, by0 = -3.0e38f, bx1 = 3.0e38f, by1 = 3.0e38f;
-    if (w.poly_aux) {
-        const float* aux = w.poly_aux + 8 * ng;
+    if (rt.aux) {
+        const float* aux = rt.aux;
         end_x = aux[0];
         end_y = aux[1];
         bx0 = aux[2];
@@ -2149,8 +2145,8 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
         // corners inside the outline's bounding box against the outline (lanes = polygon edges, all corners in one pass),
         // then the projection on the route with lanes = pieces.  Ascending slot order and a strict < keep the lowest
         // slot among equal gaps.
-        const float* pv = w.polyv + 2 * (size_t)w.polyv_off[ng];
-        const int n_v = w.polyv_off[ng + 1] - w.polyv_off[ng];
+        const float* pv = rt.verts;
+        const int n_v = rt.n_verts;
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
             const int jl = j0 + lane_id;
             bool near = false;
@@ -2211,6 +2207,106 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     MD_FINE_STAMP(st_, so_ + 5);
 }
 
+// The route cut at a spawn frame, built by one wave from the positions staged in LDS (md_build_route is the serial form; the element
+// functions are the same, so the results are bit-identical): the chain of kept points with lanes = candidate points (one ballot per
+// piece), the pieces with lanes = pieces (dropped ones squeezed out by ballot prefix counts), the running length on lane 0 (a sum in
+// a fixed order), the outline with lanes = vertices.  A few per scene and episode; ~3 us instead of ~40 on one lane.
+//   l_link [seg_cap] ints, l_len [seg_cap + 1] doubles: LDS scratch.  rn = the slot's route_n[4].
+__device__ __forceinline__ void build_route_wave(int32_t* rn, MdSeg* segs, int seg_cap, float* verts, int vert_cap, float* aux,
+                                 const float* l_pts, int n_pts, int* l_link, double* l_len, int lane) {
+    int nl = 0, i = 0;
+    while (i < n_pts - 1 && nl < seg_cap) {
+        int j = n_pts - 1;
+        for (int q0 = i + 1; q0 < n_pts; q0 += 64) {
+            const int q = q0 + lane;
+            const unsigned long long m = __ballot(q < n_pts && md_route_far(l_pts, 2, i, q));
+            if (m) {
+                j = q0 + __ffsll((long long)m) - 1;
+                break;
+            }
+        }
+        if (lane == 0) l_link[nl] = i | (j << 16);
+        ++nl;
+        i = j;
+    }
+    wave_sync();
+    int ns = 0;
+    for (int p0 = 0; p0 < nl; p0 += 64) {
+        const int p = p0 + lane;
+        MdSeg g;
+        double L = -1.0;
+        if (p < nl) {
+            const int lk = l_link[p];
+            L = md_route_piece(l_pts, 2, lk & 0xffff, lk >> 16, &g);
+        }
+        const bool keep = !(L < 0.0);
+        const unsigned long long m = __ballot(keep);
+        const int at = ns + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            segs[at] = g;
+            l_len[at] = L;
+        }
+        ns += __popcll(m);
+    }
+    __threadfence_block();
+    wave_sync();
+    const int never_moved = ns == 0;
+    if (lane == 0) {
+        if (never_moved) {
+            md_route_still_piece(l_pts, &segs[0]);
+            l_len[seg_cap] = 0.1;
+        } else {
+            double cum = 0.0;
+            for (int p = 0; p < ns; ++p) {
+                segs[p].cum = (float)cum;
+                cum += l_len[p];
+            }
+            l_len[seg_cap] = cum;
+        }
+    }
+    if (never_moved) ns = 1;
+    __threadfence_block();
+    wave_sync();
+    const int n_long = md_route_n_long(l_len[seg_cap]);
+    const int nv = 2 * (n_long + 2);
+    if (nv > vert_cap) {   // (the host sizes the buffers by the longest run: never) the slot keeps its static polyline
+        if (lane == 0) rn[0] = rn[1] = rn[3] = 0;
+        return;
+    }
+    float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;
+    for (int o0 = 0; o0 < nv; o0 += 64) {
+        const int o = o0 + lane;
+        if (o < nv) {
+            float fx, fy;
+            md_route_outline_vertex(segs, ns, never_moved, n_long, o, &fx, &fy);
+            verts[2 * o] = fx;
+            verts[2 * o + 1] = fy;
+            bx0 = md_min(bx0, fx);
+            by0 = md_min(by0, fy);
+            bx1 = md_max(bx1, fx);
+            by1 = md_max(by1, fy);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        bx0 = md_min(bx0, __shfl_xor(bx0, off, 64));
+        by0 = md_min(by0, __shfl_xor(by0, off, 64));
+        bx1 = md_max(bx1, __shfl_xor(bx1, off, 64));
+        by1 = md_max(by1, __shfl_xor(by1, off, 64));
+    }
+    if (lane == 0) {
+        md_route_end_point(segs, ns, aux);
+        aux[2] = bx0;
+        aux[3] = by0;
+        aux[4] = bx1;
+        aux[5] = by1;
+        aux[6] = aux[7] = 0.0f;
+        rn[0] = ns;
+        rn[1] = nv;
+        rn[3] = 0;
+    }
+}
+
 // Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
 // are then resident at once, one round instead of two (measured 148 vs 173 us at the compiler's own choice)
 #ifndef MD_SC_WAVES_EU
@@ -2241,6 +2337,13 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     int* l_dbest = l_count + 4;   // [A][n_side + n_lane_line] detector fractions (bit patterns), when md_step runs the detectors
     const bool fused_det = (w.side_beam_cs != nullptr && c.n_side > 0) || (w.ll_beam_cs != nullptr && c.n_lane_line > 0);
     const int n_det = (w.side_beam_cs ? c.n_side : 0) + (w.ll_beam_cs ? c.n_lane_line : 0);
+    // [route_seg_cap][2]: the positions a route cut at a spawn frame is built from (behind the detectors' share, as md_step sizes it)
+    // and the builder's scratch: [seg_cap + 1] doubles, [seg_cap] ints
+    double* l_len = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(l_count + 4 + (A + 2) * (c.n_side + c.n_lane_line) +
+                                                                          ((c.n_side + c.n_lane_line) > 0 ? 2 * kDetPairs : 0)) + 7) & ~(uintptr_t)7);
+    float* l_pts = reinterpret_cast<float*>(l_len + c.route_seg_cap + 1);
+    int* l_link = reinterpret_cast<int*>(l_pts + 2 * c.route_seg_cap);
+    int32_t* l_rn = l_link + c.route_seg_cap;   // [cap][4]: route_n of the scene (the decisions read it first: not a global round trip)
 
     MD_STAMP_AT(0);
     const MdState gv = md_env_view(&g, &c, e);
@@ -2265,7 +2368,10 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         }
     }
     if (tid == 0) *l_count = do_reset ? 0 : gv.next_agent_id[0];   // idm_policy_count
+    if (gv.route_n)
+        for (int j = tid; j < 4 * cap; j += kBlock) l_rn[j] = do_reset ? 0 : gv.route_n[j];   // a reset leaves no cut routes
     MdState s = gv;
+    if (gv.route_n) s.route_n = l_rn;
     s.shape = l_shape;
     s.dyn = l_dyn;
     s.nav = l_nav;
@@ -2335,6 +2441,25 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) *l_count += __popcll(m);
             wave_sync();
+            // a reactive policy created at a frame other than its first run's start: its route is cut at this frame.  Rare
+            // (a few per scene and episode): the wave stages the run's remaining positions, lane 0 builds (md_build_route).
+            unsigned long long mb = __ballot(in && s.route_n != nullptr && s.route_n[4 * (in ? j : 0) + 3] > 0);
+            while (mb) {
+                const int jb = j0 + __ffsll((long long)mb) - 1;
+                mb &= mb - 1;
+                const int kb = s.route_n[4 * jb + 2];
+                const int nb = min(s.route_n[4 * jb + 3], c.route_seg_cap);
+                for (int i = lane; i < nb; i += 64) {
+                    const MdShape fr = s.track_shape[(size_t)(kb + i) * (size_t)c.n_envs * (size_t)cap + (size_t)jb];
+                    l_pts[2 * i] = fr.cx;
+                    l_pts[2 * i + 1] = fr.cy;
+                }
+                wave_sync();
+                build_route_wave(s.route_n + 4 * jb, s.route_segs + (size_t)jb * c.route_seg_cap, c.route_seg_cap,
+                                 s.route_verts + 2 * (size_t)jb * c.route_vert_cap, c.route_vert_cap, s.route_aux + 8 * (size_t)jb, l_pts, nb,
+                                 l_link, l_len, lane);
+                wave_sync();
+            }
         }
     }
     __syncthreads();
@@ -2418,6 +2543,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         gv.action[2 * j + 1] = l_action[2 * j + 1];
         gv.flags[j] = l_flags[j];
     }
+    if (gv.route_n)
+        for (int j = tid; j < 4 * cap; j += kBlock) gv.route_n[j] = l_rn[j];
     if (tid == 0) {
         gv.next_agent_id[0] = *l_count;
         if (do_reset) gv.need_reset[0] = 0;
@@ -3245,7 +3372,16 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
         const size_t lds = (size_t)c->cap * (4 * 32 + 64 + 8 + 4) + (size_t)((c->cap + 3) & ~3) * 4 +
                            (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
                            (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int) +
-                           ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0);
+                           ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0) +
+                           (s->route_n ? (size_t)c->route_seg_cap * 20 + 16 + (size_t)c->cap * 16 : 0);   // route_n; positions, links, lengths of a route being built
+        if (s->route_n) {
+            NEED(s->route_segs); NEED(s->route_verts); NEED(s->route_aux); NEED(w->run_off); NEED(w->runs);
+            if (c->route_seg_cap < 1 || c->route_vert_cap < 8) {
+                snprintf(g_err, sizeof g_err, "scenario mode: route buffers need route_seg_cap >= 1 and route_vert_cap >= 8 (got %d, %d)",
+                         c->route_seg_cap, c->route_vert_cap);
+                return MD_EINVAL;
+            }
+        }
         if (lds > 64 * 1024) {
             snprintf(g_err, sizeof g_err, "scenario mode: LDS image needs %zu B (cap=%d)", lds, c->cap);
             return MD_EINVAL;

@@ -211,6 +211,14 @@ def _first_run(valid):
     return t0, t1
 
 
+def _all_runs(valid):
+    """every maximal run of valid frames [t0, t1): what get_max_valid_indicis (scenario/parse_object_state.py:8-16) returns the
+    end of for any frame inside it"""
+    v = np.concatenate([[False], np.asarray(valid, bool), [False]])
+    d = np.diff(v.astype(np.int8))
+    return list(zip(np.nonzero(d == 1)[0].tolist(), np.nonzero(d == -1)[0].tolist()))
+
+
 _KIND_OF_TYPE = {"VEHICLE": abi.KIND_VEHICLE, "PEDESTRIAN": abi.KIND_PEDESTRIAN, "CYCLIST": abi.KIND_CYCLIST,
                  "TRAFFIC_CONE": abi.KIND_CONE, "TRAFFIC_BARRIER": abi.KIND_BARRIER}
 
@@ -311,6 +319,8 @@ def _build_scene(job):
     fdyn = np.zeros((T, cap, 2), np.float32)
     meta = np.zeros((cap, 4), np.int32)
     meta[:, 2] = abi.TM_NEVER
+    runs = [[] for _ in range(cap)]      # vehicles: all valid runs (a route cut at a later spawn frame ends with its run)
+    cut_frames, cut_metres = 1, 1.0      # bounds of such a route: frames of the longest run, its path length
     sdc_id = str(sc["metadata"]["sdc_id"])
     order = [sdc_id] + [str(k) for k in sc["tracks"] if str(k) != sdc_id]
     counters = [0, 0, 0]
@@ -369,6 +379,12 @@ def _build_scene(job):
             param[n] = prm
             hl, hw = length / 2, width / 2
             polys[j] = PolyLine(pos[t0:t1])
+            runs[j] = _all_runs(valid)
+            for a_, b_ in runs[j]:
+                cut_frames = max(cut_frames, b_ - a_)
+                if b_ - a_ > 1:
+                    step = np.diff(pos[a_:b_], axis=0)
+                    cut_metres = max(cut_metres, float(np.sqrt((step ** 2).sum(1)).sum()))
         elif kind == abi.KIND_PEDESTRIAN:
             hl = hw = 0.35
         elif kind == abi.KIND_CYCLIST:
@@ -404,7 +420,7 @@ def _build_scene(job):
     from metadrive_ped_amd.mapgen.tables import StaticTables
     static = StaticTables(*scene_line_quads(sc.get("map_features"), region))      # road-line bodies + their grid
     return dict(shape0=shape0, dyn0=dyn0, param=param, fshape=fshape, fdyn=fdyn, meta=meta, order=order, segs=segs, verts=verts, ckpt=ck,
-                static=static)
+                static=static, runs=runs, cut_frames=cut_frames, cut_metres=cut_metres)
 
 
 
@@ -528,6 +544,17 @@ class ScenarioHostScene:
         a["ckpt_off"] = np.asarray(ckpt_off, np.int32)
         a["ckpt_xy"] = np.ascontiguousarray(np.concatenate(ckpts), dtype=np.float32)
         a["track_meta"] = meta
+        run_off, run_list = [0], []
+        for b_ in built:
+            for r in b_["runs"]:
+                run_list.extend(r)
+                run_off.append(run_off[-1] + len(r))
+        a["run_off"] = np.asarray(run_off, np.int32)
+        a["runs"] = np.asarray(run_list if run_list else [(0, 0)], np.int32).reshape(-1, 2)
+        # buffers for routes cut at a later spawn frame (MdState.route_*): at most one piece per frame of the longest run, the
+        # outline two vertices per metre of its path + the end caps
+        self.route_seg_cap = int(max(b_["cut_frames"] for b_ in built))
+        self.route_vert_cap = 2 * (int(math.ceil(max(b_["cut_metres"] for b_ in built))) + 3) + 4
         a["poly_aux"] = _poly_aux(a["poly_off"], a["segs"], a["polyv_off"], a["polyv"])
         st = {}
         st["shape0"], st["dyn0"], st["nav0"], st["pid0"], st["param"] = shape0, dyn0, nav0, pid0, param
@@ -546,6 +573,11 @@ class ScenarioHostScene:
         st["done_out"] = np.zeros((E * A, 2), np.uint8)
         st["need_reset"] = np.ones(E, np.int32)
         st["next_agent_id"] = np.zeros(E, np.int32)     # ScenarioTrafficManager.idm_policy_count
+        if cfg["reactive_traffic"]:
+            st["route_n"] = np.zeros((N, 4), np.int32)
+            st["route_segs"] = np.zeros((N, self.route_seg_cap), dtype=abi.SEG_DT)
+            st["route_verts"] = np.zeros((N, self.route_vert_cap, 2), np.float32)
+            st["route_aux"] = np.zeros((N, 8), np.float32)
         self.state = st
         self.tracks = dict(shape=fshape, dyn=fdyn, seeds=list(self.seeds), cap=cap)
         k = make_md_config(dict(cfg, traffic_mode="trigger"), E, A, cap, self.n_beams)
@@ -561,6 +593,7 @@ class ScenarioHostScene:
                      "no_static_vehicles"):
             setattr(k, name, int(bool(cfg[name])))
         k.allowed_more_steps = int(cfg["allowed_more_steps"] or 0)
+        k.route_seg_cap, k.route_vert_cap = self.route_seg_cap, self.route_vert_cap
         self.md_config = k
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
         self.ll_beams = beam_table(self.n_ll, np.pi / 2) if self.n_ll else None

@@ -444,6 +444,7 @@ static void step_env_scenario(const MdWorld* w, const MdState* s, const MdConfig
             s->action[2 * (base + j) + 1] = 0.0f;
         }
         s->next_agent_id[e] = 0;   /* idm_policy_count (scenario_traffic_manager.py:87) */
+        if (s->route_n) memset(&s->route_n[4 * (size_t)base], 0, sizeof(int32_t) * 4 * c->cap);   /* no cut routes left */
         s->need_reset[e] = 0;
         just_reset = 1;
     }
@@ -464,6 +465,12 @@ static void step_env_scenario(const MdWorld* w, const MdState* s, const MdConfig
             lidar_agent(w, s, c, e, a, row + md_sc_obs_lidar(c));
         }
     }
+}
+
+/* md_build_route on a point list (tests: against the reference's PointLane) */
+EXPORT int ref_build_route(const float* xy, int n_pts, MdSeg* segs, int seg_cap, float* verts, int vert_cap, float* aux,
+                           int32_t* counts) {
+    return md_build_route(xy, 2, n_pts, segs, seg_cap, verts, vert_cap, aux, counts);
 }
 
 EXPORT int ref_lifecycle(const MdWorld* w, const MdState* s, const MdConfig* c) {

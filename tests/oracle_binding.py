@@ -41,6 +41,8 @@ def load(path=None):
     lib.ref_line_detector.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
     lib.ref_abi.restype = C.c_int
     lib.ref_abi.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.ref_build_route.restype = C.c_int
+    lib.ref_build_route.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ref_others_block.restype = C.c_int
     lib.ref_others_block.argtypes = [W, S, K, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p]
     f = C.c_float
@@ -197,3 +199,21 @@ def lidar_raw(shape, beam_cs, E, cap, n_beams, lidar_range):
     rc = lib.ref_lidar(C.byref(w), C.byref(s), C.byref(k), C.c_void_p(out.ctypes.data), n_beams, 0)
     assert rc == 0
     return out
+
+
+def build_route(points, seg_cap=None, vert_cap=None):
+    """md_build_route (include/md_scenario.h) on a point list -> (pieces SEG_DT, outline [n, 2], aux [8], rc)"""
+    import numpy as np
+    from metadrive_ped_amd import abi
+    pts = np.ascontiguousarray(np.asarray(points, np.float32)[:, :2])
+    seg_cap = seg_cap or max(1, len(pts))
+    if vert_cap is None:
+        d = np.diff(pts.astype(np.float64), axis=0)
+        vert_cap = 2 * (int(np.ceil(np.sqrt((d ** 2).sum(1)).sum())) + 3) + 4
+    segs = np.zeros(seg_cap, dtype=abi.SEG_DT)
+    verts = np.zeros((vert_cap, 2), np.float32)
+    aux = np.zeros(8, np.float32)
+    counts = np.zeros(2, np.int32)
+    rc = load().ref_build_route(pts.ctypes.data, len(pts), segs.ctypes.data, seg_cap, verts.ctypes.data, vert_cap, aux.ctypes.data,
+                                counts.ctypes.data)
+    return segs[:counts[0]], verts[:counts[1]], aux, rc

@@ -17,6 +17,7 @@ from metadrive_ped_amd.scenario import PolyLine, ScenarioHostScene, make_scenari
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SC_KEYS = ["shape", "dyn", "nav", "pid", "action", "flags", "obs", "reward", "cost", "step_info", "need_reset", "next_agent_id"]
+ROUTE_KEYS = ["route_n", "route_segs", "route_verts", "route_aux"]     # routes cut at a later spawn frame (reactive_traffic only)
 
 
 def _oracle(host):
@@ -124,7 +125,8 @@ def test_scenario_step_gpu_parity(reactive):
     eng.reset()
     o.reset()
     from helpers import assert_state_equal
-    assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="scenario reset")
+    keys = SC_KEYS + (ROUTE_KEYS if reactive else [])
+    assert_state_equal(eng.download_state(), o.state, keys=keys, where="scenario reset")
     rng = np.random.RandomState(3)
     for t in range(320):
         a = _follow(o.obs, throttle=0.35 if (t // 60) % 2 == 0 else -0.4)
@@ -133,9 +135,9 @@ def test_scenario_step_gpu_parity(reactive):
         eng.step(torch.from_numpy(a).to(eng.device))
         o.step(a)
         if t % 20 == 0 or t > 300:
-            assert_state_equal(eng.download_state(), o.state, keys=SC_KEYS, where="scenario step %d" % t)
+            assert_state_equal(eng.download_state(), o.state, keys=keys, where="scenario step %d" % t)
     st = eng.download_state()
-    assert_state_equal(st, o.state, keys=SC_KEYS, where="scenario final")
+    assert_state_equal(st, o.state, keys=keys, where="scenario final")
     nav = st["nav"].reshape(E, host.cap)
     if reactive:
         assert (nav["ck0"] == abi.SC_IDM).any() or st["next_agent_id"].sum() > 0
@@ -512,3 +514,100 @@ def test_road_lines_raise_flags_and_end_episodes_on_oracle():
                 assert float(o.state["step_info"].reshape(E, -1, 8)[e, 0, 0]) == -3.0          # step_reward = -on_lane_line_penalty
     assert (done_step >= 0).all() and (done_step > 5).all()
     # crossing a BROKEN separator earlier raised no termination: every env drove more than one lane width before it ended
+
+
+# ------------------------------------------------------------------------------------------------
+# routes cut at a later spawn frame (scenario_traffic_manager.py:216-236: get_max_valid_indicis(track, episode_step), get_idm_route)
+# ------------------------------------------------------------------------------------------------
+def test_route_builder_against_reference_point_lane():
+    """md_build_route (what md_step runs when a reactive policy is created at a frame other than its first run's start) against
+    the reference's PointLane on the golden polylines, and -- on every suffix of them -- against the host's PolyLine, which the
+    golden test above pins to the reference: pieces, outline polygon, end point."""
+    g = _golden()
+    n = 0
+    for pl in g["polylines"]:
+        pts = np.asarray(pl["points"], np.float64)[:, :2]
+        segs, verts, aux, rc = ob.build_route(pts)
+        assert rc == 0 and len(segs) == len(pl["segments"]) and len(verts) == len(pl["polygon"])
+        ref = pl["segments"]
+        tol = 4e-7 * max(1.0, float(np.abs(pts).max()))      # float32 storage of coordinates up to ~900 m
+        np.testing.assert_allclose(np.c_[segs["sx"], segs["sy"]], [r["start"] for r in ref], atol=tol)
+        np.testing.assert_allclose(np.c_[segs["ex"], segs["ey"]], [r["end"] for r in ref], atol=tol)
+        np.testing.assert_allclose(np.c_[segs["dx"], segs["dy"]], [r["direction"] for r in ref], atol=1e-6)
+        np.testing.assert_allclose(segs["len"], [r["length"] for r in ref], atol=1e-6)
+        np.testing.assert_allclose(segs["heading"], [r["heading"] for r in ref], atol=1e-6)
+        np.testing.assert_allclose(verts, np.asarray(pl["polygon"])[:, :2], atol=tol)
+        np.testing.assert_allclose(aux[:2], np.asarray(pl["end"])[:2], atol=tol)
+        assert np.allclose(aux[2:6], [verts[:, 0].min(), verts[:, 1].min(), verts[:, 0].max(), verts[:, 1].max()])
+        for k in range(1, len(pts) - 1, max(1, len(pts) // 9)):       # suffixes: the route of a spawn at frame k
+            sub = pts[k:].astype(np.float32).astype(np.float64)      # (the device reads float32 frames)
+            host_line = PolyLine(sub)
+            segs, verts, aux, rc = ob.build_route(sub)
+            rec = host_line.records()
+            assert rc == 0 and len(segs) == len(rec)
+            for f in ("sx", "sy", "ex", "ey", "dx", "dy", "len", "cum"):
+                np.testing.assert_allclose(segs[f], rec[f], atol=tol, err_msg=f)
+            np.testing.assert_allclose(verts, host_line.outline(), atol=tol)
+            n += 1
+    assert n > 40
+    # buffers too small: refused, nothing usable left
+    segs, verts, aux, rc = ob.build_route(np.asarray(g["polylines"][0]["points"]), seg_cap=5)
+    assert rc == -1 and len(segs) == 0
+
+
+def test_vehicle_spawned_late_gets_a_route_cut_at_the_spawn_frame():
+    """A reactive vehicle that reaches the end of its route is removed; while its track is still valid it is spawned again at the
+    recorded position, and -- being behind the ego, moving, with more than 5 m left -- gets a NEW policy whose route starts at that
+    frame and ends with the run.  Same for a track that appears a second time after a gap."""
+    E = 16
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=400, auto_reset=False))
+    host = ScenarioHostScene(cfg, synthetic_scenarios(E, 300))
+    runs, run_off = host.world.arrays["runs"], host.world.arrays["run_off"]
+    assert host.md_config.route_seg_cap >= int((runs[:, 1] - runs[:, 0]).max())
+    o = _oracle(host)
+    o.reset()
+    frames = host.tracks["shape"].reshape(host.T, E, host.cap)
+    rn = o.state["route_n"].reshape(E, host.cap, 4)
+    segs = o.state["route_segs"].reshape(E, host.cap, -1)
+    verts = o.state["route_verts"].reshape(E, host.cap, -1, 2)
+    nav = o.state["nav"].reshape(E, host.cap)
+    meta = host.world.arrays["track_meta"].reshape(E, host.cap, 4)
+    assert (rn == 0).all()
+    seen = {}
+    for t in range(1, 200):
+        o.step(_follow(o.obs))
+        for e, j in np.argwhere(rn[:, :, 0] > 0):
+            k = int(rn[e, j, 2])
+            if (e, j, k) in seen:
+                continue
+            seen[(e, j, k)] = t
+            assert k == t and k != meta[e, j, 0] and nav["ck0"][e, j] == abi.SC_IDM     # built in the step of the spawn
+            ng = e * host.cap + j
+            mine = runs[run_off[ng]:run_off[ng + 1]]
+            t1 = int(mine[(mine[:, 0] <= k) & (k < mine[:, 1])][0, 1])
+            pts = np.c_[frames["cx"][k:t1, e, j], frames["cy"][k:t1, e, j]].astype(np.float64)
+            want = PolyLine(pts)
+            got = segs[e, j, :rn[e, j, 0]]
+            assert len(got) == len(want.seg_len)
+            np.testing.assert_allclose(np.c_[got["sx"], got["sy"]], want.start, atol=1e-4)
+            np.testing.assert_allclose(got["cum"], want.cum, atol=1e-4)
+            assert np.hypot(*(pts[0] - pts[-1])) > 5.0                                    # IDM_CREATE_MIN_LENGTH on the cut route
+            np.testing.assert_allclose(verts[e, j, :rn[e, j, 1]], want.outline(), atol=1e-4)
+            assert abs(got["sx"][0] - frames["cx"][k, e, j]) < 1e-6                       # the route starts where the vehicle was put
+    assert len(seen) >= 4
+    # an env reset leaves no cut route behind
+    o.state["need_reset"][:] = 1
+    o.step(_follow(o.obs))
+    assert (rn == 0).all()
+    # without the route buffers (MdState.route_n NULL) such spawns are replayed, as before ABI 9
+    st = host.clone_state()
+    for key in ("route_n", "route_segs", "route_verts", "route_aux"):
+        st.pop(key)
+    o2 = ob.OracleWorld(host, st)
+    o2.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+    o2.reset()
+    first = min(seen.values())
+    e, j, k = [key for key, t in seen.items() if t == first][0]
+    for t in range(1, first + 1):
+        o2.step(_follow(o2.obs))
+    assert o2.state["nav"].reshape(E, host.cap)["ck0"][e, j] == abi.SC_REPLAY

@@ -151,7 +151,7 @@ def test_mixed_length_batch_gpu_parity(tmp_path):
     o = _oracle(host)
     eng.reset()
     o.reset()
-    keys = SC_KEYS + ["need_reset", "next_agent_id"]
+    keys = SC_KEYS + ["need_reset", "next_agent_id", "route_n", "route_segs", "route_verts", "route_aux"]
     saw_max_step = np.zeros(E, bool)
     for t in range(180):
         a = np.zeros((E, 1, 2), np.float32)
