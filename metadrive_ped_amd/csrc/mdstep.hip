@@ -2344,6 +2344,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     float* l_pts = reinterpret_cast<float*>(l_len + c.route_seg_cap + 1);
     int* l_link = reinterpret_cast<int*>(l_pts + 2 * c.route_seg_cap);
     int32_t* l_rn = l_link + c.route_seg_cap;   // [cap][4]: route_n of the scene (the decisions read it first: not a global round trip)
+    // [cap] the movers as the agent's contact test sees them: after the integration, BEFORE the traffic manager's after_step
+    MdShape* l_shape_ct = reinterpret_cast<MdShape*>((reinterpret_cast<uintptr_t>(g.route_n != nullptr ? (void*)(l_rn + 4 * cap) : (void*)l_len) + 15) & ~(uintptr_t)15);
 
     MD_STAMP_AT(0);
     const MdState gv = md_env_view(&g, &c, e);
@@ -2429,6 +2431,16 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         __syncthreads();
     }
     MD_STAMP_AT(3);
+    // The agent's contact flags come from BaseVehicle.after_step (a contact test at the bodies' present poses), which the agent
+    // manager runs BEFORE the traffic manager's after_step: replayed bodies are still at frame k-1, bodies removed / spawned in
+    // this step are still / not yet there.  Wave 1 tests against a snapshot of the shapes while wave 0 runs after_step.
+    copy16(l_shape_ct, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+    __syncthreads();
+    if (wave == 1) {
+        MdState sc = s;
+        sc.shape = l_shape_ct;
+        for (int a = 0; a < A; ++a) contacts_vehicle(w, sc, c, e, a, lane, l_cfl);
+    }
     // ---- after_step of the traffic manager: lanes = track slots, in slot order ----
     if (wave == 0) {
         for (int j0 = A; j0 < cap; j0 += 64) {
@@ -2464,7 +2476,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     }
     __syncthreads();
     MD_STAMP_AT(4);
-    // ---- the agents: projection on the reference trajectory (wave 0) beside their contacts (wave 1) ----
+    // ---- the agents: projection on the reference trajectory (wave 0); waves 2, 3: the detectors ----
     float* l_beams = reinterpret_cast<float*>(l_dbest + A * n_det);   // [n_det][2]: the beam tables, read n_beams times per quad
     if (fused_det) {
         const int ns = w.side_beam_cs ? c.n_side : 0;
@@ -2479,9 +2491,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             MdTrajLoc L;
             traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L);
             if (lane == 0) l_loc[a] = L;
-        } else if (wave == 1) {
-            contacts_vehicle(w, s, c, e, a, lane, l_cfl);
-        } else if (fused_det) {
+        } else if (wave >= 2 && fused_det) {
             // waves 2 and 3 have nothing to do in this stage and the next: the side / lane-line detectors of the agent,
             // each wave one half of the scene's line pieces (the poses are final here)
             const MdShape me = s.shape[a];
@@ -3373,7 +3383,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
                            (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
                            (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int) +
                            ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0) +
-                           (s->route_n ? (size_t)c->route_seg_cap * 20 + 16 + (size_t)c->cap * 16 : 0);   // route_n; positions, links, lengths of a route being built
+                           (s->route_n ? (size_t)c->route_seg_cap * 20 + 16 + (size_t)c->cap * 16 : 0) +   // route_n; positions, links, lengths of a route being built
+                           (size_t)c->cap * sizeof(MdShape) + 32;   // the shapes the contact test sees
         if (s->route_n) {
             NEED(s->route_segs); NEED(s->route_verts); NEED(s->route_aux); NEED(w->run_off); NEED(w->runs);
             if (c->route_seg_cap < 1 || c->route_vert_cap < 8) {

@@ -455,10 +455,15 @@ static void step_env_scenario(const MdWorld* w, const MdState* s, const MdConfig
             if (v.nav[j].ck0 == MD_SC_IDM && md_present(v.shape[j].flags)) md_tidm_vehicle(w, &v, c, e, j, k);
         for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
     }
-    md_scenario_after_step_env(w, &v, c, e, k);
+    /* the agent's contact flags come from BaseVehicle.after_step (_state_check: a contact test at the bodies' present poses), which the
+     * agent manager runs BEFORE the traffic manager's after_step (same priority, registered first: envs/scenario_env.py:118-126):
+     * replayed bodies are still at frame k-1, bodies removed / spawned in this step are still / not yet there */
     for (int a = 0; a < c->agents_per_env; ++a) {
         s->flags[base + a] = 0;
         contacts_mover(w, s, c, e, a);
+    }
+    md_scenario_after_step_env(w, &v, c, e, k);
+    for (int a = 0; a < c->agents_per_env; ++a) {
         md_scenario_observe(w, &v, c, e, a, just_reset);
         if (c->n_beams > 0) {
             float* row = s->obs + (size_t)(e * c->agents_per_env + a) * c->obs_dim;

@@ -611,3 +611,30 @@ def test_vehicle_spawned_late_gets_a_route_cut_at_the_spawn_frame():
     for t in range(1, first + 1):
         o2.step(_follow(o2.obs))
     assert o2.state["nav"].reshape(E, host.cap)["ck0"][e, j] == abi.SC_REPLAY
+
+
+def test_contact_flags_see_replayed_bodies_one_frame_late():
+    """BaseVehicle.after_step (contact test at the bodies' present poses) runs before ScenarioTrafficManager.after_step moves the
+    replayed bodies (both managers have priority 10, the agent manager is registered first: envs/base_env.py:744,
+    envs/scenario_env.py:118-126): a body teleported onto the ego in frame 5 is hit in step 6, when it is already gone again;
+    the lidar (observation time) sees it in step 5."""
+    from metadrive_ped_amd.scenario import _track_dict
+    T = 40
+    pts = np.c_[np.linspace(0.0, 60.0, T), np.zeros(T)]
+    x = np.full(T, 300.0)
+    y = np.full(T, 50.0) + np.arange(T) * 0.5        # far away, drifting (so it is not a "static" car)
+    x[5], y[5] = 4.0, 0.0                              # one frame into the nose of the (standing) ego
+    other = _track_dict("9", "VEHICLE", T, np.ones(T, bool), x, y, np.zeros(T), np.zeros(T), 4.5, 1.85, 1.5)
+    host = _one_scene_host(pts, extra_tracks={"9": other}, reactive_traffic=False, crash_vehicle_done=False,
+                           vehicle_config=dict(lidar=dict(num_lasers=60, distance=50), side_detector=dict(num_lasers=0, distance=50)))
+    o = _oracle(host)
+    o.reset()
+    crash, near = [], []
+    for t in range(1, 9):
+        a = np.zeros((1, 1, 2), np.float32)
+        a[0, 0, 1] = -1.0
+        o.step(a)
+        crash.append(bool(o.state["flags"][0] & abi.FL_CRASH_VEHICLE))
+        near.append(float(o.obs[0, -60:].min()) < 0.2)
+    assert crash == [False, False, False, False, False, True, False, False]
+    assert near == [False, False, False, False, True, False, False, False]
