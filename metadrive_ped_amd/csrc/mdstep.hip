@@ -2427,15 +2427,20 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         }
         __syncthreads();
         MD_STAMP_AT(2);
-        for (int j = tid; j < cap; j += kBlock) md_integrate_mover(&s, &c, j);
+        for (int j = tid; j < cap; j += kBlock) {
+            md_integrate_mover(&s, &c, j);
+            l_shape_ct[j] = l_shape[j];   // what the contact test below sees
+        }
         __syncthreads();
     }
     MD_STAMP_AT(3);
     // The agent's contact flags come from BaseVehicle.after_step (a contact test at the bodies' present poses), which the agent
     // manager runs BEFORE the traffic manager's after_step: replayed bodies are still at frame k-1, bodies removed / spawned in
     // this step are still / not yet there.  Wave 1 tests against a snapshot of the shapes while wave 0 runs after_step.
-    copy16(l_shape_ct, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
-    __syncthreads();
+    if (just_reset) {
+        copy16(l_shape_ct, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
+        __syncthreads();
+    }
     if (wave == 1) {
         MdState sc = s;
         sc.shape = l_shape_ct;
