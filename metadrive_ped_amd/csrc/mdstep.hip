@@ -2372,6 +2372,13 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     if (tid == 0) *l_count = do_reset ? 0 : gv.next_agent_id[0];   // idm_policy_count
     if (gv.route_n)
         for (int j = tid; j < 4 * cap; j += kBlock) l_rn[j] = do_reset ? 0 : gv.route_n[j];   // a reset leaves no cut routes
+    float* l_beams = reinterpret_cast<float*>(l_dbest + A * n_det);   // [n_det][2]: the beam tables, read n_beams times per quad
+    if (fused_det) {
+        const int ns = w.side_beam_cs ? c.n_side : 0;
+        for (int it = tid; it < A * n_det; it += kBlock) l_dbest[it] = __float_as_int(1.0f);
+        for (int it = tid; it < 2 * n_det; it += kBlock)
+            l_beams[it] = (it < 2 * ns) ? w.side_beam_cs[it] : w.ll_beam_cs[it - 2 * ns];
+    }
     MdState s = gv;
     if (gv.route_n) s.route_n = l_rn;
     s.shape = l_shape;
@@ -2436,7 +2443,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     MD_STAMP_AT(3);
     // The agent's contact flags come from BaseVehicle.after_step (a contact test at the bodies' present poses), which the agent
     // manager runs BEFORE the traffic manager's after_step: replayed bodies are still at frame k-1, bodies removed / spawned in
-    // this step are still / not yet there.  Wave 1 tests against a snapshot of the shapes while wave 0 runs after_step.
+    // this step are still / not yet there.  Wave 1 tests against a snapshot of the shapes while wave 0 runs after_step and the
+    // agent's projection, and waves 2 / 3 the detectors: one stage, one barrier.
     if (just_reset) {
         copy16(l_shape_ct, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
         __syncthreads();
@@ -2479,17 +2487,9 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             }
         }
     }
-    __syncthreads();
     MD_STAMP_AT(4);
-    // ---- the agents: projection on the reference trajectory (wave 0); waves 2, 3: the detectors ----
-    float* l_beams = reinterpret_cast<float*>(l_dbest + A * n_det);   // [n_det][2]: the beam tables, read n_beams times per quad
-    if (fused_det) {
-        const int ns = w.side_beam_cs ? c.n_side : 0;
-        for (int it = tid; it < A * n_det; it += kBlock) l_dbest[it] = __float_as_int(1.0f);
-        for (int it = tid; it < 2 * n_det; it += kBlock)
-            l_beams[it] = (it < 2 * ns) ? w.side_beam_cs[it] : w.ll_beam_cs[it - 2 * ns];
-        __syncthreads();
-    }
+    // ---- the agents, in the same stage (nothing below reads a slot after_step writes: the agent's own pose is final after the
+    // integration): projection on the reference trajectory (wave 0, after its after_step); waves 2, 3: the detectors ----
     for (int a = 0; a < A; ++a) {
         if (wave == 0) {
             const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);

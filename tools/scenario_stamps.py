@@ -11,8 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = ["stage-in", "decide (TrajectoryIDMPolicy, wave per vehicle)", "integrate", "traffic manager after_step",
-          "agent: trajectory projection || contacts", "agent: observation / reward / done (one lane)", "lidar", "write-back"]
+PHASES = ["stage-in", "decide (TrajectoryIDMPolicy, wave per vehicle)", "integrate", "traffic manager after_step (wave 0; contacts on wave 1, detectors on waves 2-3 beside it)",
+          "agent: trajectory projection, then the barrier (contacts / detectors done)", "agent: observation / reward / done (one lane)", "lidar", "write-back"]
 
 
 def main():
