@@ -1332,6 +1332,109 @@ def section_scenario():
     dump("scenario.json", out)
 
 
+def section_scenario_spawn():
+    """ScenarioTrafficManager.spawn_vehicle (manager/scenario_traffic_manager.py:171-236) -- the reference's own method on a manager
+    whose engine is a recording stand-in (spawn_object / add_policy need Bullet): for posed egos and single tracks at an episode
+    step k, whether a vehicle is created, with which policy (replay / TrajectoryIDMPolicy), its policy index, and the route the
+    reactive policy gets -- PointLane(positions[k : end of the valid run]) (get_max_valid_indicis, get_idm_route): start, end,
+    length, number of pieces.
+    Supplied by the generator: BaseVehicle.convert_to_local_coordinates = the (forward, left) projection (as in agent_step.json)."""
+    from types import SimpleNamespace
+    sys.path.insert(0, ROOT)
+    from metadrive.manager.scenario_traffic_manager import ScenarioTrafficManager
+    from metadrive.policy.idm_policy import TrajectoryIDMPolicy
+    from metadrive.policy.replay_policy import ReplayTrafficParticipantPolicy
+    from metadrive_ped_amd.scenario import _track_dict
+    rng = np.random.RandomState(99)
+    T = 60
+
+    class Probe(ScenarioTrafficManager):
+        """spawn_vehicle with everything Bullet-side recorded instead of executed"""
+        def __init__(self, cfg, ego, step, idm_count):
+            self._cfg, self._ego, self._step = cfg, ego, step
+            self._static_car_id, self._moving_car_id = set(), set()
+            self._scenario_id_to_obj_id, self._obj_id_to_scenario_id = {}, {}
+            self.idm_policy_count = idm_count
+            self.even_sample_v, self.need_default_vehicle = True, False
+            self.is_ego_vehicle_replay = False
+            self._filter_overlapping_car = cfg["filter_overlapping_car"]
+            self._traffic_v_config = {}
+            self.np_random = np.random.RandomState(0)
+            self.spawned, self.policy = None, None
+
+        engine = property(lambda self: SimpleNamespace(global_config=self._cfg))
+        episode_step = property(lambda self: self._step)
+        ego_vehicle = property(lambda self: self._ego)
+
+        def spawn_object(self, cls, **kw):
+            self.spawned = dict(cls=cls.__name__, position=[float(x) for x in kw["position"]], heading=float(kw["heading"]))
+            return SimpleNamespace(name="obj")
+
+        def add_policy(self, name, cls, *args):
+            self.policy = dict(cls=cls.__name__)
+            if cls is TrajectoryIDMPolicy:
+                lane, index = args[2], args[3]
+                self.policy.update(policy_index=int(index), route_start=[float(x) for x in lane.start], route_end=[float(x) for x in lane.end],
+                                   route_length=float(lane.length), route_pieces=len(lane.segment_property))
+            return SimpleNamespace(act=lambda *a, **k: None)
+
+        def generate_seed(self):
+            return 0
+
+    cases = []
+    for ci in range(400):
+        ego_h = float(rng.uniform(-math.pi, math.pi))
+        ego_p = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20)])
+        ego = SimpleNamespace(position=ego_p, heading_theta=ego_h)
+        c_, s_ = math.cos(ego_h), math.sin(ego_h)
+        ego.convert_to_local_coordinates = lambda v, o, c_=c_, s_=s_: ((v[0] - o[0]) * c_ + (v[1] - o[1]) * s_, (v[1] - o[1]) * c_ - (v[0] - o[0]) * s_)
+        k = int(rng.choice([0, 0, 7, 13, 25]))
+        # the track at frame k, relative to the ego: near the thresholds of every filter in a good share of the cases
+        if ci % 2 == 0:     # a candidate for a reactive policy: behind the ego, beside it, heading its way, moving
+            fwd = float(rng.choice([rng.uniform(-30, -1.2), rng.uniform(-9, -7), rng.uniform(-1.5, -0.5)]))
+            side = float(rng.choice([rng.uniform(-14, 14), rng.uniform(-2.5, 2.5), rng.uniform(14, 16), rng.uniform(-16, -14)]))
+            rel_h = float(rng.choice([rng.uniform(-1.4, 1.4), math.pi / 2 + rng.uniform(-0.05, 0.05)]))
+            speed_mps = float(rng.choice([rng.uniform(2, 12), rng.uniform(2, 12), rng.uniform(0.3, 2.5)]))
+        else:
+            fwd = float(rng.choice([rng.uniform(-40, 40), rng.uniform(-9, -7), rng.uniform(7, 9), rng.uniform(-1.5, -0.5)]))
+            side = float(rng.choice([rng.uniform(-25, 25), rng.uniform(-2.5, 2.5), rng.uniform(14, 16), rng.uniform(-16, -14)]))
+            rel_h = float(rng.choice([rng.uniform(-math.pi, math.pi), rng.uniform(-0.3, 0.3), math.pi / 2 + rng.uniform(-0.05, 0.05)]))
+            speed_mps = float(rng.choice([0.0, 0.2, rng.uniform(0.5, 3.0), rng.uniform(2, 12)]))
+        h = ego_h + rel_h
+        t = np.arange(T)
+        xk, yk = float(ego_p[0] + fwd * c_ - side * s_), float(ego_p[1] + fwd * s_ + side * c_)
+        px = xk + (t - k) * 0.1 * speed_mps * math.cos(h)       # (the test rebuilds the positions with these two lines)
+        py = yk + (t - k) * 0.1 * speed_mps * math.sin(h)
+        valid = np.ones(T, bool)
+        pattern = int(rng.randint(0, 5))
+        if pattern == 1:
+            valid[:k] = False                                     # appears at k
+        elif pattern == 2 and k > 3:
+            valid[k - 3:k] = False                                # a gap right before k: second run
+        elif pattern == 3:
+            valid[k + int(rng.randint(2, 20)):] = False           # ends soon after k
+        elif pattern == 4:
+            valid[k] = bool(rng.rand() < 0.5)                     # maybe not valid at k at all
+        tr = _track_dict("9", "VEHICLE", T, valid, px, py, np.full(T, h), np.full(T, speed_mps), float(rng.choice([3.6, 4.6, 6.5])), 1.9, 1.6)
+        cfg = dict(no_static_vehicles=bool(rng.rand() < 0.25), reactive_traffic=bool(rng.rand() < 0.8), force_reuse_object_name=False,
+                   top_down_show_real_size=False, filter_overlapping_car=bool(rng.rand() < 0.8))
+        idm_count = int(rng.randint(0, 9))
+        m = Probe(cfg, ego, k, idm_count)
+        m.spawn_vehicle("9", tr)
+        st = tr["state"]
+        cases.append(dict(ego_position=[float(x) for x in ego_p], ego_heading=ego_h, step=k, idm_count=idm_count, config=cfg,
+                          track=dict(xk=xk, yk=yk, heading=float(h), speed=speed_mps, valid="".join("1" if v else "0" for v in valid),
+                                     length=float(st["length"].max())),
+                          spawned=m.spawned, policy=m.policy, idm_count_after=int(m.idm_policy_count),
+                          moving=("9" in m._moving_car_id)))
+    kinds = [(c["spawned"] is not None, (c["policy"] or {}).get("cls")) for c in cases]
+    print("scenario_spawn: %d cases, not spawned %d, replay %d, reactive %d (of them at a later frame than the run's start: %d)" % (
+        len(cases), sum(1 for a, b in kinds if not a), sum(1 for a, b in kinds if b == "ReplayTrafficParticipantPolicy"),
+        sum(1 for a, b in kinds if b == "TrajectoryIDMPolicy"),
+        sum(1 for c in cases if (c["policy"] or {}).get("cls") == "TrajectoryIDMPolicy" and c["step"] > 0 and c["track"]["valid"][c["step"] - 1] == "1")))
+    dump("scenario_spawn.json", dict(supplied_by_generator=["convert_to_local_coordinates (forward, left)"], frames=T, cases=cases))
+
+
 def section_pg_maps_v2():
     """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
     straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
@@ -1458,7 +1561,7 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -662,6 +662,13 @@ EXPORT int ref_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* 
     md_tidm_vehicle(w, &v, c, e, slot, k);
     return MD_OK;
 }
+/* ScenarioTrafficManager.after_step of env e at episode step k alone (tests: against the reference's spawn_vehicle) */
+EXPORT int ref_scenario_after_step(const MdWorld* w, const MdState* s, const MdConfig* c, int e, int k) {
+    MdState v = md_env_view(s, c, e);
+    md_scenario_after_step_env(w, &v, c, e, k);
+    return 0;
+}
+
 EXPORT int ref_point_in_polygon(const float* xy, int n, float px, float py) { return md_point_in_polygon(xy, n, px, py); }
 EXPORT int ref_abi(int32_t* sizes, int n) {
     int32_t v[11] = {sizeof(MdShape), sizeof(MdDyn), sizeof(MdParam), sizeof(MdNav), sizeof(MdPid), sizeof(MdLane),

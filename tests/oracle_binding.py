@@ -41,6 +41,8 @@ def load(path=None):
     lib.ref_line_detector.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_void_p, C.c_int, C.c_int]
     lib.ref_abi.restype = C.c_int
     lib.ref_abi.argtypes = [C.POINTER(C.c_int32), C.c_int]
+    lib.ref_scenario_after_step.restype = C.c_int
+    lib.ref_scenario_after_step.argtypes = [W, S, K, C.c_int, C.c_int]
     lib.ref_build_route.restype = C.c_int
     lib.ref_build_route.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ref_others_block.restype = C.c_int

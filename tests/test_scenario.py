@@ -638,3 +638,73 @@ def test_contact_flags_see_replayed_bodies_one_frame_late():
         near.append(float(o.obs[0, -60:].min()) < 0.2)
     assert crash == [False, False, False, False, False, True, False, False]
     assert near == [False, False, False, False, True, False, False, False]
+
+
+def test_spawn_decisions_against_reference_spawn_vehicle():
+    """ScenarioTrafficManager.spawn_vehicle itself (tests/golden/scenario_spawn.json: the reference's method with Bullet-side calls
+    recorded): created or not (validity, static cars, the 8 m x 2 m overlap filter), replay or reactive policy (behind the ego
+    by > 1 m, within 15 m sideways, heading within 90 degrees, moving, > 5 m of path left), the policy index, and the route of the
+    reactive policy -- cut at the spawn frame when that is not the start of the track's first valid run."""
+    import ctypes as C
+    from metadrive_ped_amd.scenario import _track_dict
+    with open(os.path.join(GOLDEN, "scenario_spawn.json")) as f:
+        g = json.load(f)
+    T = g["frames"]
+    sdc_pts = np.c_[np.linspace(0.0, 59.0, T), np.zeros(T)]
+    n_kind = dict(none=0, replay=0, idm=0, idm_late=0)
+    for case in g["cases"]:
+        tr, k = case["track"], case["step"]
+        t = np.arange(T)
+        px = tr["xk"] + (t - k) * 0.1 * tr["speed"] * math.cos(tr["heading"])
+        py = tr["yk"] + (t - k) * 0.1 * tr["speed"] * math.sin(tr["heading"])
+        valid = np.array([ch == "1" for ch in tr["valid"]])
+        other = _track_dict("9", "VEHICLE", T, valid, px, py, np.full(T, tr["heading"]), np.full(T, tr["speed"]), tr["length"], 1.9, 1.6)
+        cf = case["config"]
+        host = _one_scene_host(sdc_pts, T=T, extra_tracks={"9": other}, reactive_traffic=cf["reactive_traffic"],
+                               no_static_vehicles=cf["no_static_vehicles"], filter_overlapping_car=cf["filter_overlapping_car"],
+                               vehicle_config=dict(lidar=dict(num_lasers=0, distance=0), side_detector=dict(num_lasers=0, distance=50)))
+        assert host.track_ids[0][1] == "9"
+        meta = host.world.arrays["track_meta"].reshape(-1, 4)
+        if valid.any():
+            assert bool(meta[1, 2] & abi.TM_MOVING) == case["moving"], case
+        o = ob.OracleWorld(host, host.clone_state())
+        o.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+        st = o.state
+        st["need_reset"][:] = 0
+        eh = case["ego_heading"]
+        st["shape"]["cx"][0], st["shape"]["cy"][0] = case["ego_position"]
+        st["shape"]["c"][0], st["shape"]["s"][0] = math.cos(eh), math.sin(eh)
+        st["dyn"]["heading"][0] = eh
+        st["next_agent_id"][0] = case["idm_count"]
+        assert o.lib.ref_scenario_after_step(C.byref(o.w), C.byref(o.s), C.byref(o.k), 0, k) == 0
+        nav, sh, dy = st["nav"][1], st["shape"][1], st["dyn"][1]
+        where = "case ego=%s step=%d track=%s cfg=%s" % (case["ego_position"], k, tr, cf)
+        if case["spawned"] is None:
+            assert nav["ck0"] == abi.SC_ABSENT and not (sh["flags"] & abi.F_ALIVE), where
+            n_kind["none"] += 1
+            continue
+        assert sh["flags"] & abi.F_ALIVE, where
+        assert abs(sh["cx"] - case["spawned"]["position"][0]) < 1e-4 and abs(sh["cy"] - case["spawned"]["position"][1]) < 1e-4, where
+        pol = case["policy"]
+        if pol["cls"] == "ReplayTrafficParticipantPolicy":
+            assert nav["ck0"] == abi.SC_REPLAY, where
+            assert st["next_agent_id"][0] == case["idm_count"]
+            n_kind["replay"] += 1
+            continue
+        assert nav["ck0"] == abi.SC_IDM and nav["timer"] == pol["policy_index"] and dy["speed"] == 0.0, where
+        assert st["next_agent_id"][0] == case["idm_count_after"]
+        rn = st["route_n"][1]
+        if rn[0] > 0:
+            segs, aux = st["route_segs"][1][:rn[0]], st["route_aux"][1]
+            n_kind["idm_late"] += 1
+            assert k != meta[1, 0]
+        else:
+            a, b = host.world.arrays["poly_off"][1], host.world.arrays["poly_off"][2]
+            segs, aux = host.world.arrays["segs"][a:b], host.world.arrays["poly_aux"][1]
+            assert k == meta[1, 0]
+        assert len(segs) == pol["route_pieces"], where
+        np.testing.assert_allclose([segs["sx"][0], segs["sy"][0]], pol["route_start"], atol=1e-4, err_msg=where)
+        np.testing.assert_allclose(aux[:2], pol["route_end"], atol=1e-3, err_msg=where)
+        assert abs(float(segs["cum"][-1] + segs["len"][-1]) - pol["route_length"]) < 1e-3, where
+        n_kind["idm"] += 1
+    assert n_kind["none"] > 80 and n_kind["replay"] > 150 and n_kind["idm"] > 40 and n_kind["idm_late"] > 10, n_kind
