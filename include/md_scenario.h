@@ -643,6 +643,37 @@ MD_HD void md_tidm_vehicle(const MdWorld* w, const MdState* s, const MdConfig* c
 }
 
 /* ------------------------------------------------------------------------------------------
+ * agent_policy = ReplayEgoCarPolicy: the agent replays the SDC track.  In the reference (manager/agent_manager.py:164-187) a replayed
+ * agent gets before_step([0, 0]), rolls through the physics step, has its after_step (localisation, contact test) and is THEN put on
+ * frame k (position, heading, velocity).  Here it is put on frame k in place of the integration: what after_step computes sees the
+ * recorded pose instead of the pose Bullet rolled to from frame k-1 (centimetres apart, and Bullet's to begin with -- unpinned like
+ * every trajectory); the observation and the lidar see frame k as in the reference.  A frame that is not valid,
+ * or past the data, leaves the agent where it is (policy.act returns None).
+ * -----------------------------------------------------------------------------------------*/
+MD_HD void md_scenario_replay_ego(const MdState* s, const MdConfig* c, int a, int k) {
+    MdShape* sh = &s->shape[a];
+    MdDyn* d = &s->dyn[a];
+    s->action[2 * a] = 0.0f;
+    s->action[2 * a + 1] = 0.0f;
+    d->last_x = sh->cx;      /* BaseVehicle.before_step: last_position / last_heading_dir */
+    d->last_y = sh->cy;
+    d->last_c = sh->c;
+    d->last_s = sh->s;
+    d->steering = 0.0f;
+    d->throttle = 0.0f;
+    if (k >= c->track_len) return;
+    const size_t at = (size_t)k * (size_t)c->n_envs * (size_t)c->cap + (size_t)a;
+    const MdShape fr = s->track_shape[at];
+    if (!(fr.flags & MD_F_ALIVE)) return;
+    sh->cx = fr.cx;
+    sh->cy = fr.cy;
+    sh->c = fr.c;
+    sh->s = fr.s;
+    d->heading = s->track_dyn[2 * at];
+    d->speed = s->track_dyn[2 * at + 1];
+}
+
+/* ------------------------------------------------------------------------------------------
  * Traffic lifecycle at the END of episode step k (ScenarioTrafficManager.after_step / after_reset,
  * scenario_traffic_manager.py:89-146,171-296).  Per track slot (1 .. cap-1), in slot order:
  *   REPLAY   pose / velocity from frame k; removed when the frame is not valid or the data are over (cones and
@@ -701,7 +732,7 @@ MD_HD int md_scenario_slot_after_step(const MdWorld* w, const MdState* s, const 
         float rx = fr.cx - ego->cx, ry = fr.cy - ego->cy;
         float heading_dist = rx * ego->c + ry * ego->s;    /* convert_to_local_coordinates: (forward, left) */
         float side_dist = ry * ego->c - rx * ego->s;
-        if (c->filter_overlapping_car && md_fabs(heading_dist) < 8.0f && md_fabs(side_dist) < 2.0f) return 0;
+        if (!c->ego_replay && c->filter_overlapping_car && md_fabs(heading_dist) < 8.0f && md_fabs(side_dist) < 2.0f) return 0;
         const float fr_heading = s->track_dyn[2 * at];
         const int heading_ok = md_fabs(md_wrap_to_pi(s->dyn[0].heading - fr_heading)) < MD_HALF_PI_F;
         const int idm_ok = heading_dist < -1.0f && md_fabs(side_dist) < 15.0f && heading_ok;

@@ -431,6 +431,8 @@ typedef struct MdConfig {
     uint32_t side_mask, ll_mask;    /* which MD_Q_* kinds each detector sees (bit k = kind k), as md_line_detector's kind_mask */
     int32_t route_seg_cap;     /* pieces per slot in MdState.route_segs (>= the longest valid run's frames - 1)          */
     int32_t route_vert_cap;    /* vertices per slot in MdState.route_verts (>= 2 * ceil(longest run's path length + 1) + 4) */
+    int32_t ego_replay;        /* scenario mode, agent_policy = ReplayEgoCarPolicy (policy/replay_policy.py:70-82): the agent is put on
+                                * frame k of the SDC track (MdState.track_* slot 0) instead of being integrated; actions are ignored */
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

@@ -137,7 +137,7 @@ class MdConfig(C.Structure):
         ("step_kernel", C.c_int32),
         ("ma_kind", C.c_int32), ("min_pass_steps", C.c_int32), ("overspeed_penalty", C.c_float), ("n_parking", C.c_int32),
         ("side_range", C.c_float), ("ll_range", C.c_float), ("side_mask", C.c_uint32), ("ll_mask", C.c_uint32),
-        ("route_seg_cap", C.c_int32), ("route_vert_cap", C.c_int32),
+        ("route_seg_cap", C.c_int32), ("route_vert_cap", C.c_int32), ("ego_replay", C.c_int32),
     ]
 
 

@@ -217,7 +217,8 @@ def make_config(user=None):
     pol = cfg["agent_policy"]
     pol = pol if isinstance(pol, str) else getattr(pol, "__name__", repr(pol))
     if pol not in ("EnvInputPolicy", "IDMPolicy"):
-        raise NotImplementedError("agent_policy={!r}: built are EnvInputPolicy (actions from step()) and IDMPolicy".format(pol))
+        raise NotImplementedError("agent_policy={!r}: built are EnvInputPolicy (actions from step()), IDMPolicy and, in "
+                                  "BatchedScenarioEnv only, ReplayEgoCarPolicy".format(pol))
     cfg["agent_policy"] = pol
     if pol == "IDMPolicy" and cfg["is_multi_agent"]:
         raise NotImplementedError("agent_policy=IDMPolicy in a multi-agent env is not built")

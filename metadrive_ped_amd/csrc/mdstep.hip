@@ -2435,7 +2435,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         __syncthreads();
         MD_STAMP_AT(2);
         for (int j = tid; j < cap; j += kBlock) {
-            md_integrate_mover(&s, &c, j);
+            if (c.ego_replay && j < A) md_scenario_replay_ego(&s, &c, j, k);   // agent_policy = ReplayEgoCarPolicy
+            else md_integrate_mover(&s, &c, j);
             l_shape_ct[j] = l_shape[j];   // what the contact test below sees
         }
         __syncthreads();

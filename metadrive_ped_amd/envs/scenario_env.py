@@ -61,6 +61,8 @@ class BatchedScenarioEnv:
         if self.engine is None:
             raise RuntimeError("call reset() before step()")
         torch = self.engine.torch
+        if actions is None and self.config["agent_policy"] == "ReplayEgoCarPolicy":
+            actions = np.zeros((self.num_envs, 2), np.float32)      # the agent replays the SDC track: actions are ignored
         a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
         if a.dim() == 1:
             a = a.unsqueeze(0).expand(self.num_envs, 2)

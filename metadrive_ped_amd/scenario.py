@@ -56,6 +56,13 @@ def make_scenario_config(user=None):
     from metadrive_ped_amd.config import make_config
     user = copy.deepcopy(dict(user or {}))
     sc = copy.deepcopy(SCENARIO_DEFAULT_CONFIG)
+    # agent_policy = ReplayEgoCarPolicy (policy/replay_policy.py:70-82; the reference's own scenario benchmark runs with it,
+    # tests/benchmark_FPS/benchmark_waymo.py): the agent replays the SDC track, step()'s actions are ignored
+    pol = user.get("agent_policy", "EnvInputPolicy")
+    pol = pol if isinstance(pol, str) else getattr(pol, "__name__", repr(pol))
+    ego_replay = pol == "ReplayEgoCarPolicy"
+    if ego_replay:
+        user.pop("agent_policy")
     own = {}
     for k in list(user):
         if k in _ONLY_SCENARIO_KEYS:
@@ -75,6 +82,10 @@ def make_scenario_config(user=None):
     cfg = make_config(base)
     cfg.update(own)
     cfg["scenario_mode"] = True
+    if ego_replay:
+        cfg["agent_policy"] = "ReplayEgoCarPolicy"
+    if cfg["agent_policy"] == "IDMPolicy":
+        raise NotImplementedError("agent_policy=IDMPolicy needs a road network: not in BatchedScenarioEnv (EnvInputPolicy, ReplayEgoCarPolicy)")
     return cfg
 
 
@@ -361,6 +372,15 @@ def _build_scene(job):
             dyn0[n] = d
             meta[n] = (0, int(sc.get("length", own_len)), abi.TM_NEVER, 0)   # [1] = this scene's current_scenario_length
             ck = polys[0].checkpoints()
+            # the SDC's own frames (read only with agent_policy = ReplayEgoCarPolicy)
+            f = fshape[:, 0]
+            f["cx"][valid], f["cy"][valid] = pos[valid, 0], pos[valid, 1]
+            f["c"][valid], f["s"][valid] = np.cos(heading[valid]), np.sin(heading[valid])
+            f["hl"][valid], f["hw"][valid] = length / 2, width / 2
+            f["flags"][valid] = abi.KIND_VEHICLE | abi.F_ALIVE | abi.F_AGENT
+            fshape[:, 0] = f
+            fdyn[valid, 0, 0] = heading[valid]
+            fdyn[valid, 0, 1] = np.hypot(vel[valid, 0], vel[valid, 1])
             continue
         kind = _KIND_OF_TYPE.get(tr["type"])
         if kind is None or run is None or no_traffic:
@@ -594,6 +614,7 @@ class ScenarioHostScene:
             setattr(k, name, int(bool(cfg[name])))
         k.allowed_more_steps = int(cfg["allowed_more_steps"] or 0)
         k.route_seg_cap, k.route_vert_cap = self.route_seg_cap, self.route_vert_cap
+        k.ego_replay = int(cfg["agent_policy"] == "ReplayEgoCarPolicy")
         self.md_config = k
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None
         self.ll_beams = beam_table(self.n_ll, np.pi / 2) if self.n_ll else None

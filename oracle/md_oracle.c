@@ -453,7 +453,10 @@ static void step_env_scenario(const MdWorld* w, const MdState* s, const MdConfig
     if (!just_reset) {
         for (int j = c->agents_per_env; j < c->cap; ++j)
             if (v.nav[j].ck0 == MD_SC_IDM && md_present(v.shape[j].flags)) md_tidm_vehicle(w, &v, c, e, j, k);
-        for (int j = 0; j < c->cap; ++j) md_integrate_mover(&v, c, j);
+        for (int j = 0; j < c->cap; ++j) {
+            if (c->ego_replay && j < c->agents_per_env) md_scenario_replay_ego(&v, c, j, k);
+            else md_integrate_mover(&v, c, j);
+        }
     }
     /* the agent's contact flags come from BaseVehicle.after_step (_state_check: a contact test at the bodies' present poses), which the
      * agent manager runs BEFORE the traffic manager's after_step (same priority, registered first: envs/scenario_env.py:118-126):

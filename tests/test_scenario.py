@@ -708,3 +708,73 @@ def test_spawn_decisions_against_reference_spawn_vehicle():
         assert abs(float(segs["cum"][-1] + segs["len"][-1]) - pol["route_length"]) < 1e-3, where
         n_kind["idm"] += 1
     assert n_kind["none"] > 80 and n_kind["replay"] > 150 and n_kind["idm"] > 40 and n_kind["idm_late"] > 10, n_kind
+
+
+# ------------------------------------------------------------------------------------------------
+# agent_policy = ReplayEgoCarPolicy (policy/replay_policy.py:70-82; tests/benchmark_FPS/benchmark_waymo.py runs with it)
+# ------------------------------------------------------------------------------------------------
+def test_replayed_ego_follows_the_sdc_track_on_the_oracle():
+    E = 6
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=0, auto_reset=False,
+                                    agent_policy="ReplayEgoCarPolicy"))
+    assert cfg["agent_policy"] == "ReplayEgoCarPolicy"
+    scs = synthetic_scenarios(E, 700)
+    host = ScenarioHostScene(cfg, scs)
+    assert host.md_config.ego_replay == 1
+    o = _oracle(host)
+    o.reset()
+    sh = o.state["shape"].reshape(E, host.cap)
+    dy = o.state["dyn"].reshape(E, host.cap)
+    done_at = np.full(E, -1)
+    prev = None
+    for t in range(1, host.T):
+        a = np.random.RandomState(t).uniform(-1, 1, size=(E, 1, 2)).astype(np.float32)      # ignored
+        live = done_at < 0
+        o.step(a)
+        for e in range(E):
+            if not live[e]:
+                continue
+            sdc = scs[e]["tracks"][scs[e]["metadata"]["sdc_id"]]["state"]
+            assert abs(sh["cx"][e, 0] - sdc["position"][t, 0]) < 1e-3 and abs(sh["cy"][e, 0] - sdc["position"][t, 1]) < 1e-3
+            assert abs(dy["heading"][e, 0] - sdc["heading"][t]) < 1e-5
+            assert abs(dy["speed"][e, 0] - np.hypot(*sdc["velocity"][t])) < 1e-4
+            # last actions in the observation: before_step([0, 0]) -> 0.5, 0.5; steering 0 -> 0.5
+            mid = 12
+            assert np.allclose(o.obs[e, mid + 2:mid + 5], 0.5)
+        fl = o.state["flags"].reshape(E, host.cap)[:, 0]
+        ended = (fl & (abi.FL_TERMINATED | abi.FL_TRUNCATED)) != 0
+        done_at[(done_at < 0) & ended] = t
+        if (done_at >= 0).all():
+            break
+    fl = o.state["flags"].reshape(E, host.cap)[:, 0]
+    # the recorded drive completes its own route in most scenes (an episode may end earlier: a replayed neighbour is hit, or
+    # the route's 95 % are reached before the last frame)
+    assert ((fl & abi.FL_ARRIVE_DEST) != 0).sum() >= E // 2
+    assert (o.state["step_info"][:, 6][(fl & abi.FL_ARRIVE_DEST) != 0] > 0.95).all()
+    # no overlap filter with a replayed ego (scenario_traffic_manager.py:188-192): config rejected elsewhere
+    with pytest.raises(NotImplementedError):
+        from metadrive_ped_amd.config import make_config
+        make_config(dict(agent_policy="ReplayEgoCarPolicy"))
+
+
+@pytest.mark.gpu
+def test_replayed_ego_gpu_parity():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.envs.scenario_env import BatchedScenarioEnv
+    E = 16
+    scs = synthetic_scenarios(E, 720)
+    env = BatchedScenarioEnv(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=0, auto_reset=True,
+                                  agent_policy="ReplayEgoCarPolicy", allowed_more_steps=5, truncate_as_terminate=True), scenarios=scs)
+    obs, info = env.reset()
+    host = env.host
+    o = _oracle(host)
+    o.reset()
+    keys = SC_KEYS + ROUTE_KEYS
+    assert_state_equal(env.engine.download_state(), o.state, keys=keys, where="ego replay reset")
+    for t in range(260):
+        obs, rew, term, trunc, info = env.step(None)
+        o.step(np.zeros((E, 1, 2), np.float32))
+        if t % 20 == 0 or t > 250:
+            assert_state_equal(env.engine.download_state(), o.state, keys=keys, where="ego replay step %d" % t)
+    assert np.isfinite(obs.cpu().numpy()).all()
