@@ -114,7 +114,58 @@ def main_marl():
               (cls.__name__ + (" infinite" if extra else ""), steps, E, A, time.time() - t0, int(orc.state["next_agent_id"].mean())), flush=True)
 
 
+def main_scenario():
+    """Scenario mode (BASELINE configs[4]): 192 synthetic scenes of three different lengths, reactive traffic, auto reset; the ego
+    driven by a route follower with excursions, and replayed (agent_policy=ReplayEgoCarPolicy).  Every state array incl. the routes
+    cut on the device is compared every 100 steps."""
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.scenario import ScenarioHostScene, make_scenario_config, synthetic_scenario
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    E = 192
+    scs = [synthetic_scenario(5000 + i, T=(200, 150, 110)[i % 3]) for i in range(E)]
+    keys = ["shape", "dyn", "nav", "pid", "action", "flags", "obs", "reward", "cost", "step_info", "need_reset", "next_agent_id",
+            "route_n", "route_segs", "route_verts", "route_aux", "done_out"]
+    for name, extra in (("scenario", dict()), ("scenario ego replay", dict(agent_policy="ReplayEgoCarPolicy"))):
+        cfg = make_scenario_config(dict(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=0, auto_reset=True,
+                                             allowed_more_steps=20, truncate_as_terminate=True,
+                                             vehicle_config=dict(lidar=dict(num_lasers=240, distance=50))), **extra))
+        host = ScenarioHostScene(cfg, scs)
+        eng = BatchedEngine(cfg, host=host)
+        orc = ob.OracleWorld(host)
+        orc.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+        eng.reset()
+        orc.reset()
+        rng = np.random.RandomState(11)
+        t0 = time.time()
+        cut = 0
+        o_navi = (host.n_side or 2) + 6 + 1
+        for t in range(steps):
+            obs = orc.obs
+            a = np.zeros((E, 1, 2), np.float32)
+            a[:, 0, 0] = np.clip(6.0 * (obs[:, o_navi + 19] - 0.5) + 2.0 * (obs[:, o_navi + 18] - 0.5), -1, 1)
+            a[:, 0, 1] = 0.35 if (t // 70) % 3 else -0.5
+            a[::7, 0, 0] += 0.5 * np.sin(t * 0.04)
+            a[:, 0, 0] += rng.uniform(-0.05, 0.05, E)
+            before = orc.state["route_n"][:, 2].copy()
+            eng.step(torch.from_numpy(a).to(eng.device))
+            orc.step(a, threads=8)
+            rn = orc.state["route_n"]
+            cut += int(((rn[:, 0] > 0) & (rn[:, 2] != before)).sum())
+            if (t + 1) % 100 == 0:
+                assert_state_equal(eng.download_state(), orc.state, keys=keys, where="%s step %d" % (name, t + 1))
+        print("%-20s %d steps x %d scenes bit-exact (%.0f s, %d routes cut at a later spawn frame)" % (name, steps, E, time.time() - t0, cut), flush=True)
+
+
 if __name__ == "__main__":
-    if not os.environ.get("SOAK_ONLY"):
-        main()
-    main_marl()
+    only = os.environ.get("SOAK_ONLY", "")
+    if only == "scenario":
+        main_scenario()
+    else:
+        if not only:
+            main()
+        main_marl()
+        if not only:
+            main_scenario()
