@@ -286,10 +286,21 @@ def main():
     if tracks is not None:
         eng.set_tracks(tracks)
     if world > 1:
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # the communication libraries print connection notes on fd 1 ("[Gloo] Rank 0 is connected to ..."): stdout of this
+        # program is the ONE JSON line, so fd 1 points at stderr while the process group comes up (and for the first collective)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearse:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     dev = eng.device
     A, cap, B = eng.A, eng.cap, eng.n_beams
 
