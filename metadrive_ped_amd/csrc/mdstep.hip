@@ -267,12 +267,19 @@ __device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& m
     }
     const bool uniform_fan = __ballot(!fan_ok) == 0ull && n_beams >= 4;
     int cnt = 0;   // wave-uniform
+    // the 16-byte records of the NEXT 64 quads are requested before this round's are worked on: the rounds are a dependent chain
+    // (ballot, pair list), and a cold fetch per round was most of the phase
+    QuadBall nb;
+    nb.mx = nb.my = nb.rr = 0.0f;
+    nb.kind = 0;
+    if (qa + lane_id < qb) nb = quad_ball_of(w, qa + lane_id);
     for (int q0 = qa; q0 < qb; q0 += 64) {
         const int q = q0 + lane_id;
         bool near = false;
         float px = 0.0f, py = 0.0f, rr = 0.0f;
+        const QuadBall b = nb;
+        if (q + 64 < qb) nb = quad_ball_of(w, q + 64);
         if (q < qb) {
-            const QuadBall b = quad_ball_of(w, q);
             px = b.mx - me.cx;
             py = b.my - me.cy;
             rr = b.rr;
