@@ -76,6 +76,28 @@ class BatchedScenarioEnv:
         return self.engine.obs[:, 0, :], self.engine.reward[:, 0], (fl & abi.FL_TERMINATED) != 0, (fl & abi.FL_TRUNCATED) != 0, \
             self._info()
 
+    # -- checkpoints (envs/base_env.py:775-836 get_state / set_state through the managers): a dict of numpy arrays; the routes the
+    #    device cut at later spawn frames are state too and travel with it -----------------------------------------------------
+    def get_state(self):
+        if self.engine is None:
+            raise RuntimeError("call reset() before get_state()")
+        st = self.engine.download_state()
+        st["__seeds__"] = np.asarray(self.engine.host.seeds, dtype=np.int64)
+        return st
+
+    def set_state(self, state):
+        if self.engine is None:
+            raise RuntimeError("call reset() before set_state()")
+        if np.asarray(state["__seeds__"]).tolist() != list(self.engine.host.seeds):
+            raise ValueError("the checkpoint was taken with another scenario assignment (start_scenario_index / num_scenarios / "
+                             "env_seed_offset differ): tracks and routes would not match")
+        arrays = {k: v for k, v in state.items() if k != "__seeds__"}
+        ref = self.engine.host.state
+        for k, v in arrays.items():
+            if k not in ref or np.asarray(v).nbytes != ref[k].nbytes:
+                raise ValueError("checkpoint array {!r} does not fit this batch".format(k))
+        self.engine.upload_state(arrays)
+
     def _info(self):
         e = self.engine
         fl = e.flags[:, 0]

@@ -778,3 +778,35 @@ def test_replayed_ego_gpu_parity():
         if t % 20 == 0 or t > 250:
             assert_state_equal(env.engine.download_state(), o.state, keys=keys, where="ego replay step %d" % t)
     assert np.isfinite(obs.cpu().numpy()).all()
+
+
+@pytest.mark.gpu
+def test_scenario_checkpoint_resumes_bit_identically():
+    """get_state / set_state of BatchedScenarioEnv: a checkpoint taken after the device has cut routes replays the same future."""
+    import torch
+    from metadrive_ped_amd.envs.scenario_env import BatchedScenarioEnv
+    E = 16
+    env = BatchedScenarioEnv(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=0, auto_reset=True),
+                             scenarios=synthetic_scenarios(E, 300))
+    obs, _ = env.reset()
+    def act(o, t):
+        return torch.from_numpy(_follow(o.cpu().numpy(), throttle=0.35 if (t // 50) % 2 == 0 else -0.3)[:, 0]).cuda()
+    for t in range(160):
+        obs, *_ = env.step(act(obs, t))
+    ck = env.get_state()
+    assert (ck["route_n"][:, 0] > 0).any()          # some vehicle follows a route cut at its spawn frame
+    o0 = obs.clone()
+    first = []
+    for t in range(160, 260):
+        obs, r, term, trunc, _ = env.step(act(obs, t))
+        first.append((obs.cpu().numpy().copy(), r.cpu().numpy().copy(), term.cpu().numpy().copy()))
+    env.set_state(ck)
+    obs = o0
+    for i, t in enumerate(range(160, 260)):
+        obs, r, term, trunc, _ = env.step(act(obs, t))
+        assert obs.cpu().numpy().tobytes() == first[i][0].tobytes(), "obs diverged at step %d" % t
+        assert r.cpu().numpy().tobytes() == first[i][1].tobytes() and (term.cpu().numpy() == first[i][2]).all()
+    bad = dict(ck)
+    bad["__seeds__"] = ck["__seeds__"] + 1
+    with pytest.raises(ValueError):
+        env.set_state(bad)
