@@ -136,15 +136,34 @@ def build_fast_oracle():
     return out
 
 
-def load_or_build_hosts(path, build):
+def host_cache_key(args, rank, world):
+    """What a cached set of host scenes was built for: ABI, workload, sizes, rank, and the sources that shape the tables."""
+    import hashlib
+    from metadrive_ped_amd import abi
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "metadrive_ped_amd")
+    for rel in ("abi.py", "engine.py", "scene.py", "scenario.py", "marl.py", "config.py", "pg_space.py", "rng.py",
+                os.path.join("mapgen", "pg.py"), os.path.join("mapgen", "tables.py"), os.path.join("mapgen", "lanes.py")):
+        with open(os.path.join(pkg, rel), "rb") as fh:
+            h.update(fh.read())
+    return dict(abi=abi.MD_ABI_VERSION, workload=args.workload, envs=args.envs, cap=args.cap, sub=args.sub_batches, rank=rank,
+                world=world, cpu=(args.cpu_envs, bool(args.no_cpu_baseline)), src=h.hexdigest()[:16])
+
+
+def load_or_build_hosts(path, build, key):
+    """--host-cache: our own pickle of the host scenes, valid only for the key it was written with (a stale one is rebuilt)."""
     if path and os.path.exists(path):
         with open(path, "rb") as fh:   # our own file, written by the branch below
-            return pickle.load(fh)
+            blob = pickle.load(fh)
+        if isinstance(blob, dict) and blob.get("key") == key:
+            return blob["hosts"]
+        print("bench.py: host cache %s was built for %r, not %r: rebuilding" % (path, blob.get("key") if isinstance(blob, dict) else None, key),
+              file=sys.stderr)
     hosts = build()
     if path:
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, "wb") as fh:
-            pickle.dump(hosts, fh, protocol=4)
+            pickle.dump(dict(key=key, hosts=hosts), fh, protocol=4)
     return hosts
 
 
@@ -171,6 +190,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         # every rank builds its own 4096 maps: share the host cores
         os.environ.setdefault("MD_BUILD_WORKERS", str(max(1, min(32, (os.cpu_count() or 8) // world))))
+    # the host build workers first: plain child interpreters, started while this process has no GPU context, kept to the end
+    from metadrive_ped_amd import hostpool
+    if not (args.host_cache and os.path.exists(args.host_cache)):
+        hostpool.start()
     import torch
     import torch.distributed as dist
     from metadrive_ped_amd.config import make_config
@@ -178,7 +201,8 @@ def main():
 
     E = args.envs
     common = dict(num_envs=E, num_scenarios=E * max(world, 1), env_seed_offset=rank * E, start_seed=0,
-                  mover_capacity=args.cap, auto_reset=True, device="cuda:%d" % local_rank)
+                  mover_capacity=args.cap, auto_reset=True, device="cuda:%d" % local_rank,
+                  build_cache=True)   # the sub-batch leg and the CPU baseline step the same scenario seeds: built once
     env_cls = None
     if args.workload == "metadrive":
         user = dict(common, map=3, traffic_density=0.1, horizon=1000)
@@ -254,7 +278,8 @@ def main():
                 h[key] = HostScene(c)
         return h
 
-    hosts = load_or_build_hosts(args.host_cache, build_hosts)
+    hosts = load_or_build_hosts(args.host_cache, build_hosts, host_cache_key(args, rank, world))
+    hostpool.clear_memo()
     host = hosts["main"]
     cpu_lib = build_fast_oracle() if want_cpu else None
     build_s = time.time() - t0

@@ -112,7 +112,8 @@ BATCH_DEFAULT_CONFIG = dict(
     mover_capacity=0,       # slots per env (agents + traffic + props); 0 = smallest multiple of 8 that fits every env
     auto_reset=True,        # restore an env from its reset snapshot on the step after it finished
     device="cuda:0",
-    build_workers=0,        # host processes used to generate maps at reset (0 = all cores, capped at 32)
+    build_workers=0,        # 1 = generate maps in this process; otherwise the persistent workers of hostpool.py do it
+    build_cache=False,      # memoise built (map, scene) pairs by scenario seed + config (sub-batches / copies of the same envs)
     traffic_epoch=0,        # random_traffic=True: bumped by every explicit env.reset(); part of the traffic stream's seed
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
     step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from metadrive_ped_amd import abi
+from metadrive_ped_amd import abi, hostpool
 from metadrive_ped_amd.mapgen.pg import PGMap
 from metadrive_ped_amd.mapgen.tables import MapTables, WorldTables, beam_table
 from metadrive_ped_amd.scene import EnvScene
@@ -153,17 +153,12 @@ class HostScene:
                          random_traffic=cfg["random_traffic"], traffic_epoch=cfg.get("traffic_epoch", 0),
                          destination=cfg["vehicle_config"]["destination"])
         self.spawn = None
+        if not cfg["is_multi_agent"]:
+            scene_cfg["cap"] = abi.MD_MAX_CAP
         jobs = [(s, dict(mc), cfg["block_dist_config"], scene_cfg) for s in uniq]
-        workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
-        try:
-            # a process that has initialised the GPU must not fork (the children inherit a HIP runtime they cannot use,
-            # and under rocprofv3 the profiler's handlers): build serially then.  Callers that want the pool build the
-            # HostScene first (bench.py, SubBatchedEnvs.build_host) or pass a HostScene made elsewhere.
-            import torch
-            if torch.cuda.is_initialized():
-                workers = 1
-        except ImportError:
-            pass
+        # reset-time host work goes to the persistent build workers (metadrive_ped_amd/hostpool.py): they are started before
+        # this process touches the GPU and kept; a process that already has a GPU context and no workers builds serially
+        # (it must not fork).  build_workers = 1 forces the serial path.
         shared_map = cfg["is_multi_agent"] and cfg["marl_map"] != "pg"
         build_fn = _build_one
         if cfg["is_multi_agent"] and not cfg["mover_capacity"]:
@@ -179,20 +174,8 @@ class HostScene:
         if shared_map:
             mt, marl_scenes, self.spawn = _build_marl(cfg, scene_cfg, uniq)
             built = [(mt, marl_scenes[s]) for s in uniq]
-        elif len(jobs) >= 64 and workers > 1:
-            # reset-time host work only; fork BEFORE this process has touched the GPU (HostScene is built
-            # ahead of the first device allocation in BatchedEngine.build)
-            import multiprocessing as mp
-            # close + join, not the context manager's terminate(): under rocprofv3 --pmc the profiler's signal
-            # handler rides along into the forked workers and a SIGTERM there can hang the whole run
-            pool = mp.get_context("fork").Pool(workers)
-            try:
-                built = pool.map(build_fn, jobs, chunksize=max(1, len(jobs) // (workers * 4)))
-            finally:
-                pool.close()
-                pool.join()
         else:
-            built = [build_fn(j) for j in jobs]
+            built = hostpool.build_all(build_fn, jobs, workers=int(cfg.get("build_workers", 0)), cache=bool(cfg.get("build_cache", False)))
         for s, (mt, sc) in zip(uniq, built):
             if shared_map:
                 map_of_seed[s] = 0
@@ -202,9 +185,14 @@ class HostScene:
                 map_of_seed[s] = len(tables)
                 tables.append(mt)
             scenes[s] = sc
-        if not cfg["mover_capacity"] and not cfg["is_multi_agent"]:
+        if not cfg["is_multi_agent"]:
+            # single-agent scenes are always generated with the maximum slot count and cut to size here (vehicles keep their
+            # low slots, props the top ones: the same arrays as a build at that size), so that one built scene serves every
+            # capacity -- the build memo keys on the job
             need = max(A + sc.n_traffic + sc.n_props for sc in scenes.values())
-            cap = min(abi.MD_MAX_CAP, max(8, (need + 7) // 8 * 8))
+            cap = cfg["mover_capacity"] or min(abi.MD_MAX_CAP, max(8, (need + 7) // 8 * 8))
+            if need > cap:
+                raise ValueError("more than cap={} movers in an env ({}); raise `mover_capacity`".format(cap, need))
             for sc in scenes.values():
                 sc.trim(cap)
             self.cap = cap

@@ -513,23 +513,8 @@ class ScenarioHostScene:
         # scene behaves the same in whatever batch (slot, shard) it is loaded
         jobs = [(e, scenarios[e], cap, T, int(scenarios[e]["metadata"].get("seed", self.seeds[e])), dt, bool(cfg["no_traffic"]),
                  float(cfg["map_region_size"])) for e in range(E)]
-        workers = int(cfg.get("build_workers", 0)) or int(os.environ.get("MD_BUILD_WORKERS", "0")) or min(os.cpu_count() or 1, 32)
-        try:
-            import torch
-            if torch.cuda.is_initialized():
-                workers = 1          # never fork a process that has initialised the GPU (see HostScene)
-        except ImportError:
-            pass
-        if E >= 64 and workers > 1:
-            import multiprocessing as mp
-            pool = mp.get_context("fork").Pool(workers)
-            try:
-                built = pool.map(_build_scene, jobs, chunksize=max(1, E // (workers * 4)))
-            finally:
-                pool.close()
-                pool.join()
-        else:
-            built = [_build_scene(j) for j in jobs]
+        from metadrive_ped_amd import hostpool
+        built = hostpool.build_all(_build_scene, jobs, workers=int(cfg.get("build_workers", 0)))
         shape0 = np.concatenate([b_["shape0"] for b_ in built])
         dyn0 = np.concatenate([b_["dyn0"] for b_ in built])
         param = np.concatenate([b_["param"] for b_ in built])

@@ -11,6 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the host build workers must exist before the first test makes a GPU context (a process with one never forks):
+    # every HostScene of the session is then built by them
+    from metadrive_ped_amd import hostpool
+    hostpool.start()
+
+
+def pytest_unconfigure(config):
+    from metadrive_ped_amd import hostpool
+    hostpool.stop()
 
 
 @pytest.fixture(scope="session")

@@ -2,7 +2,7 @@
 # A/B of library builds on the bench workload: bash tools/ab/run.sh <out> lib1.so lib2.so ...
 OUT=$1; shift
 mkdir -p $OUT
-CACHE=/tmp/md_host_cache_ab.pkl
+CACHE=$OUT/host_cache.pkl
 LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --host-cache $CACHE"
 python bench.py --steps 100 --warmup 10 $LEAN > $OUT/base.json 2> $OUT/base.err || { tail -5 $OUT/base.err; exit 1; }
 python - <<PY

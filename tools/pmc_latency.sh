@@ -11,7 +11,7 @@ export MD_STEP_KERNEL=${2:-wg}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CACHE=/tmp/md_host_cache_$TAG.pkl
+CACHE=$OUT/host_cache.pkl
 LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --host-cache $CACHE"
 rocprofv3 -L > $OUT/avail.txt 2>&1 || true
 python bench.py --steps 20 --warmup 5 $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err
