@@ -30,7 +30,7 @@ Extra objects in the JSON line:
                host cores, bounded sample
   env_api      the same steps through BatchedMetaDriveEnv.step (the Gymnasium-shaped boundary: done flags,
                lazy info dict)
-  with_gather  (N>1) the same K steps followed by an RCCL all_gather of (obs, reward)
+  with_gather  (N>1) the same steps, each followed by ONE RCCL all_gather of the packed slab obs | reward | done+flags
 """
 import argparse
 import json
@@ -547,29 +547,44 @@ def main():
                                     "its own HIP stream; no cross-stream wait inside the timed region" % E)
         sub.close()
 
-    # ---- optional gather (N>1): obs + reward + flags to every rank over RCCL ----
+    # ---- gather leg (N>1): the rank's whole step output -- obs | reward | terminated, truncated, flags, one allocation
+    #      (BatchedEngine.out_slab) -- to every rank with ONE RCCL collective per step, timed over the same number of steps
+    #      as the main leg (>= MIN_TIMED_S) ----
     with_gather = None
     if world > 1:
-        obs_g = torch.empty(world * E * A * eng.obs_dim, device=dev)
-        rew_g = torch.empty(world * E * A, device=dev)
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            eng.step(actions[i % n_act])
-            if rehearse:   # gloo: host copies stand in for the RCCL gather
-                o_cpu, r_cpu = eng.obs.reshape(-1).cpu(), eng.reward.reshape(-1).cpu()
-                dist.all_gather([torch.empty_like(o_cpu) for _ in range(world)], o_cpu)
-                dist.all_gather([torch.empty_like(r_cpu) for _ in range(world)], r_cpu)
+        from metadrive_ped_amd.sharding import gather_step_slab
+        slab = eng.out_slab
+        gathered = torch.empty((world, slab.numel()), dtype=torch.uint8, device="cpu" if rehearse else dev)
+        cpu_slab = torch.empty(slab.numel(), dtype=torch.uint8).pin_memory() if rehearse else None
+
+        def gather_once():
+            if rehearse:          # gloo rehearsal on one GPU: a host copy stands in for the device-side RCCL gather
+                cpu_slab.copy_(slab)
+                gather_step_slab(cpu_slab, out=gathered)
             else:
-                dist.all_gather_into_tensor(obs_g, eng.obs.reshape(-1))
-                dist.all_gather_into_tensor(rew_g, eng.reward.reshape(-1))
+                gather_step_slab(slab, out=gathered)
+        for i in range(min(args.warmup, 5)):
+            eng.step(actions[i % n_act])
+            gather_once()
         torch.cuda.synchronize()
         barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(timed_steps):
+            eng.step(actions[i % n_act])
+            gather_once()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
         eg = torch.tensor([time.perf_counter() - t0], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(eg, op=dist.ReduceOp.MAX)
-        with_gather = dict(value=round(args.steps * E * A * world * active_frac / float(eg.item()), 1), unit="agent-steps/s",
-                           collective="all_gather_into_tensor(obs,reward)")
+        dt_g = float(eg.item())
+        with_gather = dict(value=round(timed_steps * E * A * world * active_frac / dt_g, 1), unit="agent-steps/s",
+                           ms_per_step=round(dt_g / timed_steps * 1e3, 4), steps=timed_steps,
+                           replicas_only_ms_per_step=round(ms_per_step, 4),
+                           collective="one all_gather_into_tensor per step of the packed slab obs | reward | (terminated, truncated, flags)",
+                           bytes_per_rank_per_step=int(slab.numel()), bytes_gathered_per_step=int(slab.numel()) * world,
+                           backend="gloo (one-GPU rehearsal, host copies)" if rehearse else "nccl (RCCL)")
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) ----
     cpu_baseline = None

@@ -47,7 +47,7 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.nav0 = g->nav0 ? g->nav0 + b : 0;
     v.pid0 = g->pid0 ? g->pid0 + b : 0;
     v.param0 = g->param0 ? g->param0 + b : 0;
-    v.done_out = g->done_out ? g->done_out + 2 * a : 0;
+    v.done_out = g->done_out ? g->done_out + 4 * a : 0;
     v.route_nodes0 = g->route_nodes0 ? g->route_nodes0 + b * MD_ROUTE_LEN : 0;
     v.route_roads0 = g->route_roads0 ? g->route_roads0 + b * MD_ROUTE_LEN : 0;
     v.final_lane0 = g->final_lane0 ? g->final_lane0 + b : 0;
@@ -81,6 +81,10 @@ MD_HD int md_obs_others(const MdConfig* c) { return md_obs_navi(c) + md_navi_dim
 MD_HD int md_others_width(const MdConfig* c) { return c->add_others_navi ? 8 : 4; }
 MD_HD int md_obs_lidar(const MdConfig* c) { return md_obs_others(c) + (c->num_others > 0 ? c->num_others * md_others_width(c) : 0); }
 
+/* MdState.done_out word of an agent: terminated | truncated << 8 | flag word << 16 */
+MD_HD uint32_t md_done_word(uint32_t fl) {
+    return ((fl & MD_FL_TERMINATED) ? 1u : 0u) | ((fl & MD_FL_TRUNCATED) ? 0x100u : 0u) | ((fl & 0xFFFFu) << 16);
+}
 MD_HD int md_kind_of(int flags) { return flags & MD_KIND_MASK; }
 MD_HD int md_is_circle_kind(int k) { return k == MD_KIND_CONE || k == MD_KIND_WARNING || k == MD_KIND_PEDESTRIAN; }
 /* present: has a body in the world (seen by lidar, can be hit).  Traffic spawned for a block that
@@ -270,7 +274,7 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     const int o_mid = md_obs_mid(c), o_ll = md_obs_ll(c), o_navi = md_obs_navi(c);
     const int toll = md_is_tollgate(c);
     if (!k->valid) {
-        if (s->done_out) s->done_out[2 * ai] = s->done_out[2 * ai + 1] = 0;
+        if (s->done_out) ((uint32_t*)s->done_out)[ai] = 0u;
         for (int i = 0; i < md_obs_lidar(c); ++i) obs[i] = 0.0f;
         for (int i = c->obs_dim - md_obs_tail(c); i < c->obs_dim; ++i) obs[i] = 0.0f;
         s->reward[ai] = 0.0f;
@@ -405,10 +409,7 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     s->flags[n] = fl;
     s->reward[ai] = reward;
     s->cost[ai] = cost;
-    if (s->done_out) {
-        s->done_out[2 * ai] = (fl & MD_FL_TERMINATED) != 0;
-        s->done_out[2 * ai + 1] = (fl & MD_FL_TRUNCATED) != 0;
-    }
+    if (s->done_out) ((uint32_t*)s->done_out)[ai] = md_done_word(fl);
     if (toll) {
         /* TollGateObservation.observe (marl_tollgate.py:96-110): the counter runs on every observation made inside the block */
         int t = nav->toll_state & 0xffffff, last = (nav->toll_state >> 24) & 0xff;

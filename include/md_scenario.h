@@ -315,10 +315,7 @@ MD_HD void md_scenario_observe_at(const MdWorld* w, const MdState* s, const MdCo
         if (max_step) fl |= MD_FL_TRUNCATED;
     }
     s->flags[n] = fl;
-    if (s->done_out) {
-        s->done_out[2 * a] = (fl & MD_FL_TERMINATED) != 0;
-        s->done_out[2 * a + 1] = (fl & MD_FL_TRUNCATED) != 0;
-    }
+    if (s->done_out) ((uint32_t*)s->done_out)[a] = md_done_word(fl);
     s->reward[a] = reward;
     s->cost[a] = cost;
     float step_energy = just_reset ? 0.0f : md_step_energy(speed_kmh, md_norm(d->last_x - sh->cx, d->last_y - sh->cy));

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 9
+#define MD_ABI_VERSION 10
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -345,9 +345,13 @@ typedef struct MdState {
      * caller like every other array; contents are meaningless between calls.  NULL = that mode is not available. */
     uint32_t* scratch;
     const MdParam* param0;     /* reset snapshot of `param` (multi-agent + random_agent_model only; NULL otherwise) */
-    /* optional: [n_envs * agents_per_env][2] bytes = (terminated, truncated) of the step, i.e. the MD_FL_TERMINATED /
-     * MD_FL_TRUNCATED bits of the agent's flag word as the two booleans step() returns (envs/base_env.py:586-612),
-     * so that the caller needs no kernel of its own to extract them */
+    /* optional: [n_envs * agents_per_env] 4-byte words, one per agent, written with ONE store (ABI v10; v9 held two bytes):
+     *   byte 0 = terminated, byte 1 = truncated -- the MD_FL_TERMINATED / MD_FL_TRUNCATED bits of the agent's flag word as the
+     *            two booleans step() returns (envs/base_env.py:586-612), so that the caller needs no kernel to extract them;
+     *   bytes 2-3 = the agent's whole step flag word MD_FL_* (all sixteen bits: crash_*, on-line, out_of_road, arrive_dest,
+     *            max_step ...), little endian -- what `info` reports.
+     * Together with obs and reward this is everything a learner acts on; a caller that lays obs | reward | done_out out in one
+     * allocation gathers a rank's whole step output with one collective (metadrive_ped_amd/sharding.py). */
     uint8_t* done_out;
     /* scenario mode, optional (all four or none; needs MdWorld.run_off / runs and MdConfig.route_seg_cap / route_vert_cap):
      * routes built on the device when a track is (re)spawned with a reactive policy at a frame k that is not the start of its

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 9
+MD_ABI_VERSION = 10
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024

@@ -236,7 +236,7 @@ class HostScene:
         st["reward"] = np.zeros(E * A, np.float32)
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
-        st["done_out"] = np.zeros((E * A, 2), np.uint8)          # (terminated, truncated) straight from the kernel
+        st["done_out"] = np.zeros((E * A, 4), np.uint8)          # (terminated, truncated, flag word lo / hi) straight from the kernel
         st["need_reset"] = np.ones(E, np.int32)
         st["scratch"] = np.zeros(2 * N + 4 * E, np.uint32)      # work space of the phase-per-launch step kernels
         self.traffic_respawns = "spawn_off" in self.world.arrays and not cfg["is_multi_agent"]
@@ -376,6 +376,7 @@ class BatchedEngine:
         self.n_beams, self.obs_dim = h.n_beams, h.obs_dim
         self.world_dev = {k: self._to_dev(v) for k, v in h.world.arrays.items()}
         self.state_dev = {k: self._to_dev(v) for k, v in h.state.items()}
+        self._pack_step_outputs()
         ptr = lambda t: t.data_ptr()
         wd = dict(self.world_dev)
         wd["lane_off_host"], wd["road_off_host"] = h.world.arrays["lane_off"], h.world.arrays["road_off"]
@@ -404,7 +405,8 @@ class BatchedEngine:
         self.flags = sd["flags"].view(torch.int32).view(self.E, self.cap)
         self.action = sd["action"].view(torch.float32).view(self.E, self.cap, 2)
         self.step_info = sd["step_info"].view(torch.float32).view(self.E, self.A, 8)
-        self.done_tt = sd["done_out"].view(torch.bool).view(self.E, self.A, 2) if "done_out" in sd else None
+        self.done_tt = sd["done_out"].view(torch.bool).view(self.E, self.A, 4)[:, :, 0:2] if "done_out" in sd else None
+        self.step_flags = sd["done_out"].view(torch.int16).view(self.E, self.A, 2)[:, :, 1] if "done_out" in sd else None   # MD_FL_* of the step
         self.need_reset = sd["need_reset"].view(torch.int32)
         self.shape_f = sd["shape"].view(torch.float32).view(self.E, self.cap, 8)
         self.dyn_f = sd["dyn"].view(torch.float32).view(self.E, self.cap, 8)
@@ -414,6 +416,25 @@ class BatchedEngine:
             tr = h.tracks
             self.set_tracks(dict(shape=torch.from_numpy(np.ascontiguousarray(tr["shape"]).view(np.uint8).reshape(tr["shape"].shape[0], -1)),
                                  dyn=torch.from_numpy(np.ascontiguousarray(tr["dyn"])), seeds=tr["seeds"], cap=tr["cap"]))
+
+    def _pack_step_outputs(self):
+        """obs | reward | done_out (terminated, truncated, step flags) of this rank in ONE allocation, in that order, each part
+        16-byte aligned: the kernel writes the three arrays where it always did, and the whole step output of the shard is one
+        contiguous slab -- the single collective of SURVEY 8(e) (sharding.gather_step_slab) moves it as it lies."""
+        torch = self.torch
+        sd = self.state_dev
+        names = [k for k in ("obs", "reward", "done_out") if k in sd]
+        layout, at = {}, 0
+        for k in names:
+            layout[k] = (at, sd[k].numel())
+            at = (at + sd[k].numel() + 15) // 16 * 16
+        slab = torch.zeros(at, dtype=torch.uint8, device=self.device)
+        for k in names:
+            o, n = layout[k]
+            view = slab[o:o + n]
+            view.copy_(sd[k])
+            sd[k] = view
+        self.out_slab, self.out_layout = slab, layout
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)

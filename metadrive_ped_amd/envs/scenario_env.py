@@ -83,15 +83,22 @@ class BatchedScenarioEnv:
             raise RuntimeError("call reset() before get_state()")
         st = self.engine.download_state()
         st["__seeds__"] = np.asarray(self.engine.host.seeds, dtype=np.int64)
+        st["__scenario_ids__"] = np.asarray(self.engine.host.scenario_ids)
+        st["__abi__"] = np.asarray([abi.MD_ABI_VERSION], dtype=np.int64)
         return st
 
     def set_state(self, state):
         if self.engine is None:
             raise RuntimeError("call reset() before set_state()")
+        if "__abi__" in state and int(np.asarray(state["__abi__"])[0]) != abi.MD_ABI_VERSION:
+            raise ValueError("the checkpoint was written by ABI v{}, this library is v{}: the record layouts differ".format(
+                int(np.asarray(state["__abi__"])[0]), abi.MD_ABI_VERSION))
         if np.asarray(state["__seeds__"]).tolist() != list(self.engine.host.seeds):
             raise ValueError("the checkpoint was taken with another scenario assignment (start_scenario_index / num_scenarios / "
                              "env_seed_offset differ): tracks and routes would not match")
-        arrays = {k: v for k, v in state.items() if k != "__seeds__"}
+        if "__scenario_ids__" in state and [str(x) for x in np.asarray(state["__scenario_ids__"]).tolist()] != list(self.engine.host.scenario_ids):
+            raise ValueError("the checkpoint was taken on other scenarios (their ids differ): tracks and routes would not match")
+        arrays = {k: v for k, v in state.items() if not k.startswith("__")}
         ref = self.engine.host.state
         for k, v in arrays.items():
             if k not in ref or np.asarray(v).nbytes != ref[k].nbytes:

@@ -502,7 +502,12 @@ class ScenarioHostScene:
         self.state_dim = (self.n_side or 2) + 6 + (self.n_ll or 1) + 22
         self.num_others, self.add_others_navi, self.others_dim = 0, False, 0
         self.obs_dim = self.state_dim + self.n_beams
-        self.seeds = [int(cfg["start_seed"]) + ((cfg["env_seed_offset"] + e) % max(1, cfg["num_scenarios"])) for e in range(E)]
+        # scene e <-> dataset index start_scenario_index + (env_seed_offset + e) % num_scenarios (scenario_data.scenario_indices):
+        # the identity checkpoints and track sets are checked against, and the fallback parameter seed of a description that
+        # carries none -- tied to WHICH scenario it is, not to where it sits in the batch
+        from metadrive_ped_amd.scenario_data import scenario_indices
+        self.seeds = scenario_indices(cfg, E)
+        self.scenario_ids = [str(sc.get("id", sc.get("metadata", {}).get("scenario_id", i))) for sc, i in zip(scenarios, self.seeds)]
         self.spawn = None
         self.traffic_respawns = False
         self.scenes, self.map_tables = {}, []
@@ -575,7 +580,7 @@ class ScenarioHostScene:
         st["reward"] = np.zeros(E * A, np.float32)
         st["cost"] = np.zeros(E * A, np.float32)
         st["step_info"] = np.zeros((E * A, 8), np.float32)
-        st["done_out"] = np.zeros((E * A, 2), np.uint8)
+        st["done_out"] = np.zeros((E * A, 4), np.uint8)
         st["need_reset"] = np.ones(E, np.int32)
         st["next_agent_id"] = np.zeros(E, np.int32)     # ScenarioTrafficManager.idm_policy_count
         if cfg["reactive_traffic"]:

@@ -14,10 +14,11 @@ Restates the reset chain of the reference in manager PRIORITY order (engine/base
 Vehicle parameters come from the vehicle's own stream (first sample_parameters draw after seeding:
 component/vehicle/base_vehicle.py:296-303), including the BoxSpace(max,min) quirk.
 
-Pinned by fixtures: map topology per seed (tests/golden/pg_maps.json).  The order in which the
-engine / manager streams are consumed by spawn_object and add_policy is restated from the code
-above; the reference cannot spawn vehicles without Bullet, so the traffic placement stream is
-parity-unpinned (documented in DESIGN.md).
+Pinned by fixtures: map topology per seed (tests/golden/pg_maps*.json); the traffic placement per seed -- which lane,
+longitude, vehicle class, vehicle seed and sampled parameters, policy seed, trigger block, and where the engine and
+traffic streams stand afterwards -- by tests/golden/traffic_spawn.json: the reference's own PGTrafficManager.reset in
+the trigger / respawn / hybrid modes with spawn_object replaced by a recorder that draws the engine seed exactly as
+BaseEngine.spawn_object does (oracle/gen/gen_golden.py: section_traffic_spawn; tests/test_oracle_golden.py).
 """
 import math
 
@@ -34,6 +35,13 @@ VEHICLE_GAP = 10  # PGTrafficManager.VEHICLE_GAP
 GRAVITY = 9.8
 TRAFFIC_TYPE_KEYS = ["s", "m", "l", "xl", "default"]  # vehicle_type.py:269-275 (dict order)
 TRAFFIC_TYPE_P = [0.2, 0.3, 0.3, 0.2, 0.0]            # traffic_manager.py:298-301
+
+
+def _peek(rng):
+    """The next rand() of a RandomState without advancing it."""
+    r = np.random.RandomState()
+    r.set_state(rng.get_state())
+    return float(r.rand())
 
 
 def vehicle_param_record(vtype, vehicle_seed, substep_dt, overrides=None):
@@ -223,6 +231,9 @@ class EnvScene:
                     self.idm_rand[slot] = [int(prng.randint(0, 25)) for _ in range(abi.MD_IDM_RAND)]
                     slot += 1
         self.n_traffic = slot - A
+        # where the two streams stand after the reset chain (copies: nothing is consumed) -- what the golden fixture of the
+        # reference's PGTrafficManager.reset ends with (tests/golden/traffic_spawn.json)
+        self.stream_probe = dict(engine=_peek(engine.np_random), traffic=_peek(traffic_mgr.np_random))
 
     @property
     def n_props(self):

@@ -1435,6 +1435,104 @@ def section_scenario_spawn():
     dump("scenario_spawn.json", dict(supplied_by_generator=["convert_to_local_coordinates (forward, left)"], frames=T, cases=cases))
 
 
+def _cls_const(cls, name):
+    """Class constant of a vehicle class; LENGTH / WIDTH are properties returning a literal (vehicle_type.py:155-165)."""
+    v = getattr(cls, name)
+    return v.fget(None) if isinstance(v, property) else v
+
+
+def section_traffic_spawn():
+    """Per-seed traffic placement: the reference's own PGTrafficManager.reset
+    (manager/traffic_manager.py:51-72) -> _create_vehicles_once (:230-277) / _create_respawn_vehicles (:213-228) /
+    _propose_vehicle_configs (:201-211) / _get_available_respawn_lanes (:279-296) on BIG maps of the default block
+    distribution, with the manager's own seeded stream.  spawn_object is a recorder that consumes the ENGINE stream
+    exactly as BaseEngine.spawn_object does (engine/base_engine.py:133-134: random_seed = generate_seed()) -- it would
+    create a Bullet vehicle otherwise -- and add_policy records the policy seed the manager draws.  The vehicle's own
+    parameter draw is the reference's BaseRunnable.__init__ -> sample_parameters (base_class/base_runnable.py:14-27,
+    81-91) on the vehicle class's PARAMETER_SPACE with that seed.  The engine stream is advanced by the draws that
+    precede the traffic manager in the reset chain (one: the agent's spawn_object, manager/agent_manager.py:43);
+    the count is part of the fixture."""
+    from types import SimpleNamespace
+    from metadrive.base_class.base_runnable import BaseRunnable
+    from metadrive.base_class.randomizable import Randomizable
+    from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
+    from metadrive.manager.traffic_manager import PGTrafficManager
+    from metadrive.utils.random_utils import get_np_random
+    type_key = {"SVehicle": "s", "MVehicle": "m", "LVehicle": "l", "XLVehicle": "xl", "DefaultVehicle": "default"}
+    ENGINE_DRAWS_BEFORE = 1
+    specs = []
+    for mode in ("trigger", "respawn", "hybrid"):
+        specs += [dict(seed=s, mode=mode, density=0.1, inverse=False, lane_num=3, lane_width=3.5, blocks=3) for s in range(0, 32)]
+    specs += [dict(seed=100 + s, mode="trigger", density=0.3, inverse=False, lane_num=3, lane_width=3.5, blocks=3) for s in range(8)]
+    specs += [dict(seed=200 + s, mode="trigger", density=0.15, inverse=True, lane_num=3, lane_width=3.5, blocks=3) for s in range(8)]
+    specs += [dict(seed=300 + s, mode=m, density=0.2, inverse=False, lane_num=2, lane_width=3.0, blocks=5)
+              for s in range(4) for m in ("trigger", "respawn")]
+    cases = []
+    maps = {}       # one BIG run per (seed, shape): the traffic manager only reads the map
+    for sp in specs:
+        seed = sp["seed"]
+        mkey = (seed, sp["lane_num"], sp["lane_width"], sp["blocks"])
+        if mkey not in maps:
+            maps[mkey] = build_reference_map(seed, sp["lane_num"], sp["lane_width"], 50, "block_num", sp["blocks"], PGBlockDistConfig)
+            for f, td in maps[mkey][1].graph.items():
+                for t, lanes in td.items():
+                    for i, l in enumerate(lanes):
+                        l.index = (f, t, i)
+        big, net = maps[mkey]
+        engine_stream = Randomizable(seed)                  # BaseEngine.seed(s) (engine/base_engine.py:546-553)
+        for _ in range(ENGINE_DRAWS_BEFORE):
+            engine_stream.generate_seed()
+        spawned = []
+
+        class Rec(PGTrafficManager):
+            def __init__(self):                             # no BaseManager / engine machinery
+                Randomizable.__init__(self, seed)           # BaseManager.seed(s) at reset
+                self._traffic_vehicles = []
+                self.block_triggered_vehicles = []
+                self.mode = sp["mode"]
+                self.random_traffic = False
+                self.density = sp["density"]
+                self.respawn_lanes = None
+
+            def spawn_object(self, cls, vehicle_config=None, **kw):
+                vseed = int(engine_stream.generate_seed())
+
+                class Params(BaseRunnable):
+                    PARAMETER_SPACE = cls.PARAMETER_SPACE
+                prm = Params(random_seed=vseed)
+                lane = net.get_lane(vehicle_config["spawn_lane_index"])
+                long = float(vehicle_config["spawn_longitude"])
+                pos = lane.position(long, 0.0)
+                rec = dict(cls=type_key[cls.__name__], vehicle_seed=vseed, lane=list(vehicle_config["spawn_lane_index"]),
+                           longitude=long, position=[float(pos[0]), float(pos[1])], heading=float(lane.heading_theta_at(long)),
+                           params={k: float(v) for k, v in dict(prm.config).items()},
+                           length=float(_cls_const(cls, "LENGTH")), width=float(_cls_const(cls, "WIDTH")),
+                           mass=float(_cls_const(cls, "MASS")), front_wheelbase=float(_cls_const(cls, "FRONT_WHEELBASE")),
+                           rear_wheelbase=float(_cls_const(cls, "REAR_WHEELBASE")))
+                spawned.append(rec)
+                return SimpleNamespace(id="v%d" % (len(spawned) - 1), name="v%d" % (len(spawned) - 1))
+
+            def add_policy(self, object_id, policy_class, obj, policy_seed):
+                spawned[int(object_id[1:])]["policy_seed"] = int(policy_seed)
+                spawned[int(object_id[1:])]["policy"] = policy_class.__name__
+
+        map_ = SimpleNamespace(blocks=big.blocks, road_network=net)
+        fake_engine = SimpleNamespace(
+            global_config=dict(traffic_mode=sp["mode"], random_traffic=False, traffic_density=sp["density"],
+                               need_inverse_traffic=sp["inverse"], traffic_vehicle_config=dict(enable_reverse=False)),
+            map_manager=SimpleNamespace(current_map=map_))
+        Rec.engine = property(lambda self: fake_engine)
+        mgr = Rec()
+        PGTrafficManager.reset(mgr)
+        blocks = [dict(trigger_road=[bv.trigger_road.start_node, bv.trigger_road.end_node], vehicles=[int(n[1:]) for n in bv.vehicles])
+                  for bv in mgr.block_triggered_vehicles]
+        cases.append(dict(spec=sp, map_blocks=[b.ID for b in big.blocks], vehicles=spawned, block_triggered=blocks,
+                          driving_from_reset=[int(v.id[1:]) for v in mgr._traffic_vehicles],
+                          respawn_lanes=[list(l.index) for l in (mgr.respawn_lanes or [])],
+                          engine_stream_next=float(engine_stream.np_random.rand()), traffic_stream_next=float(mgr.np_random.rand())))
+    dump("traffic_spawn.json", dict(engine_draws_before=ENGINE_DRAWS_BEFORE, cases=cases))
+
+
 def section_pg_maps_v2():
     """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
     straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
@@ -1561,7 +1659,8 @@ def section_scenario_export():
 
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
-                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn)
+                       scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn,
+                       traffic_spawn=section_traffic_spawn)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -36,6 +36,19 @@ def test_env_api_contract(cs_dist):
         fl_ = env.engine.flags[:, 0]
         assert tm_.dtype == torch.bool and tr_.dtype == torch.bool
         assert torch.equal(tm_, (fl_ & abi.FL_TERMINATED) != 0) and torch.equal(tr_, (fl_ & abi.FL_TRUNCATED) != 0)
+        # ... and bytes 2-3 of the same word are the agent's whole step flag word (ABI v10)
+        assert torch.equal(env.engine.step_flags[:, 0].to(torch.int32) & 0xFFFF, fl_ & 0xFFFF)
+    # obs | reward | done_out are ONE allocation (the slab the multi-GPU gather moves with one collective): the typed views of the
+    # slab are the tensors step() returned
+    from metadrive_ped_amd.sharding import slab_layout, split_step_slab
+    eng_ = env.engine
+    layout, total = slab_layout(E, 1, eng_.obs_dim)
+    assert eng_.out_slab.numel() == total and {k: tuple(v) for k, v in eng_.out_layout.items()} == layout
+    assert eng_.obs.data_ptr() == eng_.out_slab.data_ptr()
+    parts = split_step_slab(eng_.out_slab.view(1, -1), E, 1, eng_.obs_dim)
+    assert torch.equal(parts["obs"][:, 0], o_) and torch.equal(parts["reward"][:, 0], r_)
+    assert torch.equal(parts["terminated"][:, 0], tm_) and torch.equal(parts["truncated"][:, 0], tr_)
+    assert torch.equal(parts["flags"][:, 0].to(torch.int32) & 0xFFFF, eng_.flags[:, 0] & 0xFFFF)
     obs2, _ = env.reset(seed=5)                          # re-base scenarios: maps regenerate
     assert env.current_seeds[0] == 5 and env.current_seed == 5 and env.num_scenarios == E
     assert tuple(env.episode_step.shape) == (E, ) and int(env.episode_step.max()) == 0

@@ -810,3 +810,39 @@ def test_scenario_checkpoint_resumes_bit_identically():
     bad["__seeds__"] = ck["__seeds__"] + 1
     with pytest.raises(ValueError):
         env.set_state(bad)
+
+
+def test_scene_identity_follows_the_scenario_index():
+    """ScenarioHostScene.seeds / scenario_ids name WHICH scenarios a batch holds (start_scenario_index-based), so that a checkpoint
+    or track set of scenarios 0..3 cannot be loaded into a batch of scenarios 100..103."""
+    from metadrive_ped_amd.scenario import ScenarioHostScene, make_scenario_config
+    mk = lambda start, off=0: make_scenario_config(dict(num_envs=4, num_scenarios=4, start_scenario_index=start, env_seed_offset=off,
+                                                        build_workers=1))
+    h0 = ScenarioHostScene(mk(0), synthetic_scenarios(4, 0))
+    h100 = ScenarioHostScene(mk(100), synthetic_scenarios(4, 100))
+    assert h0.seeds == [0, 1, 2, 3] and h100.seeds == [100, 101, 102, 103]
+    assert h0.scenario_ids != h100.scenario_ids and len(set(h100.scenario_ids)) == 4
+    assert ScenarioHostScene(mk(100, off=2), synthetic_scenarios(4, 102)).seeds == [102, 103, 100, 101]
+
+
+@pytest.mark.gpu
+def test_scenario_checkpoint_refuses_other_scenarios():
+    from metadrive_ped_amd.envs.scenario_env import BatchedScenarioEnv
+    E = 8
+    a = BatchedScenarioEnv(dict(num_envs=E, num_scenarios=E, start_scenario_index=0, horizon=0))
+    b = BatchedScenarioEnv(dict(num_envs=E, num_scenarios=E, start_scenario_index=100, horizon=0))
+    a.reset()
+    b.reset()
+    ck = a.get_state()
+    assert int(ck["__abi__"][0]) == abi.MD_ABI_VERSION
+    with pytest.raises(ValueError, match="another scenario assignment"):
+        b.set_state(ck)
+    same_index_other_data = dict(ck)
+    same_index_other_data["__scenario_ids__"] = np.asarray(["x%d" % i for i in range(E)])
+    with pytest.raises(ValueError, match="other scenarios"):
+        a.set_state(same_index_other_data)
+    old = dict(ck)
+    old["__abi__"] = np.asarray([abi.MD_ABI_VERSION - 1])
+    with pytest.raises(ValueError, match="ABI"):
+        a.set_state(old)
+    a.set_state(ck)
