@@ -37,7 +37,7 @@ import metadrive.base_class.base_object as _bo  # noqa: E402
 
 _bo.clear_node_list = lambda node_path_list: node_path_list.clear() if hasattr(node_path_list, "clear") else None
 
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN = os.environ.get("MD_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # tools/check_golden.py regenerates elsewhere
 
 
 def dump(name, obj):
@@ -1110,7 +1110,7 @@ def section_scenario():
     from metadrive.manager.scenario_traffic_manager import ScenarioTrafficManager
     from metadrive.obs.state_obs import StateObservation
     from metadrive.component.map.base_map import BaseMap
-    from metadrive_ped_amd.scenario import synthetic_scenario
+    from gen_inputs import frozen_scenario as synthetic_scenario   # frozen inputs: never the product's own generator
     rng = np.random.RandomState(515)
     out = dict(supplied_by_generator=["convert_to_local_coordinates (forward, left)", "point_on_lane (even-odd on lane.polygon)"])
 
@@ -1344,7 +1344,7 @@ def section_scenario_spawn():
     from metadrive.manager.scenario_traffic_manager import ScenarioTrafficManager
     from metadrive.policy.idm_policy import TrajectoryIDMPolicy
     from metadrive.policy.replay_policy import ReplayTrafficParticipantPolicy
-    from metadrive_ped_amd.scenario import _track_dict
+    from gen_inputs import _track_dict
     rng = np.random.RandomState(99)
     T = 60
 
