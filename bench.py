@@ -30,6 +30,8 @@ Extra objects in the JSON line:
                host cores, bounded sample
   env_api      the same steps through BatchedMetaDriveEnv.step (the Gymnasium-shaped boundary: done flags,
                lazy info dict)
+  shared_maps  the same envs on 1 / 64 distinct maps (the reference's default num_scenarios is 1): md_step's kernel as
+               config["step_kernel"] = "auto" picks it (one wave per env on few maps)
   with_gather  (N>1) the same steps, each followed by ONE RCCL all_gather of the packed slab obs | reward | done+flags
 """
 import argparse
@@ -49,6 +51,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3   # vector FP32, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 MIN_TIMED_S = 0.05
+SHARED_MAPS = (1, 64)   # distinct maps of the shared-maps operating points
 
 
 def parse():
@@ -63,6 +66,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-lane-follow", action="store_true", help="skip the scripted-driver operating point")
     p.add_argument("--no-env-api", action="store_true", help="skip the BatchedMetaDriveEnv.step leg")
+    p.add_argument("--no-shared-maps", action="store_true", help="skip the shared-maps operating points (num_scenarios 1 / 64)")
     p.add_argument("--sub-batches", type=int, default=2,
                    help="double-buffered leg (N=1): the same envs as S sub-batches on S HIP streams; 0 or 1 = skip")
     p.add_argument("--workload", default="metadrive", choices=["metadrive", "safe", "marl", "replay", "scenario"],
@@ -247,6 +251,7 @@ def main():
     want_sub = (world == 1 and args.sub_batches > 1 and args.workload in ("metadrive", "safe", "marl")
                 and E % args.sub_batches == 0)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "metadrive"
+    want_shared = world == 1 and args.workload == "metadrive" and not args.no_shared_maps
     n_cpu = min(args.cpu_envs, E)
     n_cpu1 = max(1, n_cpu // 16)
 
@@ -271,6 +276,10 @@ def main():
             sub_ = SubBatchedEnvs(BatchedMultiAgentRoundaboutEnv if args.workload == "marl" else BatchedMetaDriveEnv,
                                   sub_user, sub_batches=args.sub_batches)
             h["sub_hosts"] = sub_.build_host()
+        if want_shared:
+            # the same envs on FEW distinct maps (the reference's default is num_scenarios = 1): step_kernel "auto" picks the
+            # wave-per-env kernel there
+            h["shared"] = {n: HostScene(make_config(dict(user, num_scenarios=n, env_seed_offset=0))) for n in SHARED_MAPS}
         if want_cpu:
             for key, n in (("cpu", n_cpu), ("cpu1", n_cpu1)):
                 c = dict(cfg)
@@ -547,6 +556,26 @@ def main():
                                     "its own HIP stream; no cross-stream wait inside the timed region" % E)
         sub.close()
 
+    # ---- shared maps (N=1): the same number of envs on 1 / 64 distinct maps; md_step's kernel is chosen by the engine
+    #      (step_kernel "auto": one wave per env when a large batch shares few maps) ----
+    shared_maps = None
+    if want_shared and "shared" in hosts:
+        shared_maps = []
+        for n_maps in SHARED_MAPS:
+            se = BatchedEngine(hosts["shared"][n_maps].cfg, host=hosts["shared"][n_maps])
+            se.reset()
+            for i in range(max(args.preroll, 0)):
+                se.step(actions[i % n_act])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(timed_steps):
+                se.step(actions[i % n_act])
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t0
+            shared_maps.append(dict(num_scenarios=n_maps, step_kernel=se.host.step_kernel, ms_per_step=round(dt_s / timed_steps * 1e3, 4),
+                                    value=round(timed_steps * E * A / dt_s, 1), unit="agent-steps/s"))
+            del se
+
     # ---- gather leg (N>1): the rank's whole step output -- obs | reward | terminated, truncated, flags, one allocation
     #      (BatchedEngine.out_slab) -- to every rank with ONE RCCL collective per step, timed over the same number of steps
     #      as the main leg (>= MIN_TIMED_S) ----
@@ -631,7 +660,7 @@ def main():
                         envs_per_gpu=E, active_agent_fraction=round(active_frac, 3), agents_per_env=A, mover_capacity=cap, n_beams=B, sharding="env-range per rank"),
             preroll=args.preroll, timed_steps=timed_steps,
             roofline=roofline, lidar=lidar, cpu_baseline=cpu_baseline, env_api=env_api, lane_follow_policy=lane_follow,
-            double_buffered=double_buffered, with_gather=with_gather, host_build_s=round(build_s, 1))
+            double_buffered=double_buffered, shared_maps=shared_maps, with_gather=with_gather, host_build_s=round(build_s, 1))
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:

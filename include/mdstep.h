@@ -341,8 +341,7 @@ typedef struct MdState {
     uint64_t* detected;        /* [n_envs * agents_per_env][2] bit j of the 128-bit set: some beam of the agent's lidar
                                   hit the mover in slot j first -- the `detected_objects` half of Lidar.perceive's
                                   return value (component/sensors/lidar.py:49-73); written by md_step           */
-    /* optional: work space of the phase-per-launch step (MdConfig.step_kernel 2): [2 * N + 4 * n_envs] uint32 owned by the
-     * caller like every other array; contents are meaningless between calls.  NULL = that mode is not available. */
+    /* reserved (NULL): was the work space of the phase-per-launch step, removed in ABI v10 (slower at every batch size) */
     uint32_t* scratch;
     const MdParam* param0;     /* reset snapshot of `param` (multi-agent + random_agent_model only; NULL otherwise) */
     /* optional: [n_envs * agents_per_env] 4-byte words, one per agent, written with ONE store (ABI v10; v9 held two bytes):
@@ -421,8 +420,9 @@ typedef struct MdConfig {
     int32_t reactive_traffic, filter_overlapping_car, no_static_vehicles;
     int32_t allowed_more_steps;/* 0 = None                                                       */
     int32_t scenario_length;   /* frames of the scenarios (data_manager.current_scenario_length)  */
-    int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env (default), 1 = one wave per env, 2 = one launch per phase.
-                                * Same results bit for bit; a machine-mapping choice, no reference counterpart. */
+    int32_t step_kernel;       /* md_step of single-agent envs: 0 = one 4-wave workgroup per env, 1 = one wave per env (faster when the
+                                * batch shares few distinct maps: the host picks, metadrive_ped_amd/engine.py).  Same results bit for
+                                * bit; a machine-mapping choice, no reference counterpart. */
     /* which multi-agent env's rules md_observe applies (is_multi_agent only): 0 = MultiAgentMetaDrive and the envs that keep
      * its reward / done / observation, 1 = MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py:181-266: no navigation
      * dims, two toll dims after the lidar cloud, overspeed penalty inside the toll block, minimum stay), 2 =

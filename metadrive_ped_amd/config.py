@@ -116,7 +116,8 @@ BATCH_DEFAULT_CONFIG = dict(
     build_cache=False,      # memoise built (map, scene) pairs by scenario seed + config (sub-batches / copies of the same envs)
     traffic_epoch=0,        # random_traffic=True: bumped by every explicit env.reset(); part of the traffic stream's seed
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
-    step_kernel="wg",       # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env (same
+    step_kernel="auto",     # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env, "auto" = by
+                            # the number of distinct maps the batch shares (engine.WAVE_KERNEL_MAX_MAPS) (same
                             # results bit for bit; a machine-mapping choice)
 )
 
@@ -251,8 +252,8 @@ def make_config(user=None):
             raise ValueError("parking_space_num > 20: the spawn tables hold 32 places")
     if not cfg["cross_yellow_line_done"] and cfg["marl_map"] != "tollgate":
         raise NotImplementedError("cross_yellow_line_done=False is built for the tollgate env only")
-    if cfg["step_kernel"] not in ("wg", "wave", "pm"):
-        raise ValueError("step_kernel must be 'wg', 'wave' or 'pm', got {!r}".format(cfg["step_kernel"]))
+    if cfg["step_kernel"] not in ("auto", "wg", "wave"):
+        raise ValueError("step_kernel must be 'auto', 'wg' or 'wave', got {!r}".format(cfg["step_kernel"]))
     if cfg["mover_capacity"] != 0 and (cfg["mover_capacity"] > 128 or cfg["mover_capacity"] < cfg["num_agents"]):
         raise ValueError("mover_capacity must be 0 (auto) or in [num_agents, 128]")
     return cfg

@@ -2575,314 +2575,6 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     MD_STAMP_AT(11);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Phase-per-launch step of the single-agent envs (MdConfig.step_kernel 2): the step as FOUR launches whose work items
-// are vehicles, not environments.
-//
-// The fused kernels above give every env one workgroup (or one wave) for the whole step: its phases form one long
-// dependent chain (PMC: 60-74 % of the wave-cycles wait on memory), a launch lasts as long as the env with the most
-// vehicles awake, and 4096 envs are at most 4096 chains.  Here every phase is a launch of its own over ALL envs, its
-// items small and alike, so the chip holds tens of thousands of short independent chains at full occupancy and no item
-// waits for a slower sibling of its env:
-//   pm_integrate   one THREAD per (env, slot): auto-reset restore, action sanitising, bicycle sub-steps
-//   pm_locate      one WAVE per (env, localisation group of <= 4 driving vehicles, 16 lanes each) or (env, agent contacts)
-//   pm_env         one WAVE per env: flag merge, removal of traffic that left every lane, next step's trigger
-//   pm_act         one WAVE per (env, agent observation) | (env, k-th driving traffic vehicle: IDM for the next step) |
-//                  (env, agent, 64-beam lidar sector)
-// State lives in HBM / L2 between the launches (an item stages the <= 5 KB of its env it reads into LDS and writes back the
-// one slot it owns); launch boundaries are the only synchronisation.  The work inside an item is the SAME wave-level
-// device function the fused kernels call: results stay bit-identical to the oracle.
-// ------------------------------------------------------------------------------------------------
-constexpr int kPmLocItems = 2;   // localisation items per env: item q takes the groups q, q + 2, ... (8 vehicles in one pass)
-constexpr int kPmIdmItems = 3;   // IDM items per env: item i takes the driving traffic vehicles k = i, i + 3, ...
-
-__device__ __forceinline__ uint32_t* pm_onlane(const MdState& g, const MdConfig& c, int e) { return g.scratch + (size_t)e * c.cap; }
-__device__ __forceinline__ uint32_t* pm_cfl(const MdState& g, const MdConfig& c, int e) {
-    return g.scratch + (size_t)c.n_envs * c.cap + (size_t)e * c.cap;
-}
-__device__ __forceinline__ uint32_t* pm_envword(const MdState& g, const MdConfig& c, int e) {
-    return g.scratch + 2 * (size_t)c.n_envs * c.cap + 4 * (size_t)e;   // [0] just_reset
-}
-
-__global__ __launch_bounds__(256) void pm_integrate_kernel(MdState g, MdConfig c) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= c.n_envs * c.cap) return;
-    const int e = n / c.cap, j = n - e * c.cap;
-    const MdState s = md_env_view(&g, &c, e);
-    const int reset = s.need_reset[0];   // nobody writes it in this launch (pm_env clears it)
-    if (j == 0) pm_envword(g, c, e)[0] = reset ? 1u : 0u;
-    if (reset) {
-        s.shape[j] = s.shape0[j];
-        s.dyn[j] = s.dyn0[j];
-        s.nav[j] = s.nav0[j];
-        s.pid[j] = s.pid0[j];
-        s.action[2 * j] = 0.0f;
-        s.action[2 * j + 1] = 0.0f;
-        s.flags[j] = 0u;
-        return;
-    }
-    if (j < c.agents_per_env && s.agent_action) {
-        s.action[2 * j] = s.agent_action[2 * j];
-        s.action[2 * j + 1] = s.agent_action[2 * j + 1];
-    }
-    md_integrate_mover(&s, &c, j);
-    md_walk_mover(&s, &c, j);
-}
-
-__global__ __launch_bounds__(256) void pm_locate_kernel(MdWorld w, MdState g, MdConfig c) {
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    constexpr int kPerEnv = kPmLocItems + 1;
-    const int e = item / kPerEnv, kind = item - e * kPerEnv;
-    if (e >= c.n_envs) return;
-    const int cap = c.cap, A = c.agents_per_env;
-    const MdState s = md_env_view(&g, &c, e);
-    unsigned long long drv_lo = 0ull, drv_hi = 0ull;
-    for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long mk = __ballot(j < cap && md_drives(s.shape[j < cap ? j : 0].flags));
-        if (j0 == 0) drv_lo = mk;
-        else drv_hi = mk;
-    }
-    const int m = w.env_map[e];
-    const MdLane* lanes = w.lanes + w.lane_off[m];
-    const MdRoad* roads = w.roads + w.road_off[m];
-    if (kind < kPmLocItems) {
-        const int nd = __popcll(drv_lo) + __popcll(drv_hi);
-        uint32_t* onlane = pm_onlane(g, c, e);
-        if (nd == 1) {
-            if (kind == 0) localize_vehicle(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, 0), lane, onlane);
-        } else if (nd == 2) {
-            if (kind == 0) localize_pair(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, 0), kth_bit(drv_lo, drv_hi, 1), lane, onlane);
-        } else {
-            for (int q = kind; 4 * q < nd; q += kPmLocItems)
-                localize_group<16>(w, lanes, roads, s, e, kth_bit(drv_lo, drv_hi, 4 * q), kth_bit(drv_lo, drv_hi, 4 * q + 1),
-                                   kth_bit(drv_lo, drv_hi, 4 * q + 2), kth_bit(drv_lo, drv_hi, 4 * q + 3), lane, onlane);
-        }
-    } else {
-        const unsigned long long a_lo = A >= 64 ? ~0ull : ((1ull << A) - 1ull);
-        const unsigned long long a_hi = A <= 64 ? 0ull : (A >= 128 ? ~0ull : ((1ull << (A - 64)) - 1ull));
-        const unsigned long long adrv_lo = drv_lo & a_lo, adrv_hi = drv_hi & a_hi;
-        const int na = __popcll(adrv_lo) + __popcll(adrv_hi);
-        for (int k = 0; k < na; ++k) contacts_vehicle(w, s, c, e, kth_bit(adrv_lo, adrv_hi, k), lane, pm_cfl(g, c, e));
-    }
-}
-
-// per-wave LDS image for pm_env / pm_act: shape dyn pid param (32 B) + nav (64 B) per slot, action, flags, final, 48 floats
-__host__ __device__ inline int pm_image_bytes(int cap) { return ((cap * (4 * 32 + 64) + cap * (8 + 4 + 4) + 48 * 4) + 15) & ~15; }
-
-struct PmImage {
-    MdShape* shape;
-    MdDyn* dyn;
-    MdPid* pid;
-    MdParam* param;
-    MdNav* nav;
-    float* action;
-    uint32_t* flags;
-    int32_t* fin;
-    float* scratch;
-};
-
-__device__ __forceinline__ PmImage pm_image_at(unsigned char* base, int cap) {
-    PmImage L;
-    L.shape = reinterpret_cast<MdShape*>(base);
-    L.dyn = reinterpret_cast<MdDyn*>(L.shape + cap);
-    L.pid = reinterpret_cast<MdPid*>(L.dyn + cap);
-    L.param = reinterpret_cast<MdParam*>(L.pid + cap);
-    L.nav = reinterpret_cast<MdNav*>(L.param + cap);
-    L.action = reinterpret_cast<float*>(L.nav + cap);
-    L.flags = reinterpret_cast<uint32_t*>(L.action + 2 * cap);
-    L.fin = reinterpret_cast<int32_t*>(L.flags + cap);
-    L.scratch = reinterpret_cast<float*>(L.fin + cap);
-    return L;
-}
-
-// one wave copies its env's arrays into its image: every global load is issued before the first LDS store
-__device__ __forceinline__ void pm_stage(const MdState& gv, const MdConfig& c, const PmImage& L, int lane, bool shapes_only) {
-    const int cap = c.cap;
-    const int n32 = cap * 2, n64 = cap * 4;
-    const uint4* g_shape = reinterpret_cast<const uint4*>(gv.shape);
-    if (shapes_only) {
-        for (int i = lane; i < n32; i += 64) reinterpret_cast<uint4*>(L.shape)[i] = g_shape[i];
-        return;
-    }
-    const uint4* g_dyn = reinterpret_cast<const uint4*>(gv.dyn);
-    const uint4* g_pid = reinterpret_cast<const uint4*>(gv.pid);
-    const uint4* g_param = reinterpret_cast<const uint4*>(gv.param);
-    const uint4* g_nav = reinterpret_cast<const uint4*>(gv.nav);
-    uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_nav1;
-    float2 r_act;
-    uint32_t r_fl;
-    int r_fin;
-    const bool p32 = lane < n32, pc = lane < cap;
-    if (p32) {
-        r_shape = g_shape[lane];
-        r_dyn = g_dyn[lane];
-        r_pid = g_pid[lane];
-        r_param = g_param[lane];
-    }
-    if (lane < n64) r_nav0 = g_nav[lane];
-    if (lane + 64 < n64) r_nav1 = g_nav[lane + 64];
-    if (pc) {
-        r_act = reinterpret_cast<const float2*>(gv.action)[lane];
-        r_fl = gv.flags[lane];
-        r_fin = gv.final_lane ? gv.final_lane[lane] : 0;
-    }
-    if (p32) {
-        reinterpret_cast<uint4*>(L.shape)[lane] = r_shape;
-        reinterpret_cast<uint4*>(L.dyn)[lane] = r_dyn;
-        reinterpret_cast<uint4*>(L.pid)[lane] = r_pid;
-        reinterpret_cast<uint4*>(L.param)[lane] = r_param;
-    }
-    if (lane < n64) reinterpret_cast<uint4*>(L.nav)[lane] = r_nav0;
-    if (lane + 64 < n64) reinterpret_cast<uint4*>(L.nav)[lane + 64] = r_nav1;
-    if (pc) {
-        reinterpret_cast<float2*>(L.action)[lane] = r_act;
-        L.flags[lane] = r_fl;
-        L.fin[lane] = r_fin;
-    }
-    for (int i = lane + 64; i < n32; i += 64) {
-        reinterpret_cast<uint4*>(L.shape)[i] = g_shape[i];
-        reinterpret_cast<uint4*>(L.dyn)[i] = g_dyn[i];
-        reinterpret_cast<uint4*>(L.pid)[i] = g_pid[i];
-        reinterpret_cast<uint4*>(L.param)[i] = g_param[i];
-    }
-    for (int i = lane + 128; i < n64; i += 64) reinterpret_cast<uint4*>(L.nav)[i] = g_nav[i];
-    for (int j = lane + 64; j < cap; j += 64) {
-        L.action[2 * j] = gv.action[2 * j];
-        L.action[2 * j + 1] = gv.action[2 * j + 1];
-        L.flags[j] = gv.flags[j];
-        L.fin[j] = gv.final_lane ? gv.final_lane[j] : 0;
-    }
-}
-
-__device__ __forceinline__ MdState pm_view(const MdState& gv, const PmImage& L) {
-    MdState s = gv;
-    s.shape = L.shape;
-    s.dyn = L.dyn;
-    s.nav = L.nav;
-    s.pid = L.pid;
-    s.action = L.action;
-    s.flags = L.flags;
-    s.param = L.param;
-    s.final_lane = L.fin;
-    return s;
-}
-
-__global__ __launch_bounds__(256) void pm_env_kernel(MdWorld w, MdState g, MdConfig c) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = blockIdx.x * 4 + wave;
-    if (e >= c.n_envs) return;
-    const int cap = c.cap;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const PmImage L = pm_image_at(smem + (size_t)wave * pm_image_bytes(cap), cap);
-    const MdState gv = md_env_view(&g, &c, e);
-    // only the shapes (flags), the nav records (trigger road / order, the agents' lanes) and the flag words are touched
-    for (int i = lane; i < cap * 2; i += 64) reinterpret_cast<uint4*>(L.shape)[i] = reinterpret_cast<const uint4*>(gv.shape)[i];
-    for (int i = lane; i < cap * 4; i += 64) reinterpret_cast<uint4*>(L.nav)[i] = reinterpret_cast<const uint4*>(gv.nav)[i];
-    const uint32_t* onlane = pm_onlane(g, c, e);
-    const uint32_t* cfl = pm_cfl(g, c, e);
-    wave_sync();
-    MdState s = gv;
-    s.shape = L.shape;
-    s.nav = L.nav;
-    s.flags = L.flags;
-    unsigned long long changed_lo = 0ull, changed_hi = 0ull;   // slots whose shape flags change here (removed / triggered)
-    for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        bool removed = false;
-        if (j < cap) {
-            const int f = L.shape[j].flags;
-            if (md_drives(f)) {
-                const uint32_t fl = onlane[j] | ((f & MD_F_AGENT) ? cfl[j] : 0u);
-                gv.flags[j] = fl;
-                if (!(f & MD_F_AGENT) && !(fl & MD_FL_ON_LANE)) {
-                    L.shape[j].flags = f & ~MD_F_ALIVE;
-                    removed = true;
-                }
-            }
-        }
-        const unsigned long long mk = __ballot(removed);
-        if (j0 == 0) changed_lo = mk;
-        else changed_hi = mk;
-    }
-    wave_sync();
-    // next step's trigger (reads the agents' lanes and the PENDING slots); remember which slots it wakes
-    for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long pend = __ballot(j < cap && (L.shape[j < cap ? j : 0].flags & MD_F_PENDING) != 0);
-        if (j0 == 0) changed_lo |= pend;
-        else changed_hi |= pend;
-    }
-    trigger_env(w.lanes + w.lane_off[w.env_map[e]], s, c, lane);
-    wave_sync();
-    for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        const unsigned long long mk = (j0 == 0) ? changed_lo : changed_hi;
-        if (j < cap && ((mk >> lane) & 1ull)) gv.shape[j].flags = L.shape[j].flags;
-    }
-    if (lane == 0 && pm_envword(g, c, e)[0]) gv.need_reset[0] = 0;
-}
-
-__global__ __launch_bounds__(256) void pm_act_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, int lidar_stride,
-                                                    int lidar_offset) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cap = c.cap, A = c.agents_per_env;
-    const int nsec = (c.n_beams + 63) >> 6;
-    const int per_env = A + kPmIdmItems + A * nsec;
-    const int item = blockIdx.x * 4 + wave;
-    const int e = item / per_env, k = item - e * per_env;
-    if (e >= c.n_envs) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const PmImage L = pm_image_at(smem + (size_t)wave * pm_image_bytes(cap), cap);
-    const MdState gv = md_env_view(&g, &c, e);
-    const int m = w.env_map[e];
-    const MdLane* lanes = w.lanes + w.lane_off[m];
-    const MdRoad* roads = w.roads + w.road_off[m];
-    if (k >= A + kPmIdmItems) {   // ---- a lidar sector ----
-        const int r = k - A - kPmIdmItems;
-        const int a = r / nsec, sec = r - a * nsec;
-        pm_stage(gv, c, L, lane, true);
-        wave_sync();
-        MdState s = gv;
-        s.shape = L.shape;
-        lidar_item(w, s, c, a, sec, lane, lidar_out + (size_t)(e * A + a) * lidar_stride + lidar_offset, nullptr);
-        return;
-    }
-    pm_stage(gv, c, L, lane, false);
-    wave_sync();
-    const MdState s = pm_view(gv, L);
-    if (k < A) {   // ---- an agent's observation, reward, done ----
-        const int a = k;
-        observe_agent_wave1(lanes, roads, s, c, a, (int)pm_envword(g, c, e)[0], lane, L.scratch);
-        wave_sync();
-        if (lane < 2) reinterpret_cast<uint4*>(gv.shape)[2 * a + lane] = reinterpret_cast<const uint4*>(L.shape)[2 * a + lane];
-        if (lane < 2) reinterpret_cast<uint4*>(gv.pid)[2 * a + lane] = reinterpret_cast<const uint4*>(L.pid)[2 * a + lane];
-        if (lane < 4) reinterpret_cast<uint4*>(gv.nav)[4 * a + lane] = reinterpret_cast<const uint4*>(L.nav)[4 * a + lane];
-        if (lane == 0) gv.flags[a] = L.flags[a];
-        return;
-    }
-    // ---- IDM for the next step: the driving traffic vehicles i, i + 3, ... of this env ----
-    const int i0 = k - A;
-    unsigned long long t_lo = 0ull, t_hi = 0ull;
-    for (int j0 = 0; j0 < cap; j0 += 64) {
-        const int j = j0 + lane;
-        const int f = L.shape[j < cap ? j : 0].flags;
-        const unsigned long long mk = __ballot(j < cap && j >= A && md_drives(f) && !(f & MD_F_AGENT));
-        if (j0 == 0) t_lo = mk;
-        else t_hi = mk;
-    }
-    const int nt = __popcll(t_lo) + __popcll(t_hi);
-    for (int q = i0; q < nt; q += kPmIdmItems) {
-        const int j = kth_bit(t_lo, t_hi, q);
-        idm_vehicle_wave(w, lanes, roads, s, c, m, j, lane, reinterpret_cast<int*>(L.scratch));
-        wave_sync();
-        if (lane < 2) reinterpret_cast<uint4*>(gv.pid)[2 * j + lane] = reinterpret_cast<const uint4*>(L.pid)[2 * j + lane];
-        if (lane < 4) reinterpret_cast<uint4*>(gv.nav)[4 * j + lane] = reinterpret_cast<const uint4*>(L.nav)[4 * j + lane];
-        if (lane == 0) reinterpret_cast<float2*>(gv.action)[j] = reinterpret_cast<const float2*>(L.action)[j];
-    }
-}
-
 // Lidar.perceive as a sensor on its own (md_lidar_detect): cloud points AND the detected-object sets, from nothing but
 // the shape table.  One workgroup per env, shapes + sets in LDS, (agent, sector) items dealt to the waves.
 __global__ __launch_bounds__(256) void lidar_detect_kernel(MdWorld w, MdState g, MdConfig c, float* out, int out_stride, int out_offset,
@@ -2959,51 +2651,11 @@ int need(const void* p, const char* name) {
     return MD_EINVAL;
 }
 
-// md_step of the single-agent envs has two kernels: env_kernel (one 4-wave workgroup per env, the default) and
-// wave_step_kernel (one wave per env), chosen by MdConfig.step_kernel; MD_STEP_KERNEL=wave / wg in the environment
-// overrides the config (A/B measurements).
-bool use_wave_kernel(const MdConfig* c) {
-    static const int forced = [] {
-        const char* v = getenv("MD_STEP_KERNEL");
-        if (!v) return 0;
-        return (v[0] == 'w' && v[1] == 'a') ? 1 : 2;
-    }();
-    if (c->is_multi_agent) return false;
-    if (forced) return forced == 1;
-    return c->step_kernel == 1;
-}
-
-// md_step as four launches (MdConfig.step_kernel 2 / MD_STEP_KERNEL=pm): the lean single-agent trigger-mode path only
-bool use_phase_kernels(const MdState* s, const MdConfig* c) {
-    static const int forced = [] {
-        const char* v = getenv("MD_STEP_KERNEL");
-        if (!v) return 0;
-        return (v[0] == 'p' && v[1] == 'm') ? 1 : 2;
-    }();
-    if (c->is_multi_agent || c->traffic_mode != 0 || c->agent_idm != 0 || s->detected != nullptr || !s->scratch) return false;
-    if (forced) return forced == 1;
-    return c->step_kernel == 2;
-}
-
-int launch_phase_step(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
-                      void* stream) {
-    const hipStream_t st = (hipStream_t)stream;
-    const int E = c->n_envs, A = c->agents_per_env;
-    const int nsec = (c->n_beams + 63) >> 6;
-    const size_t img = (size_t)pm_image_bytes(c->cap);
-    if (4 * img > 64 * 1024) return 1;   // capacity too large for four images per workgroup: the caller falls back
-    hipLaunchKernelGGL(pm_integrate_kernel, dim3((E * c->cap + 255) / 256), dim3(256), 0, st, *s, *c);
-    hipLaunchKernelGGL(pm_locate_kernel, dim3((E * (kPmLocItems + 1) + 3) / 4), dim3(256), 0, st, *w, *s, *c);
-    hipLaunchKernelGGL(pm_env_kernel, dim3((E + 3) / 4), dim3(256), 4 * img, st, *w, *s, *c);
-    hipLaunchKernelGGL(pm_act_kernel, dim3((E * (A + kPmIdmItems + A * nsec) + 3) / 4), dim3(256), 4 * img, st, *w, *s, *c, lidar_out,
-                       stride, offset);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) {
-        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
-        return MD_ELAUNCH;
-    }
-    return MD_OK;
-}
+// md_step of the single-agent envs has two kernels: env_kernel (one 4-wave workgroup per env) and wave_step_kernel (one
+// wave per env), chosen by MdConfig.step_kernel alone (0 = workgroup, 1 = wave): the host decides -- it knows how many
+// distinct maps the batch shares, which is what tips the balance (metadrive_ped_amd/engine.py) -- and the library reads no
+// environment variable.
+bool use_wave_kernel(const MdConfig* c) { return !c->is_multi_agent && c->step_kernel == 1; }
 
 int launch_wave_step(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
                      void* stream) {
@@ -3031,10 +2683,6 @@ int launch_wave_step(const MdWorld* w, const MdState* s, const MdConfig* c, floa
 template <int PH>
 int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_out, int stride, int offset,
            void* stream) {
-    if (PH == PH_ALL && use_phase_kernels(s, c)) {
-        const int r = launch_phase_step(w, s, c, lidar_out, stride, offset, stream);
-        if (r != 1) return r;
-    }
     if (PH == PH_ALL && use_wave_kernel(c)) return launch_wave_step(w, s, c, lidar_out, stride, offset, stream);
     const bool stage = w->max_lanes <= kStageMaxLanes;
     constexpr bool kCanMultiLds = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;  // same rule as the MULTI kernel variant below

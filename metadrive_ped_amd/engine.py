@@ -21,6 +21,29 @@ from metadrive_ped_amd.scene import EnvScene
 STATE_ARRAY_SPECS = None  # filled below
 
 
+# One wave per env beats the 4-wave workgroup when a LARGE batch shares few distinct maps: the lane / grid tables stay in L2, so
+# the wave's serial chain of map reads is short, and all envs are resident at once.  Measured on the MI355X
+# (tools/locality_probe.py, profiles/r03_step_kernel_by_maps.txt): 4096 envs on 1 / 8 / 16 / 32 maps 70-72 us against 83-86 us;
+# even at 64 maps, behind at 512 (82.6 vs 79.2) and with a map per env (94 vs 87); at 1024 envs and below the workgroup kernel's
+# shorter chain wins whatever the maps (38 vs 60 us).  The reference's default is num_scenarios = 1.
+WAVE_KERNEL_MAX_MAPS = 32
+WAVE_KERNEL_MIN_ENVS = 3072
+
+
+def pick_step_kernel(cfg, n_maps):
+    """config["step_kernel"] -> "wg" | "wave".  "auto": by the batch size and the number of distinct maps; MD_STEP_KERNEL in the
+    environment overrides "auto" only (A/B runs) -- read HERE, once per engine, never inside the library."""
+    want = cfg.get("step_kernel", "auto")
+    if cfg.get("is_multi_agent") or cfg.get("scenario_mode"):
+        return "wg"
+    if want == "auto":
+        env = os.environ.get("MD_STEP_KERNEL", "")
+        if env in ("wg", "wave"):
+            return env
+        return "wave" if (n_maps <= WAVE_KERNEL_MAX_MAPS and int(cfg["num_envs"]) >= WAVE_KERNEL_MIN_ENVS) else "wg"
+    return want
+
+
 def _build_marl(cfg, scene_cfg, uniq):
     """Multi-agent maps (roundabout, intersection): one shared map, one scene per env seed."""
     from metadrive_ped_amd.mapgen.pg import (MABidirectionMap, MABottleneckMap, MAIntersectionMap, MAParkingLotMap, MARoundaboutMap,
@@ -238,7 +261,6 @@ class HostScene:
         st["step_info"] = np.zeros((E * A, 8), np.float32)
         st["done_out"] = np.zeros((E * A, 4), np.uint8)          # (terminated, truncated, flag word lo / hi) straight from the kernel
         st["need_reset"] = np.ones(E, np.int32)
-        st["scratch"] = np.zeros(2 * N + 4 * E, np.uint32)      # work space of the phase-per-launch step kernels
         self.traffic_respawns = "spawn_off" in self.world.arrays and not cfg["is_multi_agent"]
         if cfg["is_multi_agent"] or self.traffic_respawns:
             # respawns (agents in MARL, traffic in the respawn / hybrid modes) rewrite routes and draw random numbers
@@ -264,7 +286,8 @@ class HostScene:
         self.md_config.random_agent_model = int(bool(cfg["random_agent_model"]))
         self.md_config.agent_idm = int(cfg["agent_policy"] == "IDMPolicy")
         self.md_config.enable_reverse = int(bool(cfg["vehicle_config"]["enable_reverse"]))
-        self.md_config.step_kernel = {"wg": 0, "wave": 1, "pm": 2}[cfg.get("step_kernel", "wg")]
+        self.step_kernel = pick_step_kernel(cfg, len(tables))
+        self.md_config.step_kernel = {"wg": 0, "wave": 1}[self.step_kernel]
         self.md_config.obs_dim = self.obs_dim
         # detector beam fans start 90 deg off the heading (SideDetector.__init__, distance_detector.py:197)
         self.side_beams = beam_table(self.n_side, np.pi / 2) if self.n_side else None

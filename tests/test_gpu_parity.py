@@ -429,7 +429,7 @@ def test_agent_policy_idm_rollout_parity(mode):
     assert (sp > 1.0).sum() > E // 2, "the agents are not driving"
 
 
-@pytest.mark.parametrize("step_kernel", ["wave", "pm"])
+@pytest.mark.parametrize("step_kernel", ["wave", "wg"])
 @pytest.mark.parametrize("name,cfg_kw,steps", [
     ("default_maps", dict(num_envs=48, num_scenarios=48, horizon=200), 260),
     ("safe", dict(num_envs=32, num_scenarios=32, accident_prob=0.8, traffic_density=0.05, crash_vehicle_done=False,

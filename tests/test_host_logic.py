@@ -387,3 +387,24 @@ def test_random_traffic_redraws_the_traffic_per_reset(cs_dist):
     assert sa[:, 0].tobytes() == sb[:, 0].tobytes()                       # the agents
     assert sa[:, 1:].tobytes() != sb[:, 1:].tobytes()                     # the traffic
     assert a.world.arrays["lanes"].tobytes() == b.world.arrays["lanes"].tobytes()
+
+
+def test_step_kernel_auto_selection(monkeypatch):
+    """config["step_kernel"] = "auto": one wave per env for a large batch on few distinct maps (the reference's default
+    num_scenarios = 1), the 4-wave workgroup otherwise; explicit choices are kept; the environment variable only steers "auto"."""
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import WAVE_KERNEL_MAX_MAPS, WAVE_KERNEL_MIN_ENVS, pick_step_kernel
+    monkeypatch.delenv("MD_STEP_KERNEL", raising=False)
+    big = make_config(dict(num_envs=4096, num_scenarios=1))
+    assert big["step_kernel"] == "auto"
+    assert pick_step_kernel(big, 1) == "wave" and pick_step_kernel(big, WAVE_KERNEL_MAX_MAPS) == "wave"
+    assert pick_step_kernel(big, WAVE_KERNEL_MAX_MAPS + 1) == "wg" and pick_step_kernel(big, 4096) == "wg"
+    small = make_config(dict(num_envs=WAVE_KERNEL_MIN_ENVS - 1, num_scenarios=1))
+    assert pick_step_kernel(small, 1) == "wg"
+    assert pick_step_kernel(make_config(dict(num_envs=4096, step_kernel="wg")), 1) == "wg"
+    assert pick_step_kernel(make_config(dict(num_envs=8, step_kernel="wave")), 8) == "wave"
+    monkeypatch.setenv("MD_STEP_KERNEL", "wave")
+    assert pick_step_kernel(small, 4096) == "wave"
+    assert pick_step_kernel(make_config(dict(num_envs=4096, step_kernel="wg")), 1) == "wg"     # an explicit choice wins
+    with pytest.raises(ValueError):
+        make_config(dict(step_kernel="pm"))

@@ -3,7 +3,7 @@
 OUT=$1; shift
 mkdir -p $OUT
 CACHE=$OUT/host_cache.pkl
-LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --host-cache $CACHE"
+LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --host-cache $CACHE"
 python bench.py --steps 100 --warmup 10 $LEAN > $OUT/base.json 2> $OUT/base.err || { tail -5 $OUT/base.err; exit 1; }
 python - <<PY
 import json; d=json.loads(open("$OUT/base.json").read().strip().splitlines()[-1]); print("base", d["ms_per_step"], d["value"], (d.get("double_buffered") or {}).get("ms_per_step"))

@@ -3,7 +3,7 @@
 OUT=$1; ENVS=$2; shift; shift
 mkdir -p $OUT
 for E in $ENVS; do
-  LEAN="--envs $E --no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --steps 100 --warmup 10 --host-cache $OUT/host_cache_$E.pkl"
+  LEAN="--envs $E --no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --sub-batches 0 --steps 100 --warmup 10 --host-cache $OUT/host_cache_$E.pkl"
   python bench.py $LEAN > $OUT/base_$E.json 2> $OUT/base_$E.err
   python - <<PY
 import json; d=json.loads(open("$OUT/base_$E.json").read().strip().splitlines()[-1]); print("$E base", d["ms_per_step"], d["value"])

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """HIP graph replay of a closed rollout loop (policy ops + md_step) for small, launch-bound batches: K steps of
 `policy(obs) -> env step` are captured once with torch.cuda.graph (md_step is launched on the capturing stream like any
 other kernel; every buffer it touches is persistent) and replayed.  Prints eager vs graph time per step and checks

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Kernel micro-bench for the roofline row of SURVEY 8(d): md_lidar alone on synthetic shape tables.
 
 E in {4096, 65536} envs, one agent each at the origin of its env, M in {4, 16, 64} OBBs uniformly in a

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Per-phase launch times of the multi-agent step (1024 roundabout envs x 40 agents, 240 beams), HIP events.
 Each md_* entry point alone (they share the stage-in / write-back cost of ~10 us)."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Per-phase launch times of the step path (each md_* entry point on its own), HIP events.
 Usage: python tools/phase_profile.py [--envs 4096] [--cap 32] [--warm 60]"""
 import argparse

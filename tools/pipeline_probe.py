@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Sub-batches in flight on separate HIP streams (double-buffered stepping): S engines of E/S envs each, every one
 on its own torch stream; one 'step' = one md_step launch per engine.  The tail of one sub-batch's launch overlaps
 the body of the other's.  Usage: python tools/pipeline_probe.py [--envs 4096] [--streams 1 2 4] [--steps 300]"""

@@ -12,7 +12,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 CACHE=$OUT/host_cache.pkl
-LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --host-cache $CACHE"
+LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --sub-batches 0 --host-cache $CACHE"
 rocprofv3 -L > $OUT/avail.txt 2>&1 || true
 python bench.py --steps 20 --warmup 5 $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err
 i=0

@@ -13,7 +13,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 CACHE=$OUT/host_cache.pkl
-LEAN="--envs $ENVS --no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --host-cache $CACHE"
+LEAN="--envs $ENVS --no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --sub-batches 0 --host-cache $CACHE"
 python bench.py --steps 20 --warmup 5 $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err
 i=0
 for SET in "VmemLatency" "SmemLatency" "LdsLatency" "InstrFetchLatency" "MeanOccupancyPerCU" "VALUBusy SALUBusy" "MemUnitStalled" "VALUUtilization"; do

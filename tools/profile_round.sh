@@ -13,7 +13,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 CACHE=$OUT/host_cache.pkl
-LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --sub-batches 0 --host-cache $CACHE"
+LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --sub-batches 0 --host-cache $CACHE"
 python bench.py --steps 300 --warmup 30 > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
 python bench.py --steps 20 --warmup 5 $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err     # writes the cache

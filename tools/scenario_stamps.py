@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Phase stamps of scenario_step_kernel (diagnostic -DMD_STAMP build) on the scenario bench workload: shader cycles per phase,
 workgroup life in microseconds, by number of reactive vehicles.  Read SHARES from it, never the run time of this build.
 

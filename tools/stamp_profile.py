@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """In-kernel phase stamps of the fused step kernel (diagnostic build, -DMD_STAMP).  Builds a separate
 library, runs the bench workload, prints per-phase cycle shares (mean / p50 / max over envs).  Read
 SHARES from it, never the run time of this build."""
@@ -24,7 +23,7 @@ WAVE_PHASES = ["stage-in", "trigger + idm (idm-first variants)", "-", "integrate
 def main():
     import numpy as np
     global PHASES
-    if os.environ.get("MD_STEP_KERNEL", "") != "wg":
+    if os.environ.get("MD_STEP_KERNEL", "wg") != "wg":
         PHASES = WAVE_PHASES     # wave_step_kernel (build with MD_EXTRA_FLAGS=-DMD_WAVE_ENVS=1: one env per workgroup)
     out = os.path.join(ROOT, "gpurun_out", "libmdstep_stamp.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Condense the rocprofv3 outputs of tools/profile_round.sh into a small text summary (what gets
 committed under profiles/)."""
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Occupancy timeline of ONE md_step launch on the bench workload (diagnostic build, -DMD_STAMP): every workgroup stamps
 s_memrealtime (100 MHz, chip-wide time base) at its start and end plus the CU it ran on.  Prints how many workgroups were
 resident over time, how long a workgroup lives, how busy the CU slots were, and the gap between a workgroup's end and the next
