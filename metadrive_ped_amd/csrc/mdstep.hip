@@ -336,39 +336,50 @@ __device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& m
     __builtin_amdgcn_wave_barrier();
 }
 
-// Side / lane-line detector as an entry point of its own (md_line_detector): one workgroup per env, one WAVE per (agent,
-// part of the map's quads) item running detector_wave above -- four agents at a time without a workgroup barrier between
-// them; with fewer than four agents the quads are split four ways instead.  One thread per beam walking all quads, the
-// first form of this kernel, took 1 ms on a scenario scene's ~1100 line pieces; a workgroup-wide compaction per agent
-// 100 us per launch on the 40-agent tollgate env.
+// Side / lane-line detector as an entry point of its own (md_line_detector).  Work items = (agent, part of the map's quads),
+// one WAVE each running detector_wave above; with four or more agents per env an item is a whole agent, with fewer the quads
+// are split four ways.  A workgroup takes FOUR consecutive items of one env (grid = n_envs x ceil(items / 4)): the 40-agent
+// tollgate batch of 512 envs is 5 120 workgroups -- the first form of this launch, one workgroup per env walking its ten
+// rounds of agents in turn, left the chip at two workgroups per CU (174 us per launch there).  One thread per beam walking
+// all quads, the very first form, took 1 ms on a scenario scene's ~1100 line pieces.
+__device__ __host__ inline int detector_parts(int A) { return (A >= kBlock / 64) ? 1 : kBlock / 64; }
+__device__ __host__ inline int detector_groups(int A) { return (A * detector_parts(A) + kBlock / 64 - 1) / (kBlock / 64); }
+
 __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdState s, MdConfig c,
                                                                const float* __restrict__ beam_cs, int n_beams,
                                                                float range, uint32_t kind_mask, float* out,
                                                                int out_stride, int out_offset) {
     extern __shared__ int l_ld[];
+    constexpr int kW = kBlock / 64;
     const int A = c.agents_per_env;
-    int* l_best = l_ld;                                              // [A * n_beams] bit patterns of the closest fractions
-    float* l_bm = reinterpret_cast<float*>(l_ld + A * n_beams);      // [n_beams][2] the beam table
-    int* l_pairs = reinterpret_cast<int*>(l_bm + 2 * n_beams);       // [kBlock / 64][kDetPairs]
-    const int e = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int parts = detector_parts(A), groups = detector_groups(A);
+    int* l_best = l_ld;                                              // [kW * n_beams] bit patterns of the closest fractions
+    float* l_bm = reinterpret_cast<float*>(l_ld + kW * n_beams);     // [n_beams][2] the beam table
+    int* l_pairs = reinterpret_cast<int*>(l_bm + 2 * n_beams);       // [kW][kDetPairs]
+    const int e = blockIdx.x / groups, grp = blockIdx.x - e * groups;
+    if (e >= c.n_envs) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = w.env_map[e];
     const int q0 = w.quad_off[m], q1 = w.quad_off[m + 1];
-    for (int it = tid; it < A * n_beams; it += kBlock) l_best[it] = __float_as_int(1.0f);
+    const int a_first = (grp * kW) / parts;                          // first agent this workgroup serves
+    const int n_here = min(A - a_first, kW / parts);                 // agents it serves (4, or 1 when the quads are split)
+    for (int it = tid; it < n_here * n_beams; it += kBlock) l_best[it] = __float_as_int(1.0f);
     for (int it = tid; it < 2 * n_beams; it += kBlock) l_bm[it] = beam_cs[it];
     __syncthreads();
-    const int parts = (A >= kBlock / 64) ? 1 : kBlock / 64;
     const int per = (q1 - q0 + parts - 1) / parts;
-    for (int it = wave; it < A * parts; it += kBlock / 64) {
+    const int it = grp * kW + wave;
+    if (it < A * parts) {
         const int a = it / parts, part = it - a * parts;
         const MdShape me = s.shape[e * c.cap + a];
-        if (!md_present(me.flags)) continue;
-        const int qa = q0 + part * per, qb = min(qa + per, q1);
-        detector_wave(w, me, qa, qb, l_bm, n_beams, range, kind_mask, l_best + a * n_beams, l_pairs + wave * kDetPairs, lane);
+        if (md_present(me.flags)) {
+            const int qa = q0 + part * per, qb = min(qa + per, q1);
+            detector_wave(w, me, qa, qb, l_bm, n_beams, range, kind_mask, l_best + (a - a_first) * n_beams, l_pairs + wave * kDetPairs, lane);
+        }
     }
     __syncthreads();
-    for (int it = tid; it < A * n_beams; it += kBlock) {
-        const int a = it / n_beams, i = it - a * n_beams;
-        out[(size_t)(e * A + a) * out_stride + out_offset + i] = __int_as_float(l_best[it]);
+    for (int k = tid; k < n_here * n_beams; k += kBlock) {
+        const int al = k / n_beams, i = k - al * n_beams;
+        out[(size_t)(e * A + a_first + al) * out_stride + out_offset + i] = __int_as_float(l_best[k]);
     }
 }
 
@@ -2889,7 +2900,7 @@ __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, co
                  out_offset, (double)range);
         return MD_EINVAL;
     }
-    const size_t lds_ld = ((size_t)c->agents_per_env * (size_t)n_beams + 2 * (size_t)n_beams + (kBlock / 64) * (size_t)kDetPairs) * sizeof(int);
+    const size_t lds_ld = ((kBlock / 64) * (size_t)n_beams + 2 * (size_t)n_beams + (kBlock / 64) * (size_t)kDetPairs) * sizeof(int);
     if (n_beams > 255) {   // a (quad, beam) pair keeps the beam in eight bits
         snprintf(g_err, sizeof g_err, "md_line_detector: n_beams=%d > 255", n_beams);
         return MD_EINVAL;
@@ -2898,7 +2909,7 @@ __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, co
         snprintf(g_err, sizeof g_err, "md_line_detector: %d agents x %d beams do not fit the LDS", c->agents_per_env, n_beams);
         return MD_EINVAL;
     }
-    hipLaunchKernelGGL(line_detector_kernel, dim3(c->n_envs), dim3(kBlock), lds_ld, (hipStream_t)stream, *w, *s, *c, beam_cs,
+    hipLaunchKernelGGL(line_detector_kernel, dim3(c->n_envs * detector_groups(c->agents_per_env)), dim3(kBlock), lds_ld, (hipStream_t)stream, *w, *s, *c, beam_cs,
                        n_beams, range, kind_mask, out, out_stride, out_offset);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
