@@ -67,7 +67,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     random_lane_num=False,
     map_config=dict(type="block_num", config=None, lane_width=3.5, lane_num=3, exit_length=50,
                     neck_lane_num=1, neck_length=20,    # multi-agent bottleneck map only (marl_bottleneck.py:13)
-                    toll_lane_num=8, toll_length=10),   # multi-agent tollgate map only (marl_tollgate.py:19)
+                    toll_lane_num=8, toll_length=10,    # multi-agent tollgate map only (marl_tollgate.py:19)
+                    radius=None),                       # multi-agent intersection maps only (tinyinter.py:349-351)
     store_map=True,
     traffic_density=0.1,
     need_inverse_traffic=False,

@@ -65,7 +65,8 @@ def _build_marl(cfg, scene_cfg, uniq):
                            toll_lane_num=mc["toll_lane_num"], toll_length=mc["toll_length"])
     else:
         cls = dict(roundabout=MARoundaboutMap, intersection=MAIntersectionMap)[kind]
-        pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
+        kw = dict(radius=mc.get("radius")) if kind == "intersection" else {}
+        pg = cls(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"], **kw)
     mt = MapTables(pg)
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
     fixed = FIXED_DESTINATION[kind]
@@ -78,8 +79,12 @@ def _build_marl(cfg, scene_cfg, uniq):
         roads, dests = parking_lot_roads(cfg["parking_space_num"])
         assert [tuple(r) for r in pg.parking_space] == [(d[:-2] + "1_", d) for d in dests[:cfg["parking_space_num"]]]
         parking = (len(PARKING_IN_ROADS), cfg["parking_space_num"], dests)
+    # MAIntersectionSpawnManager(disable_u_turn = lane_num < 2) (marl_intersection.py:73-85, :104): on the one-lane intersection a
+    # vehicle is never sent back out of the arm it came in by
+    no_u_turn = kind == "intersection" and mc["lane_num"] < 2
+    sc_cfg["exclude_own_road"] = no_u_turn
     scenes = {s: RoundaboutScene(s, mt, sc_cfg, roads, fixed, parking) for s in uniq}
-    return mt, scenes, spawn_tables(mt, roads, mc["lane_num"], fixed, dests)
+    return mt, scenes, spawn_tables(mt, roads, mc["lane_num"], fixed, dests, exclude_own_road=no_u_turn)
 
 
 def _user_spawn_roads(cfg, mt):

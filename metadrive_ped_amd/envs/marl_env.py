@@ -195,6 +195,33 @@ class BatchedMultiAgentIntersectionEnv(BatchedMultiAgentRoundaboutEnv):
         super().__init__(merged)
 
 
+class BatchedMultiAgentTinyInter(BatchedMultiAgentIntersectionEnv):
+    """MultiAgentTinyInter (envs/marl_envs/tinyinter.py:328-420): 8 agents on a ONE-lane 4-way intersection (lane width 4 m, arms
+    30 m, no U-turns: a vehicle never gets the arm it came in by as its destination), success reward 10 and penalties 10, and
+    finished vehicles leave the road at once (ignore_delay_done=True: MixedIDMAgentManager._finish, :262-268, i.e. no
+    delay_done corpse).  `map_config["radius"]` sets the intersection's radius.  The env's two optional extras are not built and
+    are refused by name: `num_RL_agents < num_agents` (the rest driven by TinyInterRuleBasedPolicy, :219-247) and
+    `use_communication_obs=True` (CommunicationObservation, :14-216)."""
+    MAP_DEFAULTS = dict(marl_map="intersection", num_agents=8, success_reward=10.0, out_of_road_penalty=10.0, crash_vehicle_penalty=10.0,
+                        crash_object_penalty=10.0, map_config=dict(exit_length=30, lane_num=1, lane_width=4.0, radius=None))
+    TINY_KEYS = dict(num_RL_agents=None, ignore_delay_done=True, target_speed=10, use_communication_obs=False)
+
+    def __init__(self, config=None):
+        config = dict(config or {})
+        tiny = {k: config.pop(k, v) for k, v in self.TINY_KEYS.items()}
+        merged = _deep_update(dict(num_agents=self.MAP_DEFAULTS["num_agents"]), config)
+        n_rl = merged["num_agents"] if tiny["num_RL_agents"] is None else tiny["num_RL_agents"]
+        if n_rl != merged["num_agents"]:
+            raise NotImplementedError("MultiAgentTinyInter with num_RL_agents ({}) < num_agents ({}): the rule-based agents "
+                                      "(TinyInterRuleBasedPolicy) are not built".format(n_rl, merged["num_agents"]))
+        if tiny["use_communication_obs"]:
+            raise NotImplementedError("MultiAgentTinyInter: use_communication_obs=True (CommunicationObservation) is not built")
+        if tiny["ignore_delay_done"]:
+            config["delay_done"] = 0          # the finished vehicle is removed in the step it finishes
+        self.tiny_config = dict(tiny, num_RL_agents=n_rl)
+        super().__init__(config)
+
+
 class BatchedMultiAgentBottleneckEnv(BatchedMultiAgentRoundaboutEnv):
     """MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py:10-140): 20 agents, 4 lanes narrowing to 1 and
     widening again, traffic in both directions, side (4 beams) and lane-line (4 beams) detectors in the observation.

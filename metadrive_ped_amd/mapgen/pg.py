@@ -15,8 +15,9 @@ Block types built: FirstPGBlock "I", Straight "S", Curve "C", Roundabout "O", St
 InRampOnStraight "r", OutRampOnStraight "R" -- the whole default BLOCK_TYPE_DISTRIBUTION_V2 -- and Merge "y", Split "Y",
 Bidirection "B", ParkingLot "P", TollGate "$" (pgblock/first_block.py, straight.py, curve.py, roundabout.py,
 intersection.py, std_intersection.py, t_intersection.py, std_t_intersection.py, ramp.py, bottleneck.py, bidirection.py,
-parking_lot.py, tollgate.py).  InFork / OutFork are not built (InFork raises in the reference itself, pgblock/fork.py:28):
-sampling one raises NotImplementedError naming it, so a config never silently changes the map distribution.
+parking_lot.py, tollgate.py).  InFork "f" / OutFork "F" behave as in the reference: both raise ValueError("Bug exists in this
+block, Recommend to use Ramp") as the first statement of their construction (pgblock/fork.py:27, :172; probability 0 in the
+default distribution), pinned by tests/golden/fork_blocks.json.
 
 Road-crossing check: check_lane_on_road (utils/pg/utils.py:36-71) with the bounding-box pre-filter
 of get_lanes_bounding_box (:74-147).
@@ -1262,19 +1263,19 @@ class MABidirectionMap:
 
 
 class MAIntersectionMap:
-    """FirstPGBlock + one InterSection (seed 1, U-turns on): the map of MultiAgentIntersectionEnv
-    (envs/marl_envs/marl_intersection.py:27-70)."""
-    def __init__(self, lane_num=2, lane_width=3.5, exit_length=60):
-        if lane_num < 2:
-            raise NotImplementedError("the one-lane multi-agent intersection (U-turns off, spawn road excluded from the "
-                                      "destinations) is not built")
+    """FirstPGBlock + one InterSection (seed 1): the map of MultiAgentIntersectionEnv and of MultiAgentTinyInter
+    (envs/marl_envs/marl_intersection.py:27-70).  U-turns exist with two or more lanes per direction only (:62-66: "We disable
+    U turn in TinyInter environment"); `radius` (map_config["radius"], :48-51) overrides the radius the block samples."""
+    def __init__(self, lane_num=2, lane_width=3.5, exit_length=60, radius=None):
         self.seed = 0
         self.lane_num, self.lane_width = lane_num, lane_width
         self.net = RoadNet()
         first = FirstBlock(self.net, lane_width, lane_num, exit_length)
         x = InterSection(1, list(first.sockets.values())[0], self.net, 1)
         x.EXIT_PART_LENGTH = exit_length
-        x.u_turn = True
+        if radius:
+            x.radius = radius
+        x.u_turn = lane_num > 1
         x.construct()
         self.blocks = [first, x]
         for a, b, lanes in self.net.roads():
@@ -1321,6 +1322,10 @@ class PGMap:
         socket_id = self.rng.choice(list(last.sockets.keys()))
         seed = int(self.rng.randint(0, 10000))
         name = str(name)
+        if name in ("InFork", "OutFork"):
+            # the reference's own behaviour: both fork blocks raise at the top of _try_plug_into_previous_block
+            # (component/pgblock/fork.py:27, :172), before any geometry; everything below that line is unreachable there
+            raise ValueError("Bug exists in this block, Recommend to use Ramp")
         if name not in BLOCK_CLASSES:
             raise NotImplementedError(
                 "PG block type '{}' (id '{}') is not built yet in metadrive_ped_amd.mapgen; restrict "

@@ -295,7 +295,7 @@ StaticTables._build_grid = MapTables._build_grid
 RESPAWN_REGION_LONGITUDE = 8.0  # manager/spawn_manager.py:28
 
 
-def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False, dests=None):
+def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False, dests=None, exclude_own_road=False):
     """Respawn places (slot 0 of every spawn road x lane) and, for each, the route to every destination
     (end node of the reversed spawn roads): SpawnManager._auto_fill_spawn_roads_randomly /
     get_available_respawn_places (manager/spawn_manager.py:123-209), RoundaboutSpawnManager.
@@ -306,8 +306,13 @@ def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False, dests=None)
         dests = [negate_road(*r)[1] for r in spawn_roads]
     if fixed_destination:   # one destination per place: the default of NodeNetworkNavigation.reset
         dests = [None]
+    all_dests = list(dests)
     places, lanes, routes, meta = [], [], [], []
     for road in spawn_roads:
+        if exclude_own_road:
+            # disable_u_turn (marl_intersection.py:80-82): the end roads are the spawn roads but the vehicle's own, in order; every
+            # place keeps len(spawn_roads) - 1 destinations and the device draws an index among them
+            dests = [d for r, d in zip(spawn_roads, all_dests) if tuple(r) != tuple(road)]
         for li in range(lane_num):
             lane = pg.net.lanes(*road)[li]
             long = RESPAWN_REGION_LONGITUDE / 2
@@ -323,7 +328,7 @@ def spawn_tables(mt, spawn_roads, lane_num, fixed_destination=False, dests=None)
                 meta.append([n, fin])
     return dict(spawn_place=np.asarray(places, np.float32), spawn_lane=np.asarray(lanes, np.int32),
                 spawn_route=np.asarray(routes, np.int32), spawn_route_meta=np.asarray(meta, np.int32), n_dest=len(dests),
-                dests=dests)
+                dests=all_dests)
 
 
 def destination_for(pg_map, seed, lane_index):

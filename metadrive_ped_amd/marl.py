@@ -131,6 +131,9 @@ class RoundaboutScene:
             elif fixed_destination:
                 from metadrive_ped_amd.mapgen.tables import destination_for
                 dest = destination_for(pg, seed, (road[0], road[1], li))
+            elif cfg.get("exclude_own_road"):     # MAIntersectionSpawnManager with disable_u_turn (marl_intersection.py:78-85)
+                others = [d_ for r_, d_ in zip(ROUNDABOUT_SPAWN_ROADS, dests) if tuple(r_) != tuple(road)]
+                dest = others[int(rng.randint(len(others)))]
             else:
                 dest = dests[int(rng.randint(len(dests)))]
             pos = lane.position(long, lat)

@@ -439,6 +439,56 @@ def section_ma_intersection():
                                       config={k: float(v) for k, v in dict(blk.get_config()).items()}))
 
 
+def section_ma_tinyinter():
+    """Map of MultiAgentTinyInter (envs/marl_envs/tinyinter.py:328-420): MAIntersectionMap._generate (marl_intersection.py:27-70) with
+    the tiny env's map_config -- ONE lane of 4 m per direction, arms of 30 m, U-turns off -- for the sampled radius and for
+    map_config["radius"] = 50; the destinations MAIntersectionSpawnManager(disable_u_turn=True).update_destination_for can draw for
+    every spawn road (:78-85: the spawn roads but the vehicle's own), the routes to them, and the env's default config values."""
+    from metadrive.component.pgblock.first_block import FirstPGBlock
+    from metadrive.component.pgblock.intersection import InterSection
+    from metadrive.component.road_network import Road
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_intersection import MAIntersectionConfig
+    from metadrive.manager.spawn_manager import SpawnManager
+    try:
+        from metadrive.envs.marl_envs.tinyinter import MultiAgentTinyInter
+        dc = MultiAgentTinyInter.default_config()
+        defaults = dict(num_agents=int(dc["num_agents"]), num_RL_agents=int(dc["num_RL_agents"]), success_reward=float(dc["success_reward"]),
+                        out_of_road_penalty=float(dc["out_of_road_penalty"]), crash_vehicle_penalty=float(dc["crash_vehicle_penalty"]),
+                        crash_object_penalty=float(dc["crash_object_penalty"]), ignore_delay_done=bool(dc["ignore_delay_done"]),
+                        exit_length=float(dc["map_config"]["exit_length"]), lane_num=int(dc["map_config"]["lane_num"]),
+                        lane_width=float(dc["map_config"]["lane_width"]), delay_done=int(dc["delay_done"]),
+                        use_communication_obs=bool(dc["use_communication_obs"]), target_speed=float(dc["target_speed"]))
+    except Exception as ex:       # noqa: BLE001
+        defaults = dict(unavailable="%s: %s" % (type(ex).__name__, ex))
+    maps = []
+    for radius in (None, 50.0):
+        net = NodeRoadNetwork()
+        first = FirstPGBlock(net, 4.0, 1, MagicMock(), MagicMock(), length=30)
+        InterSection.EXIT_PART_LENGTH = 30
+        kw = dict(radius=radius) if radius else {}
+        blk = InterSection(1, first.get_socket(index=0), net, random_seed=1, ignore_intersection_checking=False, **kw)
+        blk.enable_u_turn(False)
+        ok = blk.construct_block(MagicMock(), MagicMock())
+        InterSection.EXIT_PART_LENGTH = 35
+        roads = []
+        for f, td in net.graph.items():
+            for t, lanes in td.items():
+                roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+        routes = []
+        for sr in MAIntersectionConfig["spawn_roads"]:
+            end_roads = [r for r in MAIntersectionConfig["spawn_roads"] if Road(sr.start_node, sr.end_node) != r]   # disable_u_turn
+            for er in end_roads:
+                dest = (-er).end_node
+                routes.append(dict(start=[sr.start_node, sr.end_node], dest=dest,
+                                   path=net.shortest_path((sr.start_node, sr.end_node, 0), dest)))
+        maps.append(dict(radius=radius, used_radius=float(blk.radius), no_cross=bool(ok), roads=roads, routes=routes,
+                         config={k: float(v) for k, v in dict(blk.get_config()).items()}))
+    dump("ma_tinyinter.json", dict(maps=maps, spawn_roads=[[r.start_node, r.end_node] for r in MAIntersectionConfig["spawn_roads"]],
+                                   max_capacity=int(SpawnManager.max_capacity(MAIntersectionConfig["spawn_roads"], 30, 1)),
+                                   defaults=defaults))
+
+
 def section_ma_bottleneck():
     """Map of MultiAgentBottleneckEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 20 m)
     + Split (back to 4, exit 60 m) as MABottleneckMap._generate builds it (marl_bottleneck.py:28-69)."""
@@ -1533,6 +1583,20 @@ def section_traffic_spawn():
     dump("traffic_spawn.json", dict(engine_draws_before=ENGINE_DRAWS_BEFORE, cases=cases))
 
 
+def section_fork_blocks():
+    """InFork 'f' / OutFork 'F' (component/pgblock/fork.py): what happens when a block sequence names one.  Both raise as the first
+    statement of _try_plug_into_previous_block (:27, :172); the fixture holds the exception the reference's own BIG run ends with."""
+    from metadrive.component.algorithm.blocks_prob_dist import PGBlockDistConfig
+    cases = []
+    for seq in ("F", "f", "SF", "Cf"):
+        try:
+            build_reference_map(600, 3, 3.5, 50, "block_sequence", seq, PGBlockDistConfig)
+            cases.append(dict(sequence=seq, raised=None))
+        except Exception as ex:       # noqa: BLE001 -- the class and text are what is recorded
+            cases.append(dict(sequence=seq, raised=type(ex).__name__, message=str(ex)))
+    dump("fork_blocks.json", dict(cases=cases))
+
+
 def section_pg_maps_v2():
     """PG topology with the reference's DEFAULT block distribution (BLOCK_TYPE_DISTRIBUTION_V2: curves,
     straights, in/out ramps, X and T intersections, roundabouts) -- what `MetaDriveEnv(map=3)` builds."""
@@ -1660,7 +1724,7 @@ def section_scenario_export():
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn,
-                       traffic_spawn=section_traffic_spawn)
+                       traffic_spawn=section_traffic_spawn, fork_blocks=section_fork_blocks, ma_tinyinter=section_ma_tinyinter)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

@@ -189,8 +189,6 @@ def test_intersection_map_equals_reference():
         assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
     assert g["max_capacity"] == 48 and g["num_agents"] == 30
     assert m.blocks[1].config["radius"] == g["config"]["radius"]
-    with pytest.raises(NotImplementedError):
-        MAIntersectionMap(lane_num=1)
 
 
 def test_intersection_lifecycle_on_oracle():
@@ -239,6 +237,116 @@ def test_intersection_rollout_parity_gpu():
         if t % 25 == 0:
             assert_state_equal(eng.download_state(), orc.state, where="intersection step %d" % t)
     assert_state_equal(eng.download_state(), orc.state, where="intersection final")
+    assert (orc.state["next_agent_id"] > A).all()
+
+
+# ---- MultiAgentTinyInter (envs/marl_envs/tinyinter.py:328-420): the one-lane intersection ---------------------------
+def _tiny_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentTinyInter
+    base = dict(num_envs=3, num_scenarios=3)
+    base.update(kw)
+    return BatchedMultiAgentTinyInter(base).config
+
+
+def test_tinyinter_map_defaults_and_destinations_equal_reference():
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.mapgen.pg import MAIntersectionMap, negate_road
+    from metadrive_ped_amd.marl import INTERSECTION_SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_tinyinter.json")) as f:
+        g = json.load(f)
+    d = g["defaults"]
+    cfg = _tiny_cfg()
+    assert cfg["num_agents"] == d["num_agents"] == d["num_RL_agents"] == g["max_capacity"] == 8
+    for k in ("success_reward", "out_of_road_penalty", "crash_vehicle_penalty", "crash_object_penalty"):
+        assert cfg[k] == d[k] == 10.0, k
+    mc = cfg["map_config"]
+    assert (mc["exit_length"], mc["lane_num"], mc["lane_width"]) == (d["exit_length"], d["lane_num"], d["lane_width"]) == (30, 1, 4.0)
+    assert d["ignore_delay_done"] and d["delay_done"] == 25 and cfg["delay_done"] == 0    # finished vehicles leave at once
+    assert [list(r) for r in INTERSECTION_SPAWN_ROADS] == g["spawn_roads"]
+    for ref in g["maps"]:
+        m = MAIntersectionMap(lane_num=1, lane_width=4.0, exit_length=30, radius=ref["radius"])
+        assert ref["no_cross"] and m.blocks[1].radius == ref["used_radius"]
+        roads = list(m.net.roads())
+        assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in ref["roads"]]          # no U-turn roads
+        for (a, b, lanes), rr in zip(roads, ref["roads"]):
+            assert len(lanes) == len(rr["lanes"])
+            for l, rl in zip(lanes, rr["lanes"]):
+                assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+                np.testing.assert_allclose([l.length, l.width, *l.start, *l.end], [rl["length"], rl["width"], *rl["start"], *rl["end"]], atol=1e-9)
+        for r in ref["routes"]:
+            assert m.bfs_route(r["start"][0], r["dest"]) == r["path"]
+    # the destinations a place can be given: the other three arms, in the spawn roads' order (the device draws an index)
+    host = HostScene(_tiny_cfg(num_envs=2, num_scenarios=2, build_workers=1))
+    t = host.map_tables[0]
+    assert host.spawn["n_dest"] == 3
+    routes = host.world.arrays["spawn_route"].reshape(len(INTERSECTION_SPAWN_ROADS), 1, 3, 2, abi.MD_ROUTE_LEN)
+    meta = host.world.arrays["spawn_route_meta"].reshape(len(INTERSECTION_SPAWN_ROADS), 1, 3, 2)
+    want = [r for r in g["maps"][0]["routes"]]
+    k = 0
+    for i, road in enumerate(INTERSECTION_SPAWN_ROADS):
+        for j in range(3):
+            ref = want[k]
+            k += 1
+            assert ref["start"] == list(road) and ref["dest"] != negate_road(*road)[1]
+            n = int(meta[i, 0, j, 0])
+            assert [t.node_names[x] for x in routes[i, 0, j, 0, :n]] == ref["path"]
+    # reset-time destinations follow the same rule: nobody is sent back out of its own arm
+    for sc in host.scenes.values():
+        for a in range(host.A):
+            n = int(sc.nav[a]["route_len"])
+            first, last = t.node_names[sc.route_nodes[a, 0]], t.node_names[sc.route_nodes[a, n - 1]]
+            own = [negate_road(*r)[1] for r in INTERSECTION_SPAWN_ROADS if r[0] == first][0]
+            assert last != own
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentTinyInter
+    with pytest.raises(NotImplementedError, match="num_RL_agents"):
+        BatchedMultiAgentTinyInter(dict(num_envs=1, num_RL_agents=4))
+    with pytest.raises(NotImplementedError, match="use_communication_obs"):
+        BatchedMultiAgentTinyInter(dict(num_envs=1, use_communication_obs=True))
+
+
+def test_tinyinter_lifecycle_on_oracle():
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 3, 8
+    host = HostScene(_tiny_cfg(num_envs=E, num_scenarios=E))
+    assert host.cap == A and host.obs_dim == 19 + 72
+    o = ob.OracleWorld(host)
+    o.reset()
+    assert (_counts(o.state, E)[0] == A).all()
+    rng = np.random.RandomState(3)
+    arrived = 0
+    for t in range(500):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.5
+        a[..., 0] = rng.uniform(-0.15, 0.15, (E, A))
+        o.step(a)
+        act, dy = _counts(o.state, E)
+        assert (dy == 0).all() and (act <= A).all()            # ignore_delay_done: nobody waits on the road as a corpse
+        arrived += int(((o.state["flags"].reshape(E, -1)[:, :A] & abi.FL_ARRIVE_DEST) != 0).sum())
+    assert (o.state["next_agent_id"] > A).all()               # vehicles finished and new ones entered
+    assert (o.state["reward"] == 10.0).any() or arrived > 0    # success_reward = 10
+
+
+@pytest.mark.gpu
+def test_tinyinter_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 12, 8
+    eng = BatchedEngine(_tiny_cfg(num_envs=E, num_scenarios=E, map_config=dict(radius=20.0)))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="tinyinter reset")
+    rng = np.random.RandomState(18)
+    for t in range(300):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.6
+        a[..., 0] = rng.uniform(-0.3, 0.3, (E, A))
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="tinyinter step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="tinyinter final")
     assert (orc.state["next_agent_id"] > A).all()
 
 
