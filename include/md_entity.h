@@ -48,6 +48,7 @@ MD_HD MdState md_env_view(const MdState* g, const MdConfig* c, int e) {
     v.pid0 = g->pid0 ? g->pid0 + b : 0;
     v.param0 = g->param0 ? g->param0 + b : 0;
     v.done_out = g->done_out ? g->done_out + 4 * a : 0;
+    v.idle_ring = g->idle_ring ? g->idle_ring + a * MD_IDLE_WINDOW : 0;
     v.route_nodes0 = g->route_nodes0 ? g->route_nodes0 + b * MD_ROUTE_LEN : 0;
     v.route_roads0 = g->route_roads0 ? g->route_roads0 + b * MD_ROUTE_LEN : 0;
     v.final_lane0 = g->final_lane0 ? g->final_lane0 + b : 0;
@@ -336,6 +337,10 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
     }
     if (c->is_multi_agent && c->ma_kind == MD_MA_PARKING_LOT) /* MultiAgentParkingLotEnv._is_out_of_road (marl_parking_lot.py:257-259) */
         out_of_road = !(fl & MD_FL_ON_LANE) || (fl & (MD_FL_ON_YELLOW_CONT | MD_FL_CRASH_SIDEWALK));
+    const int racing = c->is_multi_agent && c->ma_kind == MD_MA_RACING;
+    if (racing) /* MultiAgentRacingEnv._is_out_of_road (marl_racing_env.py:354-359): the map is fenced by guardrails; only a vehicle
+                 * more than 5 m BEHIND the start of the lane it is on counts (longitudinal on vehicle.lane) */
+        out_of_road = ls < -5.0f;
     if (arrive) fl |= MD_FL_ARRIVE_DEST;
     if (out_of_road) fl |= MD_FL_OUT_OF_ROAD;
 
@@ -356,10 +361,29 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
         reward += c->speed_reward * (speed_kmh / P->max_speed_kmh) * positive_road;
     }
     float step_reward = reward;
+    int idle = 0;
+    if (racing && !just_reset && s->idle_ring) {
+        /* movement_between_steps[agent].append(abs(longitudinal_now - longitudinal_last)) on a deque(maxlen=100), and
+         * _is_idle: 100 entries whose sum (oldest first) is below 0.1 m (marl_racing_env.py:392-398,415) */
+        float* ring = s->idle_ring + (size_t)ai * MD_IDLE_WINDOW;
+        int cnt = nav->toll_state;
+        ring[cnt % MD_IDLE_WINDOW] = md_fabs(long_now - long_last);
+        cnt += 1;
+        if (cnt >= 2 * MD_IDLE_WINDOW) cnt -= MD_IDLE_WINDOW;   /* keeps (cnt mod window) and cnt >= window */
+        nav->toll_state = cnt;
+        if (cnt >= MD_IDLE_WINDOW) {
+            float sum = 0.0f;
+            for (int i = 0; i < MD_IDLE_WINDOW; ++i) sum += ring[(cnt + i) % MD_IDLE_WINDOW];
+            idle = sum < 0.1f;
+        }
+    }
     if (arrive) reward = c->success_reward;
     else if (out_of_road) reward = -c->out_of_road_penalty;
     else if (fl & MD_FL_CRASH_VEHICLE) reward = -c->crash_vehicle_penalty;
-    else if (fl & MD_FL_CRASH_OBJECT) reward = -c->crash_object_penalty;
+    else if (racing) { /* marl_racing_env.py:432-439: the sidewalk (guardrail) and idling are penalised, objects are not */
+        if (fl & MD_FL_CRASH_SIDEWALK) reward = -c->crash_sidewalk_penalty;
+        else if (idle) reward = -c->idle_penalty;
+    } else if (fl & MD_FL_CRASH_OBJECT) reward = -c->crash_object_penalty;
 
     /* ---- cost (metadrive_env.py:201-211) ---- */
     float cost = 0.0f;
@@ -384,6 +408,11 @@ MD_HD void md_observe_combine(const MdObsCtx* k, const MdState* s, const MdConfi
         if (toll) crash = (fl & MD_FL_CRASH_VEHICLE) != 0; /* marl_tollgate.py:254: only a vehicle crash is taken back */
         if (crash && !c->crash_done && !(arrive || out_of_road)) done = 0;
         if (out_of_road && !c->out_of_road_done && !arrive) done = 0;
+    }
+    if (racing && !max_step) { /* MultiAgentRacingEnv.done_function (marl_racing_env.py:361-383) */
+        if (idle) fl |= MD_FL_IDLE;
+        if (idle && c->idle_done) done = 1;
+        if ((fl & MD_FL_CRASH_SIDEWALK) && c->crash_sidewalk_done) done = 1;
     }
     if (toll && !max_step && nav->toll_entry && nav->toll_exit && nav->toll_exit - nav->toll_entry < c->min_pass_steps) {
         /* left the toll block sooner than min_pass_steps after entering it (marl_tollgate.py:254-259): done, reported as

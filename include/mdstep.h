@@ -80,6 +80,7 @@ extern "C" {
 #define MD_FL_MAX_STEP 0x2000
 #define MD_FL_TERMINATED 0x4000
 #define MD_FL_TRUNCATED 0x8000
+#define MD_FL_IDLE 0x10000   /* racing env: moved < 0.1 m along its lane over the last 100 steps (beyond the 16 bits MdState.done_out carries) */
 
 /* ---- static quad kinds (MdWorld.quad_kind) ------------------------------------------------ */
 #define MD_Q_LINE_WHITE_CONT 1   /* LINE_SOLID_SINGLE_WHITE  block/base_block.py:487-492         */
@@ -222,6 +223,8 @@ typedef struct MdSeg {
 #define MD_MA_DEFAULT 0      /* MdConfig.ma_kind */
 #define MD_MA_TOLLGATE 1
 #define MD_MA_PARKING_LOT 2
+#define MD_MA_RACING 3
+#define MD_IDLE_WINDOW 100     /* MultiAgentRacingEnv: steps of movement an agent is judged idle over (marl_racing_env.py:342,392-398) */
 
 /* Static world: everything fixed between resets. */
 typedef struct MdWorld {
@@ -364,6 +367,10 @@ typedef struct MdState {
     MdSeg* route_segs;
     float* route_verts;
     float* route_aux;
+    /* MultiAgentRacingEnv only (NULL elsewhere): [n_envs * agents_per_env][MD_IDLE_WINDOW] the |longitudinal progress| of the
+     * agent's last steps, a ring written at index (MdNav.toll_state mod MD_IDLE_WINDOW); MdNav.toll_state counts the entries
+     * (movement_between_steps, marl_racing_env.py:342,415) */
+    float* idle_ring;
 } MdState;
 
 typedef struct MdConfig {
@@ -426,7 +433,8 @@ typedef struct MdConfig {
     /* which multi-agent env's rules md_observe applies (is_multi_agent only): 0 = MultiAgentMetaDrive and the envs that keep
      * its reward / done / observation, 1 = MultiAgentTollgateEnv (envs/marl_envs/marl_tollgate.py:181-266: no navigation
      * dims, two toll dims after the lidar cloud, overspeed penalty inside the toll block, minimum stay), 2 =
-     * MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py) */
+     * MultiAgentParkingLotEnv (envs/marl_envs/marl_parking_lot.py), 3 = MultiAgentRacingEnv (envs/marl_envs/marl_racing_env.py:
+     * 338-441: out of road = more than 5 m behind the start of its lane, idle detection, sidewalk / idle penalties) */
     int32_t ma_kind;
     int32_t min_pass_steps;    /* vehicle_config.min_pass_steps (marl_tollgate.py:28)                     */
     float overspeed_penalty;   /* marl_tollgate.py:25                                                     */
@@ -437,6 +445,9 @@ typedef struct MdConfig {
     int32_t route_vert_cap;    /* vertices per slot in MdState.route_verts (>= 2 * ceil(longest run's path length + 1) + 4) */
     int32_t ego_replay;        /* scenario mode, agent_policy = ReplayEgoCarPolicy (policy/replay_policy.py:70-82): the agent is put on
                                 * frame k of the SDC track (MdState.track_* slot 0) instead of being integrated; actions are ignored */
+    /* MultiAgentRacingEnv (ma_kind 3; RACING_CONFIG, marl_racing_env.py:46-63) */
+    float crash_sidewalk_penalty, idle_penalty;
+    int32_t idle_done, crash_sidewalk_done;
 } MdConfig;
 
 /* ---- entry points ------------------------------------------------------------------------- */

@@ -62,7 +62,9 @@ ROAD_DT = np.dtype([("first_lane", i4), ("n_lanes", i4), ("start_node", i4), ("e
                     ("block", i4), ("block_kind", i4), ("spare", i4)])
 SEG_DT = np.dtype([("sx", f4), ("sy", f4), ("ex", f4), ("ey", f4), ("dx", f4), ("dy", f4), ("len", f4), ("heading", f4),
                    ("cum", f4), ("spare", f4, (3, ))])
-MA_DEFAULT, MA_TOLLGATE, MA_PARKING_LOT = 0, 1, 2
+MA_DEFAULT, MA_TOLLGATE, MA_PARKING_LOT, MA_RACING = 0, 1, 2, 3
+MD_IDLE_WINDOW = 100
+FL_IDLE = 0x10000
 TM_MOVING, TM_LENGTH_OK, TM_NEVER = 1, 2, 4
 SC_ABSENT, SC_REPLAY, SC_IDM, SC_ARRIVED = 0, 1, 2, 3
 GRID_DT = np.dtype([("x0", f4), ("y0", f4), ("inv_cell", f4), ("nx", i4), ("ny", i4), ("cell_base", i4),
@@ -102,7 +104,7 @@ class MdState(C.Structure):
         ("scratch", P),
         ("param0", P),
         ("done_out", P),
-        ("route_n", P), ("route_segs", P), ("route_verts", P), ("route_aux", P),
+        ("route_n", P), ("route_segs", P), ("route_verts", P), ("route_aux", P), ("idle_ring", P),
     ]
 
 
@@ -138,6 +140,7 @@ class MdConfig(C.Structure):
         ("ma_kind", C.c_int32), ("min_pass_steps", C.c_int32), ("overspeed_penalty", C.c_float), ("n_parking", C.c_int32),
         ("side_range", C.c_float), ("ll_range", C.c_float), ("side_mask", C.c_uint32), ("ll_mask", C.c_uint32),
         ("route_seg_cap", C.c_int32), ("route_vert_cap", C.c_int32), ("ego_replay", C.c_int32),
+        ("crash_sidewalk_penalty", C.c_float), ("idle_penalty", C.c_float), ("idle_done", C.c_int32), ("crash_sidewalk_done", C.c_int32),
     ]
 
 

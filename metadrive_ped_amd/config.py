@@ -31,7 +31,7 @@ BASE_DEFAULT_CONFIG = dict(
     # ===== termination =====
     horizon=None,
     truncate_as_terminate=False,
-    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" | "tollgate" | "parking_lot" (set by the multi-agent env classes)
+    marl_map=None,          # None | "pg" | "roundabout" | "intersection" | "bottleneck" | "bidirection" | "tollgate" | "parking_lot" | "racing" (set by the multi-agent env classes)
     # ===== vehicle =====
     vehicle_config=dict(
         vehicle_model="default",
@@ -102,6 +102,8 @@ METADRIVE_DEFAULT_CONFIG = dict(
     cross_yellow_line_done=True,   # bottleneck / bidirection / tollgate envs (marl_bottleneck.py:17,129-135, marl_tollgate.py:22,241-247)
     overspeed_penalty=0.5,         # tollgate env (marl_tollgate.py:25)
     parking_space_num=8,           # parking-lot env (marl_parking_lot.py:31): an even number >= 4
+    # racing env (RACING_CONFIG, marl_racing_env.py:46-63)
+    crash_sidewalk_penalty=1.0, idle_penalty=1.0, idle_done=True, crash_sidewalk_done=False,
     # VaryingDynamicsEnv (envs/varying_dynamics_env.py:14-25): None = off, else {parameter: (min, max) | None}
     random_dynamics=None,
 )
@@ -251,7 +253,7 @@ def make_config(user=None):
         assert n >= 4, "minimal number of parking space is 4"
         if n > 20:
             raise ValueError("parking_space_num > 20: the spawn tables hold 32 places")
-    if not cfg["cross_yellow_line_done"] and cfg["marl_map"] != "tollgate":
+    if not cfg["cross_yellow_line_done"] and cfg["marl_map"] not in ("tollgate", "racing"):
         raise NotImplementedError("cross_yellow_line_done=False is built for the tollgate env only")
     if cfg["step_kernel"] not in ("auto", "wg", "wave"):
         raise ValueError("step_kernel must be 'auto', 'wg' or 'wave', got {!r}".format(cfg["step_kernel"]))

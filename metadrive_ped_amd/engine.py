@@ -60,6 +60,9 @@ def _build_marl(cfg, scene_cfg, uniq):
     elif kind == "parking_lot":
         pg = MAParkingLotMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                              parking_space_num=cfg["parking_space_num"])
+    elif kind == "racing":
+        from metadrive_ped_amd.mapgen.pg import RacingMap
+        pg = RacingMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"])
     elif kind == "tollgate":
         pg = MATollGateMap(lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
                            toll_lane_num=mc["toll_lane_num"], toll_length=mc["toll_length"])
@@ -284,6 +287,8 @@ class HostScene:
             st["next_agent_id"] = np.full(E, cfg["initial_agents"] or A, np.int32)   # names agent0 .. agent{n-1} are taken
         if self.num_others > 0:
             st["detected"] = np.zeros((E * A, 2), np.uint64)
+        if cfg["is_multi_agent"] and cfg["marl_map"] == "racing":
+            st["idle_ring"] = np.zeros((E * A, abi.MD_IDLE_WINDOW), np.float32)     # movement_between_steps of every agent
         self.state = st
         self.md_config = make_md_config(cfg, E, A, cap, self.n_beams)
         self.md_config.n_side, self.md_config.n_lane_line = self.n_side, self.n_ll
@@ -333,6 +338,10 @@ def make_md_config(cfg, E, A, cap, n_beams):
     if cfg["is_multi_agent"] and cfg["marl_map"] == "parking_lot":
         k.ma_kind = abi.MA_PARKING_LOT
         k.n_parking = int(cfg["parking_space_num"])
+    if cfg["is_multi_agent"] and cfg["marl_map"] == "racing":
+        k.ma_kind = abi.MA_RACING
+        k.crash_sidewalk_penalty, k.idle_penalty = float(cfg["crash_sidewalk_penalty"]), float(cfg["idle_penalty"])
+        k.idle_done, k.crash_sidewalk_done = int(bool(cfg["idle_done"])), int(bool(cfg["crash_sidewalk_done"]))
     if cfg["is_multi_agent"] and cfg["marl_map"] == "tollgate":
         k.ma_kind = abi.MA_TOLLGATE
         k.min_pass_steps = int(cfg["vehicle_config"]["min_pass_steps"])

@@ -222,6 +222,41 @@ class BatchedMultiAgentTinyInter(BatchedMultiAgentIntersectionEnv):
         super().__init__(config)
 
 
+class BatchedMultiAgentRacingEnv(BatchedMultiAgentRoundaboutEnv):
+    """MultiAgentRacingEnv (envs/marl_envs/marl_racing_env.py:15-441): up to 12 agents on a hand-built ONE-WAY track (first block
+    + 12 straights / curves, 2 lanes, guardrails on both edges), all starting on the first block, no respawn.  Rules of its own
+    (MdConfig.ma_kind = 3, on the device): out of road = more than 5 m behind the start of the lane the vehicle is on (the
+    guardrails keep it in otherwise); reward = progress + speed, success +20, out of road -5, vehicle crash, sidewalk (guardrail)
+    crash -1, idle -1; an agent that moved less than 0.1 m along its lane over its last 100 steps is `idle` and done
+    (idle_done); crashes do not end the episode; horizon 3000; side detector (72 beams) and lidar (72 beams, 50 m) in the
+    observation.  Like the reference, the default 12 agents need map_config["exit_length"] >= 60 (the spawn manager counts
+    (exit_length - 10) // 8 slots per lane; the reference's own tests pass 60, tests/test_env/test_ma_racing.py:83-84).
+    Here the guardrail is a sidewalk strip that raises crash_sidewalk, not a wall: the kinematic engine has no contact response."""
+    MAP_DEFAULTS = dict(marl_map="racing", num_agents=12, allow_respawn=False, traffic_density=0.0, random_agent_model=False,
+                        map_config=dict(lane_num=2, exit_length=20),
+                        vehicle_config=dict(lidar=dict(num_lasers=72, distance=50, num_others=0),
+                                            side_detector=dict(num_lasers=72, distance=50), enable_reverse=False),
+                        out_of_road_penalty=5.0, idle_penalty=1.0, success_reward=20.0, crash_sidewalk_penalty=1.0,
+                        cross_yellow_line_done=False, out_of_road_done=True, on_continuous_line_done=False, out_of_route_done=False,
+                        crash_done=False, horizon=3000, idle_done=True, crash_sidewalk_done=False, crash_vehicle_done=False)
+
+    @classmethod
+    def default_config(cls):
+        import copy
+        return make_config(_deep_update(copy.deepcopy(MULTI_AGENT_DEFAULTS), copy.deepcopy(cls.MAP_DEFAULTS)))
+
+    def __init__(self, config=None):
+        import copy
+        merged = _deep_update(copy.deepcopy(self.MAP_DEFAULTS), dict(config or {}))
+        super().__init__(merged)
+
+    def _info(self):
+        info = super()._info()
+        e, A = self.engine, self.num_agents
+        info._lazy["idle"] = lambda: (e.flags[:, :A] & abi.FL_IDLE) != 0
+        return info
+
+
 class BatchedMultiAgentBottleneckEnv(BatchedMultiAgentRoundaboutEnv):
     """MultiAgentBottleneckEnv (envs/marl_envs/marl_bottleneck.py:10-140): 20 agents, 4 lanes narrowing to 1 and
     widening again, traffic in both directions, side (4 beams) and lane-line (4 beams) detectors in the observation.

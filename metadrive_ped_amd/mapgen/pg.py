@@ -27,7 +27,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from metadrive_ped_amd.mapgen.lanes import (COLOR_GREY, COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_NONE, LINE_SIDE,
+from metadrive_ped_amd.mapgen.lanes import (LINE_GUARDRAIL, COLOR_GREY, COLOR_YELLOW, LINE_BROKEN, LINE_CONTINUOUS, LINE_NONE, LINE_SIDE,
                                             CircularLane, StraightLane)
 from metadrive_ped_amd.pg_space import BlockParameterSpace, Parameter, sample_parameters
 from metadrive_ped_amd.rng import get_np_random
@@ -344,6 +344,11 @@ class Block:
         self.rng = get_np_random(seed)
         self.config = sample_parameters(self.rng, self.SPACE)  # the draw made in BaseRunnable.__init__
         self._part, self._road = 0, 0
+        # PGBlock.__init__ options (pgblock/pg_block.py:77-123), used by the hand-built racing map: one-way roads, and the line
+        # types of the road's outer edge / centre (None = CreateRoadFrom's defaults: SIDE / CONTINUOUS)
+        self.remove_negative_lanes = False
+        self.side_lane_line_type = None
+        self.center_line_type = None
         if index != 0:
             self.positive_lanes = [pre_socket.fake_positive] if pre_socket.fake_positive is not None else \
                 global_net.lanes(*pre_socket.positive)
@@ -404,16 +409,22 @@ class FirstBlock(Block):
     NODE_1, NODE_2, NODE_3 = ">", ">>", ">>>"
     ENTRANCE_LENGTH = 10
 
-    def __init__(self, global_net, lane_width, lane_num, length):
+    def __init__(self, global_net, lane_width, lane_num, length, remove_negative_lanes=False, side_lane_line_type=None,
+                 center_line_type=None):
         super().__init__(0, None, global_net, 0)
+        self.remove_negative_lanes = remove_negative_lanes
+        self.side_lane_line_type, self.center_line_type = side_lane_line_type, center_line_type
+        kw = dict(side_lane_line_type=side_lane_line_type, center_line_type=center_line_type)
         basic = StraightLane([0, 0], [self.ENTRANCE_LENGTH, 0], lane_width, (LINE_BROKEN, LINE_SIDE))
         r1 = (self.NODE_1, self.NODE_2)
-        create_road_from(basic, lane_num, r1, self.net, global_net)
-        create_adverse_road(r1, self.net, global_net)
+        create_road_from(basic, lane_num, r1, self.net, global_net, **kw)
+        if not remove_negative_lanes:
+            create_adverse_road(r1, self.net, global_net, **kw)
         nxt = basic.extended(length - self.ENTRANCE_LENGTH, [LINE_BROKEN, LINE_SIDE])
         r2 = (self.NODE_2, self.NODE_3)
-        create_road_from(nxt, lane_num, r2, self.net, global_net)
-        create_adverse_road(r2, self.net, global_net)
+        create_road_from(nxt, lane_num, r2, self.net, global_net, **kw)
+        if not remove_negative_lanes:
+            create_adverse_road(r2, self.net, global_net, **kw)
         global_net.merge(self.net)
         s = Socket(r2, negate_road(*r2))
         s.index = "{}-socket{}".format(self.name, 0)
@@ -431,8 +442,10 @@ class Straight(Block):
         new_lane = self.basic_lane.extended(length, [LINE_BROKEN, LINE_SIDE])
         start = self.pre_socket.positive[1]
         road = (start, self.node())
-        ok = create_road_from(new_lane, self.lane_num, road, self.net, self.global_net)
-        ok = create_adverse_road(road, self.net, self.global_net) and ok
+        kw = dict(side_lane_line_type=self.side_lane_line_type, center_line_type=self.center_line_type)
+        ok = create_road_from(new_lane, self.lane_num, road, self.net, self.global_net, **kw)
+        if not self.remove_negative_lanes:
+            ok = create_adverse_road(road, self.net, self.global_net, **kw) and ok
         self.add_socket(Socket(road, negate_road(*road)))
         return ok
 
@@ -448,12 +461,15 @@ class Curve(Block):
         road = (start, self.node())
         curve, straight = bend_then_straight(basic, p[Parameter.length], p[Parameter.radius],
                                              np.deg2rad(p[Parameter.angle]), p[Parameter.dir], basic.width,
-                                             (LINE_BROKEN, LINE_SIDE))
-        ok = create_road_from(curve, self.lane_num, road, self.net, self.global_net)
-        ok = create_adverse_road(road, self.net, self.global_net) and ok
+                                             (LINE_BROKEN, self.side_lane_line_type or LINE_SIDE))
+        kw = dict(side_lane_line_type=self.side_lane_line_type, center_line_type=self.center_line_type)
+        ok = create_road_from(curve, self.lane_num, road, self.net, self.global_net, **kw)
+        if not self.remove_negative_lanes:
+            ok = create_adverse_road(road, self.net, self.global_net, **kw) and ok
         road2 = (road[1], self.node())
-        ok = create_road_from(straight, self.lane_num, road2, self.net, self.global_net) and ok
-        ok = create_adverse_road(road2, self.net, self.global_net) and ok
+        ok = create_road_from(straight, self.lane_num, road2, self.net, self.global_net, **kw) and ok
+        if not self.remove_negative_lanes:
+            ok = create_adverse_road(road2, self.net, self.global_net, **kw) and ok
         self.add_socket(Socket(road2, negate_road(*road2)))
         return ok
 
@@ -1285,6 +1301,40 @@ class MAIntersectionMap:
     bfs_route = None  # bound below
 
 
+class RacingMap:
+    """The hand-built track of MultiAgentRacingEnv (envs/marl_envs/marl_racing_env.py:76-320): the first block (30 m: its default
+    length, whatever map_config["exit_length"] says) and twelve Straight / Curve blocks with fixed parameters, ONE-WAY (no
+    negative roads), fenced by guardrails on the outer edge and along the centre."""
+    # (block, construct_from_config parameters) in order
+    TRACK = [("S", dict(length=100)), ("C", dict(length=200, radius=100, angle=90, dir=1)), ("S", dict(length=100)),
+             ("C", dict(length=100, radius=60, angle=90, dir=1)), ("C", dict(length=100, radius=60, angle=90, dir=1)),
+             ("S", dict(length=200)), ("C", dict(length=80, radius=40, angle=90, dir=1)),
+             ("C", dict(length=40, radius=50, angle=180, dir=1)), ("C", dict(length=40, radius=50, angle=220, dir=0)),
+             ("C", dict(length=50, radius=20, angle=180, dir=1)), ("S", dict(length=100)),
+             ("C", dict(length=100, radius=40, angle=140, dir=0))]
+
+    def __init__(self, lane_num=2, lane_width=3.5, exit_length=20):
+        self.seed = 0
+        self.lane_num, self.lane_width = lane_num, lane_width
+        self.net = RoadNet()
+        opts = dict(remove_negative_lanes=True, side_lane_line_type=LINE_GUARDRAIL, center_line_type=LINE_GUARDRAIL)
+        last = FirstBlock(self.net, lane_width, lane_num, 30, **opts)
+        self.blocks = [last]
+        for i, (kind, params) in enumerate(self.TRACK, start=1):
+            blk = (Straight if kind == "S" else Curve)(i, list(last.sockets.values())[0], self.net, 1)
+            blk.remove_negative_lanes = True
+            blk.side_lane_line_type = blk.center_line_type = LINE_GUARDRAIL
+            blk.construct_config = dict(params)
+            self.no_cross = blk.construct() and getattr(self, "no_cross", True)
+            self.blocks.append(blk)
+            last = blk
+        for a, b, lanes in self.net.roads():
+            for i, l in enumerate(lanes):
+                l.index = (a, b, i)
+
+    bfs_route = None  # bound below
+
+
 class PGMap:
     """The BIG search (component/algorithm/BIG.py:27-165) driven to completion."""
     MAX_TRIAL = 5
@@ -1400,3 +1450,4 @@ MABottleneckMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, s
 MABidirectionMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MATollGateMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
 MAParkingLotMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)
+RacingMap.bfs_route = lambda self, start_node, goal: bfs_route(self.net, start_node, goal)

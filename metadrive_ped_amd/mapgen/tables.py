@@ -59,6 +59,7 @@ def _line_box(p0, p1, region=None):
 def lane_line_quads(lane, construct_left_right):
     """Quads + kinds for the lines of one lane; also the side-walk quads when a line is SIDE."""
     quads, kinds = [], []
+    has_sidewalk = False       # PGBlock.sidewalks is keyed by the lane: the first SIDE / GUARDRAIL line of a lane makes its strip
     for side, ltype, color, need in zip((-1, 1), lane.line_types, lane.line_colors, construct_left_right):
         if not need or ltype == LINE_NONE:
             continue
@@ -78,8 +79,12 @@ def lane_line_quads(lane, construct_left_right):
                 if q is not None:
                     quads.append(q)
                     kinds.append(kind)
-            if ltype == LINE_SIDE:
-                for q in sidewalk_quads(lane):
+            if ltype in (LINE_SIDE, LINE_GUARDRAIL) and not has_sidewalk:
+                # SIDE: the sidewalk on the lane's right; GUARDRAIL: the same strip on whichever side the line is
+                # (_generate_sidewalk_from_line(lane, GUARDRAIL_HEIGHT, lateral_direction=idx), pgblock/pg_block.py:341-353) --
+                # a contact raises crash_sidewalk either way (base_vehicle.py:757-767)
+                has_sidewalk = True
+                for q in sidewalk_quads(lane, side if ltype == LINE_GUARDRAIL else 1):
                     quads.append(q)
                     kinds.append(abi.Q_SIDEWALK)
         elif ltype == LINE_BROKEN:
@@ -98,9 +103,11 @@ def lane_line_quads(lane, construct_left_right):
     return quads, kinds
 
 
-def sidewalk_quads(lane):
+def sidewalk_quads(lane, lateral_direction=1):
     start_lat = lane.width / 2 + 0.2
     side_lat = start_lat + SIDEWALK_WIDTH
+    start_lat *= lateral_direction
+    side_lat *= lateral_direction
     if lane.radius != 0 and side_lat > lane.radius:
         return []
     longs = np.arange(0, lane.length + SIDEWALK_LENGTH, SIDEWALK_LENGTH)

@@ -47,10 +47,12 @@ def parking_lot_roads(parking_space_num):
 
 
 SPAWN_ROADS = dict(roundabout=ROUNDABOUT_SPAWN_ROADS, intersection=INTERSECTION_SPAWN_ROADS, bottleneck=BOTTLENECK_SPAWN_ROADS,
-                   bidirection=BIDIRECTION_SPAWN_ROADS, tollgate=TOLLGATE_SPAWN_ROADS, parking_lot=parking_lot_roads(8)[0])
+                   bidirection=BIDIRECTION_SPAWN_ROADS, tollgate=TOLLGATE_SPAWN_ROADS, parking_lot=parking_lot_roads(8)[0],
+                   racing=PG_SPAWN_ROADS)      # MultiAgentRacingEnv keeps MultiAgentMetaDrive's spawn road (the first block's exit)
 # roundabout / intersection: the spawn manager draws a destination among the arms (update_destination_for overrides);
 # bottleneck: the base SpawnManager leaves it to NodeNetworkNavigation.reset (the far end of the map)
-FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True, tollgate=True, parking_lot=False)
+FIXED_DESTINATION = dict(roundabout=False, intersection=False, bottleneck=True, bidirection=True, tollgate=True, parking_lot=False,
+                         racing=True)
 MAX_VEHICLE_LENGTH, MAX_VEHICLE_WIDTH = 10.0, 2.5   # BaseVehicle.MAX_LENGTH / MAX_WIDTH
 REGION_LONG, REGION_LAT = 8.0, 3.0
 

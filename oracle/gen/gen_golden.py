@@ -489,6 +489,55 @@ def section_ma_tinyinter():
                                    defaults=defaults))
 
 
+def section_ma_racing():
+    """MultiAgentRacingEnv (envs/marl_envs/marl_racing_env.py): the hand-built RacingMap as RacingMap._generate builds it (:76-320;
+    run on a bare object that carries what the method reads: config, road_network, blocks, engine placeholders), every lane with
+    its line types, the sidewalk strips the guardrails generate (PGBlock._generate_sidewalk_from_line, one per lane), the route of
+    an agent from the spawn road to the end, and RACING_CONFIG's numbers."""
+    from types import SimpleNamespace
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_racing_env import RACING_CONFIG, RacingMap
+    from metadrive.manager.spawn_manager import SpawnManager
+    from metadrive.envs.marl_envs.multi_agent_metadrive import MULTI_AGENT_METADRIVE_DEFAULT_CONFIG as MA
+    net = NodeRoadNetwork()
+    fake = SimpleNamespace(config={"lane_num": 2, "lane_width": 3.5}, road_network=net, blocks=[],
+                           engine=SimpleNamespace(worldNP=MagicMock(), physics_world=MagicMock()))
+    RacingMap._generate(fake)
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            for i, l in enumerate(lanes):
+                l.index = (f, t, i)
+    roads = []
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            roads.append(dict(start=f, end=t, lanes=[lane_record(l) for l in lanes]))
+    # the sidewalk strips: rebuild them through the reference's own method on each block (it only needs `sidewalks`)
+    strips = []
+    for b in fake.blocks:
+        b.sidewalks = {}
+        for f, td in b.block_network.graph.items():
+            for t, lanes in td.items():
+                for l in lanes:
+                    for idx, lt in zip([-1, 1], l.line_types):
+                        if lt == "guardrail" or str(lt).lower().endswith("guardrail"):
+                            b._generate_sidewalk_from_line(l, sidewalk_height=4.0, lateral_direction=idx)
+        for key, sw in b.sidewalks.items():
+            strips.append(dict(lane=key, polygon=[[float(p[0]), float(p[1])] for p in sw["polygon"]]))
+    spawn = [[r.start_node, r.end_node] for r in MA["spawn_roads"]]
+    last = fake.blocks[-1].get_socket_list()[0].positive_road.end_node
+    path = net.shortest_path((spawn[0][0], spawn[0][1], 0), last)
+    cfg = {k: (float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v) for k, v in RACING_CONFIG.items()
+           if k in ("num_agents", "out_of_road_penalty", "idle_penalty", "success_reward", "crash_sidewalk_penalty", "cross_yellow_line_done",
+                    "out_of_road_done", "on_continuous_line_done", "out_of_route_done", "crash_done", "horizon", "idle_done",
+                    "crash_sidewalk_done", "crash_vehicle_done", "allow_respawn", "traffic_density")}
+    cfg["map_config"] = {k: float(v) for k, v in RACING_CONFIG["map_config"].items()}
+    cfg["lidar"] = {k: float(v) for k, v in RACING_CONFIG["vehicle_config"]["lidar"].items() if not isinstance(v, bool)}
+    cfg["side_detector"] = {k: float(v) for k, v in RACING_CONFIG["vehicle_config"]["side_detector"].items()}
+    dump("ma_racing.json", dict(roads=roads, blocks=[b.ID for b in fake.blocks], sidewalks=strips, spawn_roads=spawn, route=path,
+                                capacity_exit_20=int(SpawnManager.max_capacity(MA["spawn_roads"], 20, 2)),
+                                capacity_exit_60=int(SpawnManager.max_capacity(MA["spawn_roads"], 60, 2)), config=cfg))
+
+
 def section_ma_bottleneck():
     """Map of MultiAgentBottleneckEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 20 m)
     + Split (back to 4, exit 60 m) as MABottleneckMap._generate builds it (marl_bottleneck.py:28-69)."""
@@ -1724,7 +1773,7 @@ def section_scenario_export():
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn,
-                       traffic_spawn=section_traffic_spawn, fork_blocks=section_fork_blocks, ma_tinyinter=section_ma_tinyinter)
+                       traffic_spawn=section_traffic_spawn, fork_blocks=section_fork_blocks, ma_tinyinter=section_ma_tinyinter, ma_racing=section_ma_racing)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

