@@ -26,7 +26,7 @@ def test_config_contract(cs_dist):
 
 def test_unbuilt_block_type_fails_loudly():
     """Every block type of the default distribution, Merge / Split, Bidirection, ParkingLot and TollGate are built; the
-    forks (broken in the reference itself: pgblock/fork.py:27) are not and say so instead of silently changing the map.
+    forks raise the reference's own ValueError (they are broken there: pgblock/fork.py:27) instead of silently changing the map.
     A parking lot after a three-lane road fails like the reference's assertion."""
     from collections import OrderedDict
     from metadrive_ped_amd.mapgen.pg import BLOCK_TYPE_DISTRIBUTION_V2, BlockDist, PGMap
@@ -36,7 +36,7 @@ def test_unbuilt_block_type_fails_loudly():
     d["TollGate"] = 1.0
     assert [b.ID for b in PGMap(0, block_dist=BlockDist(d)).blocks] == ["I", "$", "$", "$"]
     d["TollGate"], d["InFork"] = 0.0, 1.0
-    with pytest.raises(NotImplementedError, match="not built yet"):
+    with pytest.raises(ValueError, match="Bug exists in this block"):     # the reference's own error (pgblock/fork.py:27, :172)
         PGMap(0, block_dist=BlockDist(d))
     with pytest.raises(AssertionError, match="must be 1 in each direction"):
         PGMap(0, generate_type="block_sequence", generate_config="P")            # default lane_num = 3
