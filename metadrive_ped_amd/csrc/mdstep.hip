@@ -3083,6 +3083,10 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
                  md_obs_tail(c));
         return MD_EINVAL;
     }
+    if (!c->is_multi_agent && c->agents_per_env != 1) {   // the single-agent kernels schedule ONE agent's observation per env
+        snprintf(g_err, sizeof g_err, "single-agent envs step one agent per env (agents_per_env=%d): use the multi-agent configs", c->agents_per_env);
+        return MD_EINVAL;
+    }
     if (c->num_others < 0 || c->num_others > 16 || (c->num_others > 0 && c->n_beams <= 0)) {
         snprintf(g_err, sizeof g_err, "num_others=%d needs 0..16 and the lidar on", c->num_others);
         return MD_EINVAL;
