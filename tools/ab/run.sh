@@ -2,7 +2,7 @@
 # A/B of library builds on the bench workload: bash tools/ab/run.sh <out> lib1.so lib2.so ...
 OUT=$1; shift
 mkdir -p $OUT
-CACHE=$OUT/host_cache.pkl
+CACHE_DIR=$(mktemp -d); CACHE=$CACHE_DIR/host_cache.pkl   # a private scratch dir (the pickle is keyed; gpurun_out/ only carries results back)
 LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --host-cache $CACHE"
 python bench.py --steps 100 --warmup 10 $LEAN > $OUT/base.json 2> $OUT/base.err || { tail -5 $OUT/base.err; exit 1; }
 python - <<PY

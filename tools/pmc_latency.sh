@@ -11,7 +11,7 @@ export MD_STEP_KERNEL=${2:-wg}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CACHE=$OUT/host_cache.pkl
+CACHE_DIR=$(mktemp -d); CACHE=$CACHE_DIR/host_cache.pkl   # a private scratch dir (the pickle is keyed; gpurun_out/ only carries results back)
 LEAN="--no-cpu-baseline --no-lane-follow --no-env-api --no-shared-maps --sub-batches 0 --host-cache $CACHE"
 rocprofv3 -L > $OUT/avail.txt 2>&1 || true
 python bench.py --steps 20 --warmup 5 $LEAN > $OUT/bench_lean.json 2> $OUT/bench_lean.err
