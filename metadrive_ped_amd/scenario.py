@@ -11,8 +11,10 @@ manager/scenario_traffic_manager.py, manager/scenario_data_manager.py) and what 
   TrajectoryNavigation.set_route    checkpoints every 2 m along the reference trajectory
 
 PolyLine restates utils/interpolating_line.py:12-71 (segment construction) in float64; the device tables are float32.
-The maps of scenario descriptions exported by this package hold lanes only (no road-line features), so no line / sidewalk
-bodies exist in these scenes: the side detector reports "nothing" and no line flags are raised.
+Road lines and road boundaries of a description's `map_features` ARE bodies (line pieces in the scene's own static map: the
+side / lane-line detectors see them, crossing them raises the line flags; pinned by tests/golden/scenario_lines.json).  A
+description without such features -- e.g. the lanes-only maps scenario_export.py writes -- simply has none: the side detector
+then reports "nothing" and no line flag is raised.  Sidewalk / crosswalk polygons are not built.
 """
 import copy
 import math
