@@ -538,6 +538,111 @@ def section_ma_racing():
                                 capacity_exit_60=int(SpawnManager.max_capacity(MA["spawn_roads"], 60, 2)), config=cfg))
 
 
+def section_ma_racing_rules():
+    """MultiAgentRacingEnv's own rules, called step by step: reward_function, done_function (through
+    MultiAgentMetaDrive's and MetaDriveEnv's), _is_out_of_road and _is_idle with its 100-step movement deque
+    (envs/marl_envs/marl_racing_env.py:354-441) on a vehicle walked along the reference's own RacingMap lanes through five scripted
+    episodes: standing still until idle, scraping the guardrail / another vehicle, falling behind the start of its lane, arriving,
+    and running into the horizon while idle.  The env is a bare instance (no engine); what the methods read is laid on it."""
+    import types
+    from collections import defaultdict, deque
+    from types import SimpleNamespace
+    from metadrive.component.map.base_map import BaseMap
+    from metadrive.component.navigation_module.node_network_navigation import NodeNetworkNavigation
+    from metadrive.component.road_network import Road
+    from metadrive.component.road_network.node_road_network import NodeRoadNetwork
+    from metadrive.envs.marl_envs.marl_racing_env import MultiAgentRacingEnv, RacingMap
+    from metadrive.envs.metadrive_env import MetaDriveEnv
+    from metadrive.utils.math import Vector
+    net = NodeRoadNetwork()
+    fake_map = SimpleNamespace(config={"lane_num": 2, "lane_width": 3.5}, road_network=net, blocks=[],
+                               engine=SimpleNamespace(worldNP=MagicMock(), physics_world=MagicMock()))
+    RacingMap._generate(fake_map)
+    for f, td in net.graph.items():
+        for t, lanes in td.items():
+            for i, l in enumerate(lanes):
+                l.index = (f, t, i)
+    last = fake_map.blocks[-1].get_socket_list()[0].positive_road.end_node
+    ckpts = net.shortest_path((">>", ">>>", 0), last)
+    final_lane = net.graph[ckpts[-2]][ckpts[-1]][-1]
+    cfg = dict(MultiAgentRacingEnv.default_config())
+
+    class PosedNavigation(NodeNetworkNavigation):
+        map = SimpleNamespace(MAX_LANE_NUM=BaseMap.MAX_LANE_NUM, MAX_LANE_WIDTH=BaseMap.MAX_LANE_WIDTH)
+
+    class BareRacing(MultiAgentRacingEnv):       # class attributes stand where the real env has engine-backed properties
+        agents = None
+        current_seed = 0
+        config = None
+
+    def run(script, horizon):
+        env = object.__new__(BareRacing)
+        env.config = dict(cfg, horizon=horizon)
+        env.logger = MagicMock()
+        env.movement_between_steps = defaultdict(lambda: deque(maxlen=100))
+        env.episode_lengths = {"agent0": 0}
+        out = []
+        last_pos = None
+        for (k, li, s_, lat, speed, crash_vehicle, crash_sidewalk) in script:
+            lanes = net.graph[ckpts[k]][ckpts[k + 1]]
+            lane = lanes[li]
+            pos = lane.position(s_, lat)
+            pos = (float(pos[0]), float(pos[1]))
+            if last_pos is None:
+                last_pos = pos
+            heading = float(lane.heading_theta_at(max(0.0, min(s_, lane.length))))
+            last_road = (k + 1 == len(ckpts) - 1)
+            nav = object.__new__(PosedNavigation)
+            nav.checkpoints = ckpts
+            nav._target_checkpoints_index = [k, k] if last_road else [k, k + 1]
+            nav.current_ref_lanes = lanes
+            nav.next_ref_lanes = None if last_road else net.graph[ckpts[k + 1]][ckpts[k + 2]]
+            nav.current_road = Road(ckpts[k], ckpts[k + 1])
+            nav.final_lane = final_lane
+            nav._current_lane = lane
+            veh = SimpleNamespace(position=Vector(pos), last_position=last_pos, lane=lane, navigation=nav, speed_km_h=speed * 3.6,
+                                  max_speed_km_h=80.0, crash_vehicle=bool(crash_vehicle), crash_sidewalk=bool(crash_sidewalk),
+                                  crash_object=False, crash_building=False, crash_human=False, on_lane=True,
+                                  on_yellow_continuous_line=False, on_white_continuous_line=False, out_of_route=False)
+            env.agents = {"agent0": veh}
+            env.episode_lengths["agent0"] += 1
+            reward, rinfo = MultiAgentRacingEnv.reward_function(env, "agent0")
+            done, dinfo = MultiAgentRacingEnv.done_function(env, "agent0")
+            out.append(dict(k=k, lane=list(lane.index), idx=list(nav._target_checkpoints_index), pos=list(pos), last_pos=list(last_pos),
+                            heading=heading, speed=speed, crash_vehicle=bool(crash_vehicle), crash_sidewalk=bool(crash_sidewalk),
+                            steps=env.episode_lengths["agent0"] - 1, reward=float(reward), step_reward=float(rinfo["step_reward"]),
+                            progress=float(rinfo["progress"]), done=bool(done),
+                            done_info={k_: bool(v) for k_, v in dinfo.items() if k_ != "env_seed"}))
+            last_pos = pos
+        return out
+
+    episodes = []
+    # A: 30 moving steps (1.5 m each), then 104 standing ones: idle at the 100th still step, done
+    sc = [(1, 0, 2.0 + 1.5 * i, 0.3, 15.0, 0, 0) for i in range(30)] + [(1, 0, 2.0 + 1.5 * 29, 0.3, 0.0, 0, 0)] * 104
+    episodes.append(dict(name="idle", horizon=3000, steps=run(sc, 3000)))
+    # B: the guardrail and another vehicle: penalties, nothing terminal; vehicle crash has priority over the sidewalk
+    sc = []
+    for i in range(40):
+        sc.append((2, i % 2, 5.0 + 2.0 * i, -1.2 if i % 2 == 0 else 1.2, 20.0, 1 if i in (7, 8, 20) else 0, 1 if i in (12, 13, 20, 30) else 0))
+    episodes.append(dict(name="scrapes", horizon=3000, steps=run(sc, 3000)))
+    # C: sliding back behind the start of one's lane: out of road only beyond 5 m
+    sc = [(3, 1, 3.0 - 1.0 * i, 0.0, 1.0, 0, 0) for i in range(12)]
+    episodes.append(dict(name="behind_lane_start", horizon=3000, steps=run(sc, 3000)))
+    # D: the last road, up to the destination
+    kl = len(ckpts) - 2
+    L = float(final_lane.length)
+    sc = [(kl, 1, L - 30.0 + 2.0 * i, 0.2, 20.0, 0, 0) for i in range(16)]
+    episodes.append(dict(name="arrive", horizon=3000, steps=run(sc, 3000)))
+    # E: standing still into the horizon: max_step, and the idle verdict is not even reported then (marl_racing_env.py:363-364)
+    sc = [(1, 1, 10.0, 0.0, 0.0, 0, 0)] * 103
+    episodes.append(dict(name="idle_at_horizon", horizon=100, steps=run(sc, 100)))
+    dump("ma_racing_rules.json", dict(route=ckpts, final_lane=list(final_lane.index), episodes=episodes,
+                                      config={k_: cfg[k_] for k_ in ("driving_reward", "speed_reward", "success_reward", "out_of_road_penalty",
+                                                                    "crash_vehicle_penalty", "crash_sidewalk_penalty", "idle_penalty",
+                                                                    "idle_done", "crash_sidewalk_done", "crash_done", "out_of_road_done",
+                                                                    "crash_vehicle_done", "truncate_as_terminate")}))
+
+
 def section_ma_bottleneck():
     """Map of MultiAgentBottleneckEnv: FirstPGBlock(60 m, 4 lanes) + Merge (to 1 lane over 20 m)
     + Split (back to 4, exit 60 m) as MABottleneckMap._generate builds it (marl_bottleneck.py:28-69)."""
@@ -1773,7 +1878,7 @@ def section_scenario_export():
 
 SECTIONS = OrderedDict(pg_maps=section_pg_maps, lanes=section_lanes, utils=section_utils, agent_step=section_agent_step, objects=section_objects, roundabout=section_roundabout, idm=section_idm, idm_policy=section_idm_policy, scenario=section_scenario, pg_maps_v2=section_pg_maps_v2, pg_maps_v6=section_pg_maps_v6, ma_intersection=section_ma_intersection, ma_bottleneck=section_ma_bottleneck, pg_maps_v3=section_pg_maps_v3,
                        scenario_export=section_scenario_export, ma_bidirection=section_ma_bidirection, ma_tollgate=section_ma_tollgate, ma_parking_lot=section_ma_parking_lot, scenario_lines=section_scenario_lines, others=section_others, pg_maps_v4=section_pg_maps_v4, pg_maps_v5=section_pg_maps_v5, scenario_spawn=section_scenario_spawn,
-                       traffic_spawn=section_traffic_spawn, fork_blocks=section_fork_blocks, ma_tinyinter=section_ma_tinyinter, ma_racing=section_ma_racing)
+                       traffic_spawn=section_traffic_spawn, fork_blocks=section_fork_blocks, ma_tinyinter=section_ma_tinyinter, ma_racing=section_ma_racing, ma_racing_rules=section_ma_racing_rules)
 
 if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)

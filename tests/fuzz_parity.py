@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Random combinations of the config options (not collected by pytest: run by hand on the GPU box): for each draw a
 short rollout of HIP against the oracle, every state array compared.  Usage: python tests/fuzz_parity.py [n] [seed]"""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python
 """Long parity soak (not collected by pytest: run by hand on the GPU box): thousands of steps of HIP against the
 oracle on a few hundred envs per configuration, comparing every state array at the end of each 250-step chunk.
 Usage: python tests/soak_parity.py [steps]"""
@@ -32,10 +31,12 @@ def main():
                                           max_steering=(10, 80), mass=(300, 3000))),
         walkers=dict(mover_capacity=40, traffic_density=0.15),   # + a pedestrian and a cyclist spawned every 400 steps
         idm_agent=dict(agent_policy="IDMPolicy", traffic_density=0.15),
+        wave_shared=dict(num_scenarios=8, step_kernel="wave"),     # the wave-per-env kernel (what "auto" picks for large batches on few maps)
     )
     for name, extra in configs.items():
         cfg = make_config(dict(dict(num_envs=E, num_scenarios=E, horizon=1000), **extra))
         eng = BatchedEngine(cfg)
+        assert eng.host.step_kernel == cfg.get("step_kernel", "auto").replace("auto", "wg")
         orc = ob.OracleWorld(eng.host)
         eng.reset()
         orc.reset()
@@ -80,14 +81,15 @@ def main_marl():
     from helpers import assert_state_equal
     from metadrive_ped_amd.engine import BatchedEngine
     from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,
-                                                 BatchedMultiAgentParkingLotEnv, BatchedMultiAgentRoundaboutEnv,
-                                                 BatchedMultiAgentTollgateEnv)
+                                                 BatchedMultiAgentParkingLotEnv, BatchedMultiAgentRacingEnv, BatchedMultiAgentRoundaboutEnv,
+                                                 BatchedMultiAgentTinyInter, BatchedMultiAgentTollgateEnv)
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     E = 48
     only = os.environ.get("SOAK_ONLY", "")          # e.g. SOAK_ONLY=Tollgate,ParkingLot
     for cls, extra in ((BatchedMultiAgentRoundaboutEnv, {}), (BatchedMultiAgentIntersectionEnv, {}), (BatchedMultiAgentBottleneckEnv, {}),
                        (BatchedMultiAgentRoundaboutEnv, dict(num_agents=-1, map_config=dict(exit_length=40, lane_num=2))),
-                       (BatchedMultiAgentTollgateEnv, {}), (BatchedMultiAgentParkingLotEnv, {})):
+                       (BatchedMultiAgentTollgateEnv, {}), (BatchedMultiAgentParkingLotEnv, {}), (BatchedMultiAgentTinyInter, {}),
+                       (BatchedMultiAgentRacingEnv, dict(map_config=dict(exit_length=60), horizon=700))):
         if only and not any(k in cls.__name__ for k in only.split(",")):
             continue
         cfg = cls(dict(dict(num_envs=E, num_scenarios=E), **extra)).config
@@ -160,6 +162,8 @@ def main_scenario():
 
 
 if __name__ == "__main__":
+    from metadrive_ped_amd import hostpool
+    hostpool.start()                                   # before the first GPU call
     only = os.environ.get("SOAK_ONLY", "")
     if only == "scenario":
         main_scenario()

@@ -452,6 +452,67 @@ def test_racing_rules_on_oracle():
     assert left_lanes.any() and not ((fl() & abi.FL_OUT_OF_ROAD) != 0)[left_lanes].all()
 
 
+def test_racing_rules_against_reference():
+    """MultiAgentRacingEnv.reward_function / done_function / _is_out_of_road / _is_idle of the reference, called step by step on a
+    vehicle walked along the reference's RacingMap (tests/golden/ma_racing_rules.json: idle after 100 still steps, guardrail and
+    vehicle scrapes, sliding behind the lane start, arrival, the horizon) vs ref_observe on the same poses: every boolean, the
+    reward and the step reward to 2e-4 (float32 against float64), the idle verdict at exactly the same step."""
+    from metadrive_ped_amd.engine import HostScene
+    with open(os.path.join(GOLDEN, "ma_racing_rules.json")) as f:
+        g = json.load(f)
+    host = HostScene(_racing_cfg(num_envs=1, num_scenarios=1, build_workers=1))
+    t = host.map_tables[0]
+    c = g["config"]
+    k_ = host.md_config
+    assert (k_.success_reward, k_.out_of_road_penalty, k_.crash_vehicle_penalty, k_.crash_sidewalk_penalty, k_.idle_penalty) == \
+        (c["success_reward"], c["out_of_road_penalty"], c["crash_vehicle_penalty"], c["crash_sidewalk_penalty"], c["idle_penalty"])
+    assert (bool(k_.idle_done), bool(k_.crash_sidewalk_done), bool(k_.crash_done), bool(k_.out_of_road_done)) == \
+        (c["idle_done"], c["crash_sidewalk_done"], c["crash_done"], c["out_of_road_done"])
+    route = [t.node_names[i] for i in host.state["route_nodes"][0, :len(g["route"])]]
+    assert route == g["route"] and host.state["final_lane"][0] == t.lane_id[tuple(g["final_lane"])]
+    n, seen = 0, set()
+    for ep in g["episodes"]:
+        orc = ob.OracleWorld(host, host.clone_state())
+        st = orc.state
+        st["need_reset"][:] = 0
+        orc.k.horizon = ep["horizon"]
+        sh, dy, nv = st["shape"], st["dyn"], st["nav"]
+        ever_done = False
+        for smp in ep["steps"]:
+            sh["cx"][0], sh["cy"][0] = smp["pos"]
+            sh["c"][0], sh["s"][0] = math.cos(smp["heading"]), math.sin(smp["heading"])
+            dy["heading"][0], dy["speed"][0] = smp["heading"], smp["speed"]
+            dy["last_x"][0], dy["last_y"][0] = smp["last_pos"]
+            dy["last_c"][0], dy["last_s"][0] = sh["c"][0], sh["s"][0]
+            nv["lane"][0] = t.lane_id[tuple(smp["lane"])]
+            nv["ck0"][0], nv["ck1"][0] = smp["idx"]
+            nv["road0"][0], nv["road1"][0] = st["route_roads"][0, smp["idx"][0]], st["route_roads"][0, smp["idx"][1]]
+            nv["steps"][0] = smp["steps"]
+            nv["done"][0] = 0
+            fl = abi.FL_ON_LANE
+            fl |= abi.FL_CRASH_VEHICLE if smp["crash_vehicle"] else 0
+            fl |= abi.FL_CRASH_SIDEWALK if smp["crash_sidewalk"] else 0
+            st["flags"][0] = fl
+            orc.call("ref_observe")
+            out = int(st["flags"][0])
+            di = smp["done_info"]
+            where = (ep["name"], smp["steps"])
+            assert bool(out & abi.FL_IDLE) == di.get("idle", False), where
+            assert bool(out & abi.FL_OUT_OF_ROAD) == di["out_of_road"], where
+            assert bool(out & abi.FL_ARRIVE_DEST) == di["arrive_dest"], where
+            assert bool(out & abi.FL_MAX_STEP) == di["max_step"], where
+            assert bool(out & abi.FL_TERMINATED) == smp["done"], where
+            assert abs(st["reward"][0] - smp["reward"]) < 2e-4, (where, st["reward"][0], smp["reward"])
+            assert abs(st["step_info"][0, 0] - smp["step_reward"]) < 2e-4, where
+            ever_done |= smp["done"]
+            for key in ("idle", "out_of_road", "arrive_dest", "max_step", "crash_sidewalk", "crash_vehicle"):
+                if di.get(key):
+                    seen.add(key)
+            n += 1
+        assert ever_done or ep["name"] == "scrapes"
+    assert n > 290 and seen == {"idle", "out_of_road", "arrive_dest", "max_step", "crash_sidewalk", "crash_vehicle"}
+
+
 @pytest.mark.gpu
 def test_racing_rollout_parity_gpu():
     import torch
