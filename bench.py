@@ -151,7 +151,8 @@ def host_cache_key(args, rank, world):
         with open(os.path.join(pkg, rel), "rb") as fh:
             h.update(fh.read())
     return dict(abi=abi.MD_ABI_VERSION, workload=args.workload, envs=args.envs, cap=args.cap, sub=args.sub_batches, rank=rank,
-                world=world, cpu=(args.cpu_envs, bool(args.no_cpu_baseline)), src=h.hexdigest()[:16])
+                world=world, cpu=(args.cpu_envs, bool(args.no_cpu_baseline)), src=h.hexdigest()[:16],
+                step_kernel=os.environ.get("MD_STEP_KERNEL", ""), shared=bool(args.no_shared_maps))
 
 
 def load_or_build_hosts(path, build, key):

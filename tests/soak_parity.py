@@ -83,8 +83,7 @@ def main_marl():
     from metadrive_ped_amd.envs.marl_env import (BatchedMultiAgentBottleneckEnv, BatchedMultiAgentIntersectionEnv,
                                                  BatchedMultiAgentParkingLotEnv, BatchedMultiAgentRacingEnv, BatchedMultiAgentRoundaboutEnv,
                                                  BatchedMultiAgentTinyInter, BatchedMultiAgentTollgateEnv)
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-    E = 48
+    steps_all = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     only = os.environ.get("SOAK_ONLY", "")          # e.g. SOAK_ONLY=Tollgate,ParkingLot
     for cls, extra in ((BatchedMultiAgentRoundaboutEnv, {}), (BatchedMultiAgentIntersectionEnv, {}), (BatchedMultiAgentBottleneckEnv, {}),
                        (BatchedMultiAgentRoundaboutEnv, dict(num_agents=-1, map_config=dict(exit_length=40, lane_num=2))),
@@ -92,6 +91,8 @@ def main_marl():
                        (BatchedMultiAgentRacingEnv, dict(map_config=dict(exit_length=60), horizon=700))):
         if only and not any(k in cls.__name__ for k in only.split(",")):
             continue
+        racing = cls is BatchedMultiAgentRacingEnv      # 72 + 72 beams x 3256 line pieces per agent on the CPU oracle: a smaller batch
+        E, steps = (6, min(steps_all, 800)) if racing else (48, steps_all)
         cfg = cls(dict(dict(num_envs=E, num_scenarios=E), **extra)).config
         eng = BatchedEngine(cfg)
         A = eng.A
