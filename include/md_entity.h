@@ -1037,6 +1037,21 @@ MD_HD int md_kth_set_bit(uint32_t v, int k) { /* index of the k-th (0-based) set
 #define MD_RESPAWN_HALF_LEN 4.0f  /* RESPAWN_REGION_LONGITUDE / 2 (spawn_manager.py:28) */
 #define MD_RESPAWN_HALF_WID 1.5f  /* RESPAWN_REGION_LATERAL / 2 */
 
+/* agent_policy = IDMPolicy in a multi-agent env: a (re)spawned agent gets a fresh IDMPolicy (manager/agent_manager.py:37-52:
+ * add_policy(obj.id, policy_cls, obj, self.generate_seed())) -- overtake_timer = randint(0, LANE_CHANGE_FREQ) (idm_policy.py:229), clean
+ * PID states, NORMAL_SPEED, no routing target lane.  The reference seeds that policy from the agent manager's stream; the respawn
+ * draws here come from the env's xorshift32 stream like the place and the destination. */
+MD_HD void md_agent_idm_init(const MdState* s, const MdConfig* c, int slot) {
+    if (!c->agent_idm) return;
+    MdNav* nav = &s->nav[slot];
+    nav->timer = (int)(md_rng_next(s->rng) % (uint32_t)IDM_LANE_CHANGE_FREQ);
+    nav->target_lane = -1;
+    nav->rand_cursor = 0;
+    MdPid* p = &s->pid[slot];
+    p->hp = p->hi = p->hd = p->lp = p->li = p->ld = 0.0f;
+    p->target_speed = IDM_NORMAL_SPEED;
+}
+
 MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* c, int m) {
     const int A = c->agents_per_env;
     s->env_steps[0] += 1;
@@ -1142,6 +1157,7 @@ MD_HD void md_lifecycle_env(const MdWorld* w, const MdState* s, const MdConfig* 
             nav->done = 0;
             nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
             nav->toll_entry = space;
+            md_agent_idm_init(s, c, slot);
             if (c->random_agent_model && w->n_vclass > 0) md_draw_vehicle_class(w, s, slot);
             s->final_lane[slot] = w->spawn_route_meta[2 * ri + 1];
             for (int k = 0; k < MD_ROUTE_LEN; ++k) {

@@ -225,8 +225,6 @@ def make_config(user=None):
         raise NotImplementedError("agent_policy={!r}: built are EnvInputPolicy (actions from step()), IDMPolicy and, in "
                                   "BatchedScenarioEnv only, ReplayEgoCarPolicy".format(pol))
     cfg["agent_policy"] = pol
-    if pol == "IDMPolicy" and cfg["is_multi_agent"]:
-        raise NotImplementedError("agent_policy=IDMPolicy in a multi-agent env is not built")
     if cfg["num_agents"] == -1:
         # "infinite agents" (spawn_manager.py:74-78, agent_manager.py:272-279, multi_agent_metadrive.py:86-92): every spawn
         # point holds an agent at reset and a new agent enters whenever a spawn region is clear, whatever the number on

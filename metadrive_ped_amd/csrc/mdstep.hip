@@ -1253,6 +1253,7 @@ __device__ __forceinline__ void lifecycle_block(const MdWorld& w, const MdState&
                     nav->done = 0;
                     nav->toll_state = nav->toll_entry = nav->toll_exit = 0;
                     nav->toll_entry = space;
+                    md_agent_idm_init(&s, &c, slot);
                     if (c.random_agent_model && w.n_vclass > 0) md_draw_vehicle_class(&w, &s, slot);
                     s.final_lane[slot] = w.spawn_route_meta[2 * ri + 1];
                     *new_slot = slot;
@@ -1510,7 +1511,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     // agent_policy = IDMPolicy (single-agent envs): the agents are planned like the traffic, in the reference's order
     // (decide, then move): the observation reports the action applied in THIS step.  Never in the lean fused variant:
     // the launcher sends such configs to the RESPAWN one.
-    const bool agent_idm = (kFused && !RESPAWN) ? false : (!MULTI && c.agent_idm != 0);
+    const bool agent_idm = (kFused && !RESPAWN && !MULTI) ? false : (c.agent_idm != 0);
     constexpr bool kPlanAhead = kFused && kWaves > 1 && !MULTI;
     const bool plan_ahead = kPlanAhead && !agent_idm;
     if ((PH & PH_IDM) && !just_reset && !plan_ahead) {
@@ -2671,10 +2672,6 @@ int check_common(const MdWorld* w, const MdState* s, const MdConfig* c) {
     }
     if (c->n_beams < 0 || c->n_beams > MD_MAX_BEAMS) {
         snprintf(g_err, sizeof g_err, "n_beams=%d out of range [0,%d]", c->n_beams, MD_MAX_BEAMS);
-        return MD_EINVAL;
-    }
-    if (c->agent_idm && c->is_multi_agent) {
-        snprintf(g_err, sizeof g_err, "agent_idm (agent_policy = IDMPolicy) is built for single-agent envs only");
         return MD_EINVAL;
     }
     if (!s->shape) {

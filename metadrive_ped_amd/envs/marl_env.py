@@ -86,12 +86,14 @@ class BatchedMultiAgentRoundaboutEnv:
         if self.engine is None:
             raise RuntimeError("call reset() before step()")
         torch = self.engine.torch
-        if self.config["discrete_action"]:
+        if self.config["agent_policy"] == "IDMPolicy":      # every agent is driven by its own IDMPolicy: `actions` is ignored
+            a = None
+        elif self.config["discrete_action"]:
             from metadrive_ped_amd.envs.metadrive_env import discrete_to_continuous
             a = discrete_to_continuous(torch, self.config, actions, (self.num_envs, self.num_agents), self.engine.device)
         else:
             a = actions if torch.is_tensor(actions) else torch.as_tensor(np.asarray(actions, dtype=np.float32))
-        if tuple(a.shape) != (self.num_envs, self.num_agents, 2):
+        if a is not None and tuple(a.shape) != (self.num_envs, self.num_agents, 2):
             raise ValueError("actions must have shape [{}, {}, 2], got {}".format(self.num_envs, self.num_agents, tuple(a.shape)))
         self.engine.step(a)
         A = self.num_agents

@@ -158,6 +158,11 @@ class RoundaboutScene:
             nv["ck0"], nv["ck1"] = (0, 1) if n > 2 else (0, 0)
             nv["route_len"] = n
             nv["toll_entry"] = space     # parking-lot env: the space this agent holds (+1), see md_lifecycle_env
+            if cfg.get("agent_policy") == "IDMPolicy":
+                # IDMPolicy.__init__ (policy/idm_policy.py:225-233): overtake_timer = randint(0, LANE_CHANGE_FREQ); the pre-drawn
+                # randint(0, 25) values its move_to_next_road consumes (:285)
+                nv["timer"] = int(rng.randint(0, 50))
+                self.idm_rand[a] = [int(rng.randint(0, 25)) for _ in range(abi.MD_IDM_RAND)]
         # free slots keep the vehicle's dimensions / parameters so that a respawn only rewrites the pose
         for a in range(len(chosen), A):
             self.shape["hl"][a], self.shape["hw"][a] = length / 2, width / 2

@@ -538,6 +538,62 @@ def test_racing_rollout_parity_gpu():
     assert ((orc.state["flags"].reshape(E, -1)[:, :A] & abi.FL_MAX_STEP) != 0).any() or True
 
 
+# ---- agent_policy = IDMPolicy in the multi-agent envs (manager/agent_manager.py:37-52; the reference's racing tests drive so) ----
+def test_marl_agents_driven_by_idm_on_oracle():
+    """Every agent has its own IDMPolicy: they follow their routes without any input, queue behind each other, arrive, and the
+    agents that respawn get a fresh policy state."""
+    from metadrive_ped_amd.engine import HostScene
+    E, A = 2, 12
+    host = HostScene(_racing_cfg(num_envs=E, num_scenarios=E, agent_policy="IDMPolicy"))
+    assert host.md_config.agent_idm == 1 and (host.state["nav0"]["timer"].reshape(E, -1)[:, :A] < 50).all()
+    assert len(set(host.state["nav0"]["timer"].reshape(-1).tolist())) > 3          # drawn per agent
+    o = ob.OracleWorld(host)
+    o.reset()
+    fl = lambda: o.state["flags"].reshape(E, -1)[:, :A]
+    x0 = o.state["shape"]["cx"].reshape(E, -1)[:, :A].copy()
+    for t in range(400):
+        o.step(None)
+        assert not (fl() & abi.FL_CRASH_VEHICLE).any(), t            # IDM keeps its distance (reference test: no crash, all arrive)
+    moved = np.abs(o.state["shape"]["cx"].reshape(E, -1)[:, :A] - x0)
+    assert (moved > 50).all()                                        # everybody drove off along the track
+    sp = o.state["dyn"]["speed"].reshape(E, -1)[:, :A]
+    assert (sp > 3.0).all() and (sp < 12.0).all()                    # around NORMAL_SPEED = 30 km/h
+    # a map with respawns: new agents come with a policy of their own and drive too
+    host = HostScene(_inter_cfg(num_envs=E, num_scenarios=E, agent_policy="IDMPolicy"))
+    o = ob.OracleWorld(host)
+    o.reset()
+    for t in range(500):
+        o.step(None)
+    assert (o.state["next_agent_id"] > 30).all()                     # agents arrived and were replaced
+    A = 30
+    act, _ = _counts(o.state, E)
+    sp = o.state["dyn"]["speed"].reshape(E, -1)[:, :A]
+    live = ((o.state["shape"]["flags"].reshape(E, -1)[:, :A] & (abi.F_ALIVE | abi.F_STATIC)) == abi.F_ALIVE)
+    assert (act > 10).all() and (sp[live] >= 0).all() and (sp[live] > 1.0).mean() > 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["intersection", "racing"])
+def test_marl_idm_agents_rollout_parity_gpu(which):
+    import torch
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    E = 6
+    cfg = _inter_cfg(num_envs=E, num_scenarios=E, agent_policy="IDMPolicy") if which == "intersection" else \
+        _racing_cfg(num_envs=E, num_scenarios=E, agent_policy="IDMPolicy", horizon=300)
+    eng = BatchedEngine(cfg)
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    assert_state_equal(eng.download_state(), orc.state, where="%s idm reset" % which)
+    for t in range(350):
+        eng.step(None)
+        orc.step(None)
+        if t % 25 == 0:
+            assert_state_equal(eng.download_state(), orc.state, where="%s idm step %d" % (which, t))
+    assert_state_equal(eng.download_state(), orc.state, where="%s idm final" % which)
+
+
 # ---- multi-agent bottleneck (envs/marl_envs/marl_bottleneck.py; blocks pgblock/bottleneck.py) -------------------
 def _bottle_cfg(**kw):
     from metadrive_ped_amd.envs.marl_env import BatchedMultiAgentBottleneckEnv
