@@ -487,6 +487,12 @@ int md_lidar_detect(const MdWorld* w, const MdState* s, const MdConfig* c, float
  * kind_mask selects MD_Q_* kinds (bit k set = kind k is a target). beam table = beam_cs. */
 int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c, const float* beam_cs, int n_beams,
                      float range, uint32_t kind_mask, float* out, int out_stride, int out_offset, void* stream);
+/* The same for TWO fans at once -- the side detector and the lane-line detector of one observation (obs/state_obs.py:77-86 and
+ * :129-140 call SideDetector.perceive and LaneLineDetector.perceive one after the other): one launch, one pass over the map's
+ * line pieces; fan k writes its n_beams_k fractions at out_offset_k of every agent's row.  n_beams0 + n_beams1 <= 255. */
+int md_line_detectors(const MdWorld* w, const MdState* s, const MdConfig* c, const float* beam_cs0, int n_beams0, float range0,
+                      uint32_t kind_mask0, int out_offset0, const float* beam_cs1, int n_beams1, float range1, uint32_t kind_mask1,
+                      int out_offset1, float* out, int out_stride, void* stream);
 
 /* Dynamics: BaseVehicle.before_step/_set_action/_apply_throttle_brake (component/vehicle/
  * base_vehicle.py:211-232,447-484) + EngineCore.step_physics_world x decision_repeat

@@ -368,6 +368,139 @@ __device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& m
     __builtin_amdgcn_wave_barrier();
 }
 
+// One or TWO detector fans of one agent (side detector + lane-line detector: different beam tables, ranges and line kinds) against
+// the quads [qa, qb) of its map by ONE wave, in ONE pass over the quads' cull records, in two phases so that the expensive slab
+// tests run on full wavefronts: (1) lanes = quads: per fan kind, reach, then the beams that can meet the quad's bounding circle (a
+// dozen instructions each); the (quad, beam) pairs that survive -- a few per hundred -- are appended to `pairs` (LDS, kDetPairs
+// ints of this wave) through ballot prefix counts, the second fan's beams numbered behind the first's; (2) lanes = pairs: fetch
+// the quad, cast, atomicMin on the fraction's bit pattern in the fan's `best` (initialised to 1.0).  The list is drained whenever
+// a pass could overflow it.  Same arithmetic and the same minima as the oracle's serial loop per detector.
+struct DetFan2 {
+    const float* cs0; int n0; float range0; uint32_t mask0; int* best0;
+    const float* cs1; int n1; float range1; uint32_t mask1; int* best1;   // n1 == 0: one fan only
+};
+__device__ __forceinline__ void detector_drain2(const MdWorld& w, const MdShape& me, const DetFan2& f, const int* pairs, int n, int qa,
+                               int lane_id) {   // a pair = (quad - qa) << 8 | beam (fan 1's beams from n0 on)
+    const float4* quads4 = reinterpret_cast<const float4*>(w.quads);
+    for (int k = lane_id; k < n; k += 64) {
+        const int pr = pairs[k];
+        const int q = qa + (pr >> 8), ig = pr & 255;
+        const bool second = ig >= f.n0;
+        const int i = second ? ig - f.n0 : ig;
+        const float* cs = second ? f.cs1 : f.cs0;
+        const float range = second ? f.range1 : f.range0;
+        const float4 lo = quads4[2 * (size_t)q], hi = quads4[2 * (size_t)q + 1];
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const float bc = cs[2 * i], bs = cs[2 * i + 1];
+        const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+        const float t = md_ray_quad(me.cx, me.cy, ux * range, uy * range, v);
+        if (t < 1.0f) atomicMin(second ? &f.best1[i] : &f.best0[i], __float_as_int(t));
+    }
+}
+
+// is the table a uniform fan?  beam i = (cos, sin)(phase0 + i 2 pi / n): one lane per beam compares
+__device__ __forceinline__ bool detector_uniform_fan(const float* beam_cs, int n_beams, int lane_id, float* phase0_out) {
+    const float phase0 = atan2f(beam_cs[1], beam_cs[0]);
+    const float dphi = 6.283185307179586f / (float)n_beams;
+    bool fan_ok = true;
+    for (int i = lane_id; i < n_beams; i += 64) {
+        float sn, cs;
+        sincosf(phase0 + (float)i * dphi, &sn, &cs);
+        fan_ok = fan_ok && md_fabs(cs - beam_cs[2 * i]) < 1.0e-3f && md_fabs(sn - beam_cs[2 * i + 1]) < 1.0e-3f;
+    }
+    *phase0_out = phase0;
+    return __ballot(!fan_ok) == 0ull && n_beams >= 4;
+}
+
+__device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& me, int qa, int qb, const DetFan2& f, int* pairs, int lane_id) {
+    float ph0 = 0.0f, ph1 = 0.0f;
+    const bool uni0 = detector_uniform_fan(f.cs0, f.n0, lane_id, &ph0);
+    const bool uni1 = f.n1 > 0 ? detector_uniform_fan(f.cs1, f.n1, lane_id, &ph1) : false;
+    const float reach_max = md_max(f.range0, f.n1 > 0 ? f.range1 : 0.0f) * 1.001f;
+    int cnt = 0;   // wave-uniform
+    // the 16-byte records of the NEXT 64 quads are requested before this round's are worked on: the rounds are a dependent chain
+    // (ballot, pair list), and a cold fetch per round was most of the phase
+    QuadBall nb;
+    nb.mx = nb.my = nb.rr = 0.0f;
+    nb.kind = 0;
+    if (qa + lane_id < qb) nb = quad_ball_of(w, qa + lane_id);
+    for (int q0 = qa; q0 < qb; q0 += 64) {
+        const int q = q0 + lane_id;
+        float px = 0.0f, py = 0.0f, rr = 0.0f;
+        const QuadBall b = nb;
+        if (q + 64 < qb) nb = quad_ball_of(w, q + 64);
+        bool in_reach = false;
+        if (q < qb) {
+            px = b.mx - me.cx;
+            py = b.my - me.cy;
+            rr = b.rr;
+            const float far = reach_max + rr;
+            in_reach = !(px * px + py * py > far * far);
+        }
+        if (__ballot(in_reach) == 0ull) continue;
+        // one fan after the other against this round's quads (the second only where there is one)
+        for (int fan = 0; fan < (f.n1 > 0 ? 2 : 1); ++fan) {
+            const float* beam_cs = fan ? f.cs1 : f.cs0;
+            const int n_beams = fan ? f.n1 : f.n0;
+            const float reach = (fan ? f.range1 : f.range0) * 1.001f;
+            const uint32_t kind_mask = fan ? f.mask1 : f.mask0;
+            const float phase0 = fan ? ph1 : ph0;
+            const bool uniform_fan = fan ? uni1 : uni0;
+            const int beam_base = fan ? f.n0 : 0;
+            const float inv_dphi = 1.0f / (6.283185307179586f / (float)n_beams);
+            const float far = reach + rr;
+            const bool near = in_reach && ((kind_mask >> b.kind) & 1u) && !(px * px + py * py > far * far);
+            if (__ballot(near) == 0ull) continue;
+            // Which beams can meet this quad at all?  For a uniform fan (beam i at phase0 + i dphi from the heading -- every
+            // detector table is one; checked above, else all beams are tried) only those within asin(r / d) of the direction
+            // to the quad's centre: a handful instead of all 12 ... 72.  Hardware atan2 / asin are good enough here, a margin
+            // covers them and the exact circle test follows anyway.
+            int i_lo = 0, n_try = n_beams;
+            if (uniform_fan && near) {
+                const float d2 = px * px + py * py;
+                if (d2 > rr * rr * 1.0201f) {
+                    const float lx = px * me.c + py * me.s, ly = py * me.c - px * me.s;   // the centre in the agent's frame
+                    const float half = asinf(md_min(rr * 1.01f * rsqrtf(d2), 1.0f)) + 0.02f;
+                    float rel = atan2f(ly, lx) - phase0;
+                    const float lo = (rel - half) * inv_dphi, hi = (rel + half) * inv_dphi;
+                    i_lo = (int)floorf(lo);
+                    n_try = min((int)ceilf(hi) - i_lo + 1, n_beams);
+                    i_lo = ((i_lo % n_beams) + n_beams) % n_beams;
+                }
+            }
+            int max_try = near ? n_try : 0;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) max_try = max(max_try, __shfl_xor(max_try, off, 64));
+            for (int k = 0; k < max_try; ++k) {
+                int i = i_lo + k;
+                if (i >= n_beams) i -= n_beams;
+                const bool mine_ = near && k < n_try;
+                const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
+                const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
+                const float perp = ux * py - uy * px, along = ux * px + uy * py;
+                const bool pass = mine_ && !(md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr);
+                const unsigned long long m = __ballot(pass);
+                if (m == 0ull) continue;
+                if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    detector_drain2(w, me, f, pairs, cnt, qa, lane_id);
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = 0;
+                }
+                if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q - qa) << 8) | (beam_base + i);
+                cnt += __popcll(m);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    detector_drain2(w, me, f, pairs, cnt, qa, lane_id);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Side / lane-line detector as an entry point of its own (md_line_detector).  Work items = (agent, part of the map's quads),
 // one WAVE each running detector_wave above; with four or more agents per env an item is a whole agent, with fewer the quads
 // are split four ways.  A workgroup takes FOUR consecutive items of one env (grid = n_envs x ceil(items / 4)): the 40-agent
@@ -380,14 +513,18 @@ __device__ __host__ inline int detector_groups(int A) { return (A * detector_par
 __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdState s, MdConfig c,
                                                                const float* __restrict__ beam_cs, int n_beams,
                                                                float range, uint32_t kind_mask, float* out,
-                                                               int out_stride, int out_offset) {
+                                                               int out_stride, int out_offset,
+                                                               const float* __restrict__ beam_cs1, int n_beams1, float range1,
+                                                               uint32_t kind_mask1, int out_offset1) {
+    // (beam_cs1, n_beams1 > 0, ...): a SECOND fan evaluated in the same pass over the quads (md_line_detectors)
     extern __shared__ int l_ld[];
     constexpr int kW = kBlock / 64;
     const int A = c.agents_per_env;
+    const int nb = n_beams + n_beams1;
     const int parts = detector_parts(A), groups = detector_groups(A);
-    int* l_best = l_ld;                                              // [kW * n_beams] bit patterns of the closest fractions
-    float* l_bm = reinterpret_cast<float*>(l_ld + kW * n_beams);     // [n_beams][2] the beam table
-    int* l_pairs = reinterpret_cast<int*>(l_bm + 2 * n_beams);       // [kW][kDetPairs]
+    int* l_best = l_ld;                                              // [kW * nb] bit patterns of the closest fractions
+    float* l_bm = reinterpret_cast<float*>(l_ld + kW * nb);          // [nb][2] the beam tables, fan 0 then fan 1
+    int* l_pairs = reinterpret_cast<int*>(l_bm + 2 * nb);            // [kW][kDetPairs]
     const int e = blockIdx.x / groups, grp = blockIdx.x - e * groups;
     if (e >= c.n_envs) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -395,8 +532,9 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
     const int q0 = w.quad_off[m], q1 = w.quad_off[m + 1];
     const int a_first = (grp * kW) / parts;                          // first agent this workgroup serves
     const int n_here = min(A - a_first, kW / parts);                 // agents it serves (4, or 1 when the quads are split)
-    for (int it = tid; it < n_here * n_beams; it += kBlock) l_best[it] = __float_as_int(1.0f);
+    for (int it = tid; it < n_here * nb; it += kBlock) l_best[it] = __float_as_int(1.0f);
     for (int it = tid; it < 2 * n_beams; it += kBlock) l_bm[it] = beam_cs[it];
+    for (int it = tid; it < 2 * n_beams1; it += kBlock) l_bm[2 * n_beams + it] = beam_cs1[it];
     __syncthreads();
     const int per = (q1 - q0 + parts - 1) / parts;
     const int it = grp * kW + wave;
@@ -405,13 +543,18 @@ __global__ __launch_bounds__(kBlock) void line_detector_kernel(MdWorld w, MdStat
         const MdShape me = s.shape[e * c.cap + a];
         if (md_present(me.flags)) {
             const int qa = q0 + part * per, qb = min(qa + per, q1);
-            detector_wave(w, me, qa, qb, l_bm, n_beams, range, kind_mask, l_best + (a - a_first) * n_beams, l_pairs + wave * kDetPairs, lane);
+            DetFan2 f;
+            f.cs0 = l_bm; f.n0 = n_beams; f.range0 = range; f.mask0 = kind_mask; f.best0 = l_best + (a - a_first) * nb;
+            f.cs1 = l_bm + 2 * n_beams; f.n1 = n_beams1; f.range1 = range1; f.mask1 = kind_mask1; f.best1 = f.best0 + n_beams;
+            detector_wave2(w, me, qa, qb, f, l_pairs + wave * kDetPairs, lane);
         }
     }
     __syncthreads();
-    for (int k = tid; k < n_here * n_beams; k += kBlock) {
-        const int al = k / n_beams, i = k - al * n_beams;
-        out[(size_t)(e * A + a_first + al) * out_stride + out_offset + i] = __int_as_float(l_best[k]);
+    for (int k = tid; k < n_here * nb; k += kBlock) {
+        const int al = k / nb, i = k - al * nb;
+        float* row = out + (size_t)(e * A + a_first + al) * out_stride;
+        if (i < n_beams) row[out_offset + i] = __int_as_float(l_best[k]);
+        else row[out_offset1 + (i - n_beams)] = __int_as_float(l_best[k]);
     }
 }
 
@@ -1300,6 +1443,7 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int nbytes, i
 // (intersections, roundabouts: 100-200 lanes) are read through L1/L2 instead -- staging 30 KB per env per
 // step would cost more HBM traffic and LDS occupancy than it saves in latency.
 constexpr int kStageMaxLanes = 64;
+constexpr int kWideMaxEnvs = 640;   // multi-agent batches up to this many envs step with eight waves per env (see launch<>)
 constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot removed in this step
 
 // RESPAWN: the variant for everything off the headline path -- traffic modes respawn / hybrid / replay, detected
@@ -1319,13 +1463,15 @@ constexpr uint32_t kRemovedMark = 0xFFFFFFFFu;  // l_cfl value of a traffic slot
 template <int PH, bool RESPAWN, bool MULTI>
 constexpr int env_waves_per_eu() { return (PH == PH_ALL && !RESPAWN && !MULTI && MD_ENV_BLOCK >= 128) ? MD_ENV_WAVES_EU : 0; }
 
-template <int PH, bool STAGE_MAP, bool RESPAWN = false, bool MULTI = false>
-__global__ __launch_bounds__(MD_ENV_BLOCK)
+// BLK: threads of the workgroup (MD_ENV_BLOCK; multi-agent batches small enough to stay resident are also instantiated with 512:
+// eight waves share an env's 20-40 agents -- lifecycle search, contacts, observe groups, lidar sectors -- instead of four).
+template <int PH, bool STAGE_MAP, bool RESPAWN = false, bool MULTI = false, int BLK = MD_ENV_BLOCK>
+__global__ __launch_bounds__(BLK)
 __attribute__((amdgpu_waves_per_eu(env_waves_per_eu<PH, RESPAWN, MULTI>() ? env_waves_per_eu<PH, RESPAWN, MULTI>() : 1,
                                    env_waves_per_eu<PH, RESPAWN, MULTI>() ? env_waves_per_eu<PH, RESPAWN, MULTI>() : 8)))
 void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
                                                   int lidar_stride, int lidar_offset) {
-    constexpr int kBlock = MD_ENV_BLOCK;
+    constexpr int kBlock = BLK;
     constexpr int kWaves = kBlock / 64;
     if ((int)blockIdx.x >= c.n_envs) return;
 #ifdef MD_STAMP
@@ -2726,12 +2872,18 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     if (PH == PH_ALL && use_wave_kernel(c)) return launch_wave_step(w, s, c, lidar_out, stride, offset, stream);
     const bool stage = w->max_lanes <= kStageMaxLanes;
     constexpr bool kCanMultiLds = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;  // same rule as the MULTI kernel variant below
+    // Multi-agent md_step: eight waves per env while every workgroup of the batch is resident at once at that size (the MULTI
+    // kernel's 92 VGPRs allow 5 waves per SIMD = 640 eight-wave workgroups on the 256 CUs); larger batches keep four, which
+    // then fill the chip by themselves.  Measured: 512 tollgate envs x 40 agents, 1024 roundabout envs (profiles/r03_*).
+    const bool wide = (PH == PH_ALL) && kCanMultiLds && c->is_multi_agent && c->n_envs <= kWideMaxEnvs && MD_ENV_BLOCK == 256 &&
+                      c->agents_per_env > 8;
+    const int blk = wide ? 512 : MD_ENV_BLOCK;
     // the lidar-only kernel stages nothing but the shapes: asking for the full image would cost it occupancy
     const size_t lds = (PH == PH_LIDAR) ? (size_t)c->cap * sizeof(MdShape) + 16 :
                        (size_t)c->cap * (sizeof(MdShape) + sizeof(MdDyn) + sizeof(MdNav) + sizeof(MdPid) + 8) +
                        (size_t)((c->cap + 3) & ~3) * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
-                       (MD_ENV_BLOCK / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
+                       (blk / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
                        (size_t)c->cap * 8 + 32;   // + 32: the lifecycle's 8 scratch words sit at the start of the last region
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
@@ -2744,7 +2896,12 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
     constexpr bool kCanMulti = (PH & (PH_LIFECYCLE | PH_RESET)) != 0;
 #define MD_LAUNCH(STAGE, RESP, MUL) \
     hipLaunchKernelGGL((env_kernel<PH, STAGE, RESP, MUL>), grid, dim3(MD_ENV_BLOCK), lds, st, *w, *s, *c, lidar_out, stride, offset)
-    if (kCanMulti && c->is_multi_agent) {
+#define MD_LAUNCH_WIDE(STAGE) \
+    hipLaunchKernelGGL((env_kernel<PH, STAGE, false, kCanMulti && PH == PH_ALL, (PH == PH_ALL ? 512 : MD_ENV_BLOCK)>), grid, dim3(512), lds, st, *w, *s, *c, lidar_out, stride, offset)
+    if (kCanMulti && c->is_multi_agent && wide) {
+        if (stage) MD_LAUNCH_WIDE(true);
+        else MD_LAUNCH_WIDE(false);
+    } else if (kCanMulti && c->is_multi_agent) {
         if (stage) MD_LAUNCH(true, false, kCanMulti);
         else MD_LAUNCH(false, false, kCanMulti);
     } else if (kCanRespawn && (c->traffic_mode != 0 || c->agent_idm != 0 || (PH == PH_ALL && s->detected != nullptr))) {
@@ -2756,6 +2913,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
         MD_LAUNCH(false, false, false);
     }
 #undef MD_LAUNCH
+#undef MD_LAUNCH_WIDE
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
@@ -2917,35 +3075,51 @@ __attribute__((visibility("default"))) int md_lidar_detect(const MdWorld* w, con
     return MD_OK;
 }
 
-__attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c,
-                                                           const float* beam_cs, int n_beams, float range,
-                                                           uint32_t kind_mask, float* out, int out_stride,
-                                                           int out_offset, void* stream) {
+static int line_detector_launch(const MdWorld* w, const MdState* s, const MdConfig* c, const float* beam_cs, int n_beams, float range,
+                                uint32_t kind_mask, int out_offset, const float* beam_cs1, int n_beams1, float range1, uint32_t kind_mask1,
+                                int out_offset1, float* out, int out_stride, void* stream, const char* who) {
     int r = check_common(w, s, c);
     if (r != MD_OK) return r;
     NEED(out); NEED(beam_cs); NEED(w->env_map); NEED(w->quad_off); NEED(w->quads); NEED(w->quad_kind);
-    if (n_beams <= 0 || n_beams > MD_MAX_BEAMS || out_stride < n_beams + out_offset || out_offset < 0 || !(range > 0.0f)) {
-        snprintf(g_err, sizeof g_err, "md_line_detector: n_beams=%d stride=%d offset=%d range=%f", n_beams, out_stride,
-                 out_offset, (double)range);
+    if (n_beams <= 0 || n_beams > MD_MAX_BEAMS || out_stride < n_beams + out_offset || out_offset < 0 || !(range > 0.0f) ||
+        (n_beams1 > 0 && (!beam_cs1 || out_stride < n_beams1 + out_offset1 || out_offset1 < 0 || !(range1 > 0.0f)))) {
+        snprintf(g_err, sizeof g_err, "%s: n_beams=%d/%d stride=%d offset=%d/%d range=%f/%f", who, n_beams, n_beams1, out_stride, out_offset,
+                 out_offset1, (double)range, (double)range1);
         return MD_EINVAL;
     }
-    const size_t lds_ld = ((kBlock / 64) * (size_t)n_beams + 2 * (size_t)n_beams + (kBlock / 64) * (size_t)kDetPairs) * sizeof(int);
-    if (n_beams > 255) {   // a (quad, beam) pair keeps the beam in eight bits
-        snprintf(g_err, sizeof g_err, "md_line_detector: n_beams=%d > 255", n_beams);
+    const size_t nb = (size_t)n_beams + (size_t)(n_beams1 > 0 ? n_beams1 : 0);
+    if (nb > 255) {   // a (quad, beam) pair keeps the beam in eight bits
+        snprintf(g_err, sizeof g_err, "%s: %zu beams > 255", who, nb);
         return MD_EINVAL;
     }
-    if (lds_ld > 60 * 1024) {
-        snprintf(g_err, sizeof g_err, "md_line_detector: %d agents x %d beams do not fit the LDS", c->agents_per_env, n_beams);
-        return MD_EINVAL;
-    }
+    const size_t lds_ld = ((kBlock / 64) * nb + 2 * nb + (kBlock / 64) * (size_t)kDetPairs) * sizeof(int);
     hipLaunchKernelGGL(line_detector_kernel, dim3(c->n_envs * detector_groups(c->agents_per_env)), dim3(kBlock), lds_ld, (hipStream_t)stream, *w, *s, *c, beam_cs,
-                       n_beams, range, kind_mask, out, out_stride, out_offset);
+                       n_beams, range, kind_mask, out, out_stride, out_offset, beam_cs1, n_beams1 > 0 ? n_beams1 : 0, range1, kind_mask1, out_offset1);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
         snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
         return MD_ELAUNCH;
     }
     return MD_OK;
+}
+
+__attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                           const float* beam_cs, int n_beams, float range,
+                                                           uint32_t kind_mask, float* out, int out_stride,
+                                                           int out_offset, void* stream) {
+    return line_detector_launch(w, s, c, beam_cs, n_beams, range, kind_mask, out_offset, nullptr, 0, 0.0f, 0u, 0, out, out_stride, stream,
+                                "md_line_detector");
+}
+
+// Two detector fans (the side detector and the lane-line detector of one observation) in ONE launch and one pass over the map's
+// line pieces: what SideDetector.perceive + LaneLineDetector.perceive cost twice (obs/state_obs.py:77-86,129-140).
+__attribute__((visibility("default"))) int md_line_detectors(const MdWorld* w, const MdState* s, const MdConfig* c,
+                                                            const float* beam_cs0, int n_beams0, float range0, uint32_t kind_mask0,
+                                                            int out_offset0, const float* beam_cs1, int n_beams1, float range1,
+                                                            uint32_t kind_mask1, int out_offset1, float* out, int out_stride,
+                                                            void* stream) {
+    return line_detector_launch(w, s, c, beam_cs0, n_beams0, range0, kind_mask0, out_offset0, beam_cs1, n_beams1, range1, kind_mask1,
+                                out_offset1, out, out_stride, stream, "md_line_detectors");
 }
 
 __attribute__((visibility("default"))) int md_integrate(const MdWorld* w, const MdState* s, const MdConfig* c,

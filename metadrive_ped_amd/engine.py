@@ -501,12 +501,20 @@ class BatchedEngine:
     def _step_raw(self):
         self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
         h = self.host
+        vc = self.cfg["vehicle_config"]
         if self._fused_detectors:
             pass
+        elif h.n_side and h.n_ll and h.n_side + h.n_ll <= 255:
+            # both detector clouds in ONE launch and one pass over the line pieces (md_line_detectors)
+            self._check(self.lib.md_line_detectors(
+                C.byref(self.w), C.byref(self.s), C.byref(self.k),
+                C.c_void_p(self._side_beams.data_ptr()), h.n_side, C.c_float(float(vc["side_detector"]["distance"])), C.c_uint32(self.SIDE_MASK), h.obs_base,
+                C.c_void_p(self._ll_beams.data_ptr()), h.n_ll, C.c_float(float(vc["lane_line_detector"]["distance"])), C.c_uint32(self.LANE_LINE_MASK),
+                h.obs_base + (h.n_side or 2) + 6, C.c_void_p(self.state_dev["obs"].data_ptr()), h.obs_dim, self._stream()), "md_line_detectors")
         elif h.n_side:   # SideDetector cloud replaces obs[0:2] (obs/state_obs.py:77-86)
             self.line_detector(self._side_beams, h.n_side, float(self.cfg["vehicle_config"]["side_detector"]["distance"]),
                                self.SIDE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base)
-        if h.n_ll and not self._fused_detectors:     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
+        if h.n_ll and not self._fused_detectors and not (h.n_side and h.n_side + h.n_ll <= 255):     # LaneLineDetector cloud replaces the lateral dim (obs/state_obs.py:129-140)
             self.line_detector(self._ll_beams, h.n_ll, float(self.cfg["vehicle_config"]["lane_line_detector"]["distance"]),
                                self.LANE_LINE_MASK, self.state_dev["obs"], h.obs_dim, h.obs_base + (h.n_side or 2) + 6)
         self._lidar_noise()
