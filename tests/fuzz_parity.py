@@ -21,7 +21,8 @@ def draw(rng):
                auto_reset=bool(rng.randint(4) > 0), crash_vehicle_done=bool(rng.randint(2)), crash_object_done=bool(rng.randint(2)),
                out_of_route_done=bool(rng.randint(4) == 0), on_continuous_line_done=bool(rng.randint(2)),
                use_lateral_reward=bool(rng.randint(2)), enable_idm_lane_change=bool(rng.randint(4) > 0),
-               agent_policy=pick("EnvInputPolicy", "EnvInputPolicy", "EnvInputPolicy", "IDMPolicy"))
+               agent_policy=pick("EnvInputPolicy", "EnvInputPolicy", "EnvInputPolicy", "IDMPolicy"),
+               step_kernel=pick("auto", "wg", "wave"))
     cfg["num_scenarios"] = int(pick(1, cfg["num_envs"], max(1, cfg["num_envs"] // 2)))
     vc = dict(enable_reverse=bool(rng.randint(3) == 0))
     beams = int(pick(0, 30, 72, 240))
@@ -44,7 +45,7 @@ def draw(rng):
 
 def draw_marl(rng):
     pick = lambda *xs: xs[int(rng.randint(len(xs)))]
-    kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg", "tollgate", "parking_lot")
+    kind = pick("roundabout", "intersection", "bottleneck", "bidirection", "pg", "tollgate", "parking_lot", "tinyinter", "racing")
     cfg = dict(num_envs=int(pick(1, 4, 9)), start_seed=int(rng.randint(0, 500)), horizon=int(pick(60, 200, 1000)),
                num_agents=int(pick(1, 3, 8, 12, -1)), delay_done=int(pick(0, 5, 25)), allow_respawn=bool(rng.randint(4) > 0),
                crash_done=bool(rng.randint(2)), out_of_road_done=bool(rng.randint(4) > 0), random_agent_model=bool(rng.randint(4) == 0),
@@ -63,6 +64,19 @@ def draw_marl(rng):
         cfg["vehicle_config"]["min_pass_steps"] = int(pick(5, 30))
         cfg["cross_yellow_line_done"] = bool(rng.randint(2))
         cfg["overspeed_penalty"] = float(pick(0.5, 2.0))
+    if rng.randint(5) == 0 and kind != "tinyinter":
+        cfg["agent_policy"] = "IDMPolicy"            # every agent driven by its own IDMPolicy (round 3)
+    if kind == "tinyinter":
+        cfg["map_config"] = dict(exit_length=int(pick(30, 40)), lane_num=1, lane_width=4.0, radius=pick(None, 20.0, 50.0))
+        cfg["num_agents"] = int(pick(1, 3, 8))
+        cfg.pop("delay_done")
+    if kind == "racing":
+        cfg["map_config"] = dict(exit_length=60, lane_num=2)
+        cfg["num_agents"] = int(pick(1, 3, 8, 12))
+        cfg["allow_respawn"] = False
+        cfg["idle_done"] = bool(rng.randint(2))
+        cfg["crash_sidewalk_done"] = bool(rng.randint(2))
+        cfg["vehicle_config"]["side_detector"] = dict(num_lasers=int(pick(4, 72)), distance=50)
     if kind == "parking_lot":
         cfg["map_config"] = dict(exit_length=int(pick(20, 30)), lane_num=1)
         cfg["parking_space_num"] = int(pick(4, 8, 12))
@@ -90,7 +104,8 @@ def main():
                 cls = dict(roundabout=M.BatchedMultiAgentRoundaboutEnv, intersection=M.BatchedMultiAgentIntersectionEnv,
                            bottleneck=M.BatchedMultiAgentBottleneckEnv, bidirection=M.BatchedMultiAgentBidirectionEnv,
                            pg=M.BatchedMultiAgentMetaDrive, tollgate=M.BatchedMultiAgentTollgateEnv,
-                           parking_lot=M.BatchedMultiAgentParkingLotEnv)[kind]
+                           parking_lot=M.BatchedMultiAgentParkingLotEnv, tinyinter=M.BatchedMultiAgentTinyInter,
+                           racing=M.BatchedMultiAgentRacingEnv)[kind]
                 cfg = cls(user).config
                 user = dict(user, marl_map=kind)
             else:
@@ -133,4 +148,6 @@ def main():
 
 
 if __name__ == "__main__":
+    from metadrive_ped_amd import hostpool
+    hostpool.start()                                   # before the first GPU call
     main()

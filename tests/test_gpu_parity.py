@@ -124,6 +124,17 @@ def test_side_and_lane_line_detectors_in_obs(cs_dist):
     assert (side < 1.0).any() and (side >= 0).all()           # the road border is within 50 m of a car on the road
     ll = st["obs"][:, 18:24]
     assert (ll < 1.0).any()
+    # the step above took both clouds from ONE launch (md_line_detectors); the single-fan entry point, called once per detector on
+    # the same poses, gives the same bits
+    both = eng.obs.clone()
+    h = eng.host
+    vc = eng.cfg["vehicle_config"]
+    eng.obs[:, :, :12] = -1.0
+    eng.obs[:, :, 18:24] = -1.0
+    eng.line_detector(eng._side_beams, h.n_side, float(vc["side_detector"]["distance"]), eng.SIDE_MASK, eng.state_dev["obs"], h.obs_dim, h.obs_base)
+    eng.line_detector(eng._ll_beams, h.n_ll, float(vc["lane_line_detector"]["distance"]), eng.LANE_LINE_MASK, eng.state_dev["obs"], h.obs_dim,
+                      h.obs_base + h.n_side + 6)
+    assert torch.equal(eng.obs.view(torch.int32), both.view(torch.int32))
 
 
 def test_default_distribution_maps_rollout_parity():
