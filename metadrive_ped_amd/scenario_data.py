@@ -24,55 +24,74 @@ def is_scenario_file(name):
     return stem[:3] == "sd_" or (len(stem) > 0 and all(ch.isdigit() for ch in stem))
 
 
+def _unpickle(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
 def read_scenario_data(path):
+    """One scenario description as a plain dict; refuses files that are not named like scenario files or lack a top-level part."""
     if not is_scenario_file(path):
         raise ValueError("File: {} is not scenario file".format(path))
-    with open(path, "rb") as f:
-        data = pickle.load(f)
-    data = dict(data)
-    missing = [k for k in _REQUIRED if k not in data]
-    if missing:
-        raise KeyError("scenario {} lacks {}".format(path, missing))
+    data = dict(_unpickle(path))
+    absent = [k for k in _REQUIRED if k not in data]
+    if absent:
+        raise KeyError("scenario {} lacks {}".format(path, absent))
     return data
 
 
-def read_dataset_summary(folder, check_file_existence=True):
-    """-> (summary: file name -> metadata, file names in dataset order, mapping: file name -> sub-folder)"""
-    folder = str(folder)
-    if not os.path.isdir(folder):
-        raise FileNotFoundError("data_directory {!r} does not exist".format(folder))
-    summary_path = os.path.join(folder, SUMMARY_FILE)
-    if os.path.isfile(summary_path):
-        with open(summary_path, "rb") as f:
-            summary = dict(pickle.load(f))
-    else:   # the old layout: every scenario file of the folder, by number where the names are numbers
-        names = [n for n in os.listdir(folder) if is_scenario_file(n)]
-        try:
-            names.sort(key=lambda n: int(n[:-len(".pkl")]))
-        except ValueError:
-            names.sort(key=lambda n: n[:-len(".pkl")])
-        summary = {n: read_scenario_data(os.path.join(folder, n))["metadata"] for n in names}
-    mapping = None
-    mapping_path = os.path.join(folder, MAPPING_FILE)
-    if os.path.exists(mapping_path):
-        with open(mapping_path, "rb") as f:
-            mapping = pickle.load(f)
-    if not mapping:
-        mapping = {k: "" for k in summary}
-    if check_file_existence:
-        for name in summary:
-            if name not in mapping:
+class DatasetIndex:
+    """What a dataset folder holds, resolved once: the scenario files in dataset order, the metadata of each, and where each file
+    lives.  Two layouts exist (scenario/utils.py:342-392): a `dataset_summary.pkl` (+ optional `dataset_mapping.pkl` of
+    sub-folders), or bare `0.pkl, 1.pkl, ...` / `sd_*.pkl` files, whose order is numeric where the names are numbers."""
+    def __init__(self, folder):
+        self.folder = str(folder)
+        if not os.path.isdir(self.folder):
+            raise FileNotFoundError("data_directory {!r} does not exist".format(self.folder))
+        self.summary = self._summary()
+        self.names = list(self.summary)
+        self.subfolder = self._subfolders()
+
+    def _summary(self):
+        listed = os.path.join(self.folder, SUMMARY_FILE)
+        if os.path.isfile(listed):
+            return dict(_unpickle(listed))
+        stems = {n: n[:-len(".pkl")] for n in os.listdir(self.folder) if is_scenario_file(n)}
+        numeric = all(st.isdigit() for st in stems.values())
+        order = sorted(stems, key=(lambda n: int(stems[n])) if numeric else (lambda n: stems[n]))
+        return {n: read_scenario_data(os.path.join(self.folder, n))["metadata"] for n in order}
+
+    def _subfolders(self):
+        listed = os.path.join(self.folder, MAPPING_FILE)
+        found = _unpickle(listed) if os.path.exists(listed) else None
+        return found if found else dict.fromkeys(self.summary, "")
+
+    def path_of(self, name):
+        return os.path.join(self.folder, self.subfolder[name], name)
+
+    def verify(self):
+        """every listed scenario has a sub-folder entry, a scenario-file name and a file"""
+        for name in self.names:
+            if name not in self.subfolder:
                 raise KeyError("FileName in mapping mismatch with summary: {}".format(name))
             if not is_scenario_file(name):
                 raise ValueError("File:{} is not sd scenario file".format(name))
-            p = os.path.join(folder, mapping[name], name)
-            if not os.path.exists(p):
-                raise FileNotFoundError("Can not find file: {}".format(p))
-    return summary, list(summary.keys()), mapping
+            if not os.path.exists(self.path_of(name)):
+                raise FileNotFoundError("Can not find file: {}".format(self.path_of(name)))
+        return self
+
+
+def read_dataset_summary(folder, check_file_existence=True):
+    """-> (summary: file name -> metadata, file names in dataset order, mapping: file name -> sub-folder): the triple the
+    reference's function of this name returns (scenario/utils.py:342-392)"""
+    index = DatasetIndex(folder)
+    if check_file_existence:
+        index.verify()
+    return index.summary, index.names, index.subfolder
 
 
 def get_number_of_scenarios(folder):
-    return len(read_dataset_summary(folder)[1])
+    return len(DatasetIndex(folder).verify().names)
 
 
 def scenario_indices(cfg, num_envs=None):
