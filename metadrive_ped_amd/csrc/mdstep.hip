@@ -2549,21 +2549,56 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     const int reset_flag = gv.need_reset[0];
     const bool fused_act = gv.agent_action != nullptr;
     const bool do_reset = reset_flag != 0;
-    copy16(l_shape, do_reset ? gv.shape0 : gv.shape, cap * (int)sizeof(MdShape), tid, kBlock);
-    copy16(l_dyn, do_reset ? gv.dyn0 : gv.dyn, cap * (int)sizeof(MdDyn), tid, kBlock);
-    copy16(l_pid, do_reset ? gv.pid0 : gv.pid, cap * (int)sizeof(MdPid), tid, kBlock);
-    copy16(l_nav, do_reset ? gv.nav0 : gv.nav, cap * (int)sizeof(MdNav), tid, kBlock);
-    copy16(l_param, gv.param, cap * (int)sizeof(MdParam), tid, kBlock);
-    for (int j = tid; j < cap; j += kBlock) {
-        if (do_reset) {
+    {
+        // ONE memory round trip: every global load of the live state is issued before the first LDS store, and nothing waits for
+        // the reset flag (a chain of copy loops waits for each loop's loads in turn: ~15 k cycles per scene); only a scene that
+        // resets re-stages from the snapshot below.  16-byte units: shape / dyn / pid / param cap * 2 each, nav cap * 4.
+        const int n32 = cap * 2, n64 = cap * 4;
+        const uint4* g_shape = reinterpret_cast<const uint4*>(gv.shape);
+        const uint4* g_dyn = reinterpret_cast<const uint4*>(gv.dyn);
+        const uint4* g_pid = reinterpret_cast<const uint4*>(gv.pid);
+        const uint4* g_param = reinterpret_cast<const uint4*>(gv.param);
+        const uint4* g_nav = reinterpret_cast<const uint4*>(gv.nav);
+        uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_nav1;
+        float2 r_act;
+        uint32_t r_fl;
+        const bool p32 = tid < n32, pc = tid < cap;
+        if (p32) {
+            r_shape = g_shape[tid];
+            r_dyn = g_dyn[tid];
+            r_pid = g_pid[tid];
+            r_param = g_param[tid];
+        }
+        if (tid < n64) r_nav0 = g_nav[tid];
+        if (tid + kBlock < n64) r_nav1 = g_nav[tid + kBlock];
+        if (pc) {
+            r_act = (fused_act && tid < A) ? reinterpret_cast<const float2*>(gv.agent_action)[tid] : reinterpret_cast<const float2*>(gv.action)[tid];
+            r_fl = gv.flags[tid];
+        }
+        if (p32) {
+            reinterpret_cast<uint4*>(l_shape)[tid] = r_shape;
+            reinterpret_cast<uint4*>(l_dyn)[tid] = r_dyn;
+            reinterpret_cast<uint4*>(l_pid)[tid] = r_pid;
+            reinterpret_cast<uint4*>(l_param)[tid] = r_param;
+        }
+        if (tid < n64) reinterpret_cast<uint4*>(l_nav)[tid] = r_nav0;
+        if (tid + kBlock < n64) reinterpret_cast<uint4*>(l_nav)[tid + kBlock] = r_nav1;
+        if (pc) {
+            reinterpret_cast<float2*>(l_action)[tid] = r_act;
+            l_flags[tid] = r_fl;
+        }
+    }
+    if (do_reset) {   // block-uniform, rare: the snapshot over what was just staged (same threads wrote the same words: no barrier needed
+                      // between a thread's own stores, and the barrier below orders everything before the first read)
+        __syncthreads();
+        copy16(l_shape, gv.shape0, cap * (int)sizeof(MdShape), tid, kBlock);
+        copy16(l_dyn, gv.dyn0, cap * (int)sizeof(MdDyn), tid, kBlock);
+        copy16(l_pid, gv.pid0, cap * (int)sizeof(MdPid), tid, kBlock);
+        copy16(l_nav, gv.nav0, cap * (int)sizeof(MdNav), tid, kBlock);
+        for (int j = tid; j < cap; j += kBlock) {
             l_action[2 * j] = 0.0f;
             l_action[2 * j + 1] = 0.0f;
             l_flags[j] = 0u;
-        } else {
-            const float* src = (fused_act && j < A) ? gv.agent_action : gv.action;
-            l_action[2 * j] = src[2 * j];
-            l_action[2 * j + 1] = src[2 * j + 1];
-            l_flags[j] = gv.flags[j];
         }
     }
     if (tid == 0) *l_count = do_reset ? 0 : gv.next_agent_id[0];   // idm_policy_count
