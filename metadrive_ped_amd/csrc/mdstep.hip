@@ -2191,20 +2191,51 @@ __global__ __launch_bounds__(64 * kWaveEnvs) void wave_step_kernel(MdWorld w, Md
 // Every lane first keeps the best of ITS segments (lane, lane + 64, ...: a strict < keeps the earliest), then ONE dense
 // wave reduction: the minimum distance by a 6-step butterfly, and among the lanes that hold it the lowest segment index
 // (a sparse set, usually one lane: ballot walk).
-__device__ __forceinline__ int poly_argmin_wave(const MdPoly& p, float px, float py, int lane_id) {
-    float bd = 3.0e38f;
+__device__ __forceinline__ int poly_local_wave(const MdPoly& p, float px, float py, int lane_id, float* lng, float* lat) {
+    // The coordinates come WITHOUT a second trip to memory (arg-min, then md_poly_local_at of that piece): every lane keeps the
+    // coordinates w.r.t. the best of its own pieces (the expressions of md_poly_local_at), the winner's are read from its lane --
+    // the lane of piece `best` is best & 63, and its own best IS that piece (strict <: the earliest of a lane's minima).
+    float bd = 3.0e38f, bl = 0.0f, bt = 0.0f;
     int bi = 0x7fffffff;
     for (int i = lane_id; i < p.n; i += 64) {
-        const float d = md_seg_dist(&p.segs[i], px, py);
+        const MdSeg g = p.segs[i];
+        const float d = md_seg_dist(&g, px, py);
         if (d < bd) {
+            const float ddx = px - g.sx, ddy = py - g.sy;
             bd = d;
             bi = i;
+            bl = g.cum + (ddx * g.dx + ddy * g.dy);
+            bt = ddx * g.dy - ddy * g.dx;
         }
     }
     float m = bd;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
-    return wave_min_i(bi, bd == m, 0x7fffffff);
+    const int best = wave_min_i(bi, bd == m, 0x7fffffff);
+    *lng = bcast_f(bl, best & 63);
+    *lat = bcast_f(bt, best & 63);
+    return best;
+}
+
+// What a decision needs to know about a slot's route before it touches a piece: staged into LDS with the scene's state (one memory
+// round trip for the whole scene) instead of three dependent ones per vehicle (route_n -> poly_off -> aux).  md_route_of + aux.
+struct __attribute__((aligned(16))) RouteDesc {
+    const MdSeg* segs;
+    const float* verts;
+    int n;
+    int n_verts;          // bit 30: no aux record (end point / outline box are derived by the decision)
+    float end_x, end_y;
+    float bx0, by0, bx1, by1;
+};
+constexpr int kDescNoAux = 1 << 30;
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <typename T>
+__device__ __forceinline__ const T* uni_p(const T* q) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffull));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
 // crossing number of the ray from (px, py) over the polygon's edges, lanes = edges: odd = inside (md_point_in_polygon)
@@ -2228,9 +2259,66 @@ __device__ __forceinline__ int poly_first_wave(const MdPoly& p, int lane_id, F p
     return p.n - 1;
 }
 
-__device__ __forceinline__ void traj_locate_wave(const MdPoly& p, float px, float py, int lane_id, MdTrajLoc* o) {
-    const int best = poly_argmin_wave(p, px, py, lane_id);
-    md_poly_local_at(&p, best, px, py, &o->lng, &o->lat);
+// The agent on its reference trajectory (md_traj_locate) and the trajectory's length (md_poly_of's) in TWO trips to memory for up to
+// 256 pieces: every lane keeps the end longitudinals of its (<= 4) pieces, so the two "first piece that ends beyond" look-ups are
+// ballots over registers; then the two pieces they name are read together.
+__device__ __forceinline__ void traj_locate_wave(const MdPoly& p, float px, float py, int lane_id, MdTrajLoc* o, float* length) {
+    constexpr int kChunks = 4;
+    if (p.n > 0 && p.n <= 64 * kChunks) {   // wave-uniform
+        float ce[kChunks];
+        float bd = 3.0e38f, bl = 0.0f, bt = 0.0f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const int i = lane_id + 64 * q;
+            ce[q] = -3.0e38f;     // never "ends beyond" anything
+            if (i < p.n) {
+                const MdSeg g = p.segs[i];
+                const float d = md_seg_dist(&g, px, py);
+                if (d < bd) {
+                    const float ddx = px - g.sx, ddy = py - g.sy;
+                    bd = d;
+                    bi = i;
+                    bl = g.cum + (ddx * g.dx + ddy * g.dy);
+                    bt = ddx * g.dy - ddy * g.dx;
+                }
+                ce[q] = g.cum + g.len;
+            }
+        }
+        float m = bd;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
+        const int best = wave_min_i(bi, bd == m, 0x7fffffff);
+        const float lng = bcast_f(bl, best & 63);
+        o->lng = lng;
+        o->lat = bcast_f(bt, best & 63);
+        const int il = p.n - 1;
+        int ih = il, is = il;
+        bool fh = false, fs = false;
+        float len = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kChunks; ++q) {
+            const unsigned long long mh = __ballot(ce[q] > lng), ms = __ballot(ce[q] + 0.1f >= lng);
+            if (!fh && mh) {
+                ih = 64 * q + __ffsll((long long)mh) - 1;
+                fh = true;
+            }
+            if (!fs && ms) {
+                is = 64 * q + __ffsll((long long)ms) - 1;
+                fs = true;
+            }
+            if ((il >> 6) == q) len = bcast_f(ce[q], il & 63);
+        }
+        *length = len;
+        const float hh = p.segs[ih].heading;
+        const MdSeg gs = p.segs[is];
+        o->heading_at = hh;
+        o->lat_dx = gs.dy;
+        o->lat_dy = -gs.dx;
+        return;
+    }
+    *length = (p.n > 0) ? p.segs[p.n - 1].cum + p.segs[p.n - 1].len : 0.0f;
+    poly_local_wave(p, px, py, lane_id, &o->lng, &o->lat);
     const float lng = o->lng;
     const int ih = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len > lng; });
     const int is = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len + 0.1f >= lng; });
@@ -2266,27 +2354,32 @@ __device__ __forceinline__ int points_in_polygon_wave4(const float* xy, int n, c
 // outline's bounding box come precomputed (MdWorld.poly_aux); the four chassis corners of a candidate are tested in
 // one pass over the outline's edges, and only those inside its bounding box.
 __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
-                                  int lane_id) {
+                                  int lane_id, const RouteDesc* l_desc) {
 #ifdef MD_STAMP
     bool st_ = lane_id == 0;   // diagnostic: the scene's first reactive vehicle, apart for its speed-control steps (slots 16.. / 24..)
     for (int q = c.agents_per_env; q < slot; ++q) st_ = st_ && !(s.nav[q].ck0 == MD_SC_IDM && md_present(s.shape[q].flags));
     const int so_ = ((k % MD_TIDM_BATCH) == s.nav[slot].timer) ? 8 : 0;
 #endif
     MD_FINE_STAMP(st_, so_ + 0);
-    // the slot's static polyline or the route cut at its spawn frame (md_route_of); without the length: that is a dependent
-    // load of the last piece, only the fallback needs it
-    const MdRoute rt = md_route_of(&w, &s, &c, e, slot);
-    MdPoly route = rt.poly;
+    // the slot's static polyline or the route cut at its spawn frame (md_route_of), end point and outline box (aux): the record the
+    // stage-in left in LDS -- wave-uniform, kept in scalar registers
+    const RouteDesc rd = l_desc[slot];
+    MdPoly route;
+    route.segs = uni_p(rd.segs);
+    route.n = uni_i(rd.n);
+    route.length = 0.0f;   // only the fallback below needs it: a dependent load of the last piece
+    const float* pv = uni_p(rd.verts);
+    const int nvf = uni_i(rd.n_verts);
+    const int n_v = nvf & ~kDescNoAux;
     const float px = s.shape[slot].cx, py = s.shape[slot].cy;
     float end_x, end_y, bx0 = -3.0e38f, by0 = -3.0e38f, bx1 = 3.0e38f, by1 = 3.0e38f;
-    if (rt.aux) {
-        const float* aux = rt.aux;
-        end_x = aux[0];
-        end_y = aux[1];
-        bx0 = aux[2];
-        by0 = aux[3];
-        bx1 = aux[4];
-        by1 = aux[5];
+    if (!(nvf & kDescNoAux)) {
+        end_x = uni_f(rd.end_x);
+        end_y = uni_f(rd.end_y);
+        bx0 = uni_f(rd.bx0);
+        by0 = uni_f(rd.by0);
+        bx1 = uni_f(rd.bx1);
+        by1 = uni_f(rd.by1);
     } else {
         route.length = (route.n > 0) ? route.segs[route.n - 1].cum + route.segs[route.n - 1].len : 0.0f;
         const float length = route.length;
@@ -2306,8 +2399,9 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
     const bool small = route.n <= 64 * kChunks;   // wave-uniform
     float ce[kChunks], hd[kChunks];
     int best;
+    float cur_long;
     if (small) {
-        float bd = 3.0e38f;
+        float bd = 3.0e38f, bl = 0.0f;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int q = 0; q < kChunks; ++q) {
@@ -2320,6 +2414,7 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
                 if (d < bd) {
                     bd = d;
                     bi = i;
+                    bl = g.cum + ((px - g.sx) * g.dx + (py - g.sy) * g.dy);   // md_poly_local_at w.r.t. this piece
                 }
                 ce[q] = g.cum + g.len;
                 hd[q] = g.heading;
@@ -2329,11 +2424,11 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
         best = wave_min_i(bi, bd == m, 0x7fffffff);
+        cur_long = bcast_f(bl, best & 63);   // the lane of piece `best`; its own best is that piece (strict <)
     } else {
-        best = poly_argmin_wave(route, px, py, lane_id);
+        float tmp;
+        best = poly_local_wave(route, px, py, lane_id, &cur_long, &tmp);
     }
-    float cur_long, tmp;
-    md_poly_local_at(&route, best, px, py, &cur_long, &tmp);
     int front = -1;
     float front_dist = MD_TIDM_MAX_DIST;
     MD_FINE_STAMP(st_, so_ + 2);
@@ -2342,8 +2437,6 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
         // corners inside the outline's bounding box against the outline (lanes = polygon edges, all corners in one pass),
         // then the projection on the route with lanes = pieces.  Ascending slot order and a strict < keep the lowest
         // slot among equal gaps.
-        const float* pv = rt.verts;
-        const int n_v = rt.n_verts;
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
             const int jl = j0 + lane_id;
             bool near = false;
@@ -2365,9 +2458,8 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
                     if (!(qx[q] < bx0 || qx[q] > bx1 || qy[q] < by0 || qy[q] > by1)) want |= 1 << q;
                 if (want == 0) continue;
                 if (points_in_polygon_wave4(pv, n_v, qx, qy, want, lane_id) == 0) continue;
-                const int bo = poly_argmin_wave(route, o.cx, o.cy, lane_id);
                 float lg, lt;
-                md_poly_local_at(&route, bo, o.cx, o.cy, &lg, &lt);
+                poly_local_wave(route, o.cx, o.cy, lane_id, &lg, &lt);
                 const float gap = lg - cur_long;
                 if (gap > 0.0f && gap < front_dist) {
                     front_dist = gap;
@@ -2543,6 +2635,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     int32_t* l_rn = l_link + c.route_seg_cap;   // [cap][4]: route_n of the scene (the decisions read it first: not a global round trip)
     // [cap] the movers as the agent's contact test sees them: after the integration, BEFORE the traffic manager's after_step
     MdShape* l_shape_ct = reinterpret_cast<MdShape*>((reinterpret_cast<uintptr_t>(g.route_n != nullptr ? (void*)(l_rn + 4 * cap) : (void*)l_len) + 15) & ~(uintptr_t)15);
+    RouteDesc* l_desc = reinterpret_cast<RouteDesc*>(l_shape_ct + cap);   // [cap] what the decisions know about each slot's route
 
     MD_STAMP_AT(0);
     const MdState gv = md_env_view(&g, &c, e);
@@ -2562,6 +2655,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_nav1;
         float2 r_act;
         uint32_t r_fl;
+        int po0 = 0, po1 = 0, pv0 = 0, pv1 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0, r_cnt = 0;
+        float ax[6];
         const bool p32 = tid < n32, pc = tid < cap;
         if (p32) {
             r_shape = g_shape[tid];
@@ -2574,7 +2669,24 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         if (pc) {
             r_act = (fused_act && tid < A) ? reinterpret_cast<const float2*>(gv.agent_action)[tid] : reinterpret_cast<const float2*>(gv.action)[tid];
             r_fl = gv.flags[tid];
+            // the slot's route record (md_route_of + MdWorld.poly_aux): every address is known here
+            const size_t ng = (size_t)e * cap + tid;
+            po0 = w.poly_off[ng];
+            po1 = w.poly_off[ng + 1];
+            pv0 = w.polyv_off[ng];
+            pv1 = w.polyv_off[ng + 1];
+            if (w.poly_aux) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) ax[q] = w.poly_aux[8 * ng + q];
+            }
+            if (gv.route_n) {
+                rn0 = gv.route_n[4 * tid];
+                rn1 = gv.route_n[4 * tid + 1];
+                rn2 = gv.route_n[4 * tid + 2];
+                rn3 = gv.route_n[4 * tid + 3];
+            }
         }
+        if (tid == 0) r_cnt = gv.next_agent_id[0];
         if (p32) {
             reinterpret_cast<uint4*>(l_shape)[tid] = r_shape;
             reinterpret_cast<uint4*>(l_dyn)[tid] = r_dyn;
@@ -2586,7 +2698,41 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         if (pc) {
             reinterpret_cast<float2*>(l_action)[tid] = r_act;
             l_flags[tid] = r_fl;
+            if (do_reset) rn0 = rn1 = rn2 = rn3 = 0;   // a reset leaves no cut routes
+            if (gv.route_n) {
+                l_rn[4 * tid] = rn0;
+                l_rn[4 * tid + 1] = rn1;
+                l_rn[4 * tid + 2] = rn2;
+                l_rn[4 * tid + 3] = rn3;
+            }
+            RouteDesc d;
+            if (rn0 > 0 && tid >= A) {   // a route cut at a spawn frame (rare; never an agent's: its slot keeps the reference trajectory): its record lives in the state, one more trip for this lane
+                d.segs = gv.route_segs + (size_t)tid * c.route_seg_cap;
+                d.verts = gv.route_verts + 2 * (size_t)tid * c.route_vert_cap;
+                d.n = rn0;
+                d.n_verts = rn1;
+                const float* ra = gv.route_aux + 8 * (size_t)tid;
+                d.end_x = ra[0];
+                d.end_y = ra[1];
+                d.bx0 = ra[2];
+                d.by0 = ra[3];
+                d.bx1 = ra[4];
+                d.by1 = ra[5];
+            } else {
+                d.segs = w.segs + po0;
+                d.verts = w.polyv + 2 * (size_t)pv0;
+                d.n = po1 - po0;
+                d.n_verts = (pv1 - pv0) | (w.poly_aux ? 0 : kDescNoAux);
+                d.end_x = w.poly_aux ? ax[0] : 0.0f;
+                d.end_y = w.poly_aux ? ax[1] : 0.0f;
+                d.bx0 = w.poly_aux ? ax[2] : 0.0f;
+                d.by0 = w.poly_aux ? ax[3] : 0.0f;
+                d.bx1 = w.poly_aux ? ax[4] : 0.0f;
+                d.by1 = w.poly_aux ? ax[5] : 0.0f;
+            }
+            l_desc[tid] = d;
         }
+        if (tid == 0) *l_count = do_reset ? 0 : r_cnt;   // idm_policy_count
     }
     if (do_reset) {   // block-uniform, rare: the snapshot over what was just staged (same threads wrote the same words: no barrier needed
                       // between a thread's own stores, and the barrier below orders everything before the first read)
@@ -2601,9 +2747,6 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             l_flags[j] = 0u;
         }
     }
-    if (tid == 0) *l_count = do_reset ? 0 : gv.next_agent_id[0];   // idm_policy_count
-    if (gv.route_n)
-        for (int j = tid; j < 4 * cap; j += kBlock) l_rn[j] = do_reset ? 0 : gv.route_n[j];   // a reset leaves no cut routes
     float* l_beams = reinterpret_cast<float*>(l_dbest + A * n_det);   // [n_det][2]: the beam tables, read n_beams times per quad
     if (fused_det) {
         const int ns = w.side_beam_cs ? c.n_side : 0;
@@ -2662,7 +2805,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             if (i < 0 || i >= n_list) break;
             const int slot = __builtin_amdgcn_readfirstlane(l_list[i]);
             if (slot < A || slot >= cap) break;        // never index with anything but a mover slot
-            tidm_vehicle_wave(w, s, c, e, slot, k, lane);
+            tidm_vehicle_wave(w, s, c, e, slot, k, lane, l_desc);
         }
         __syncthreads();
         MD_STAMP_AT(2);
@@ -2725,10 +2868,18 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     // integration): projection on the reference trajectory (wave 0, after its after_step); waves 2, 3: the detectors ----
     for (int a = 0; a < A; ++a) {
         if (wave == 0) {
-            const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
+            // the reference trajectory = the agent slot's static polyline (md_poly_of): its record is in LDS already
+            MdPoly ref;
+            ref.segs = uni_p(l_desc[a].segs);
+            ref.n = uni_i(l_desc[a].n);
+            ref.length = 0.0f;
             MdTrajLoc L;
-            traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L);
-            if (lane == 0) l_loc[a] = L;
+            float ref_len;
+            traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L, &ref_len);
+            if (lane == 0) {
+                l_loc[a] = L;
+                l_count[3] = __float_as_int(ref_len);   // single-agent scenes (md_step refuses others): one length
+            }
         } else if (wave >= 2 && fused_det) {
             // waves 2 and 3 have nothing to do in this stage and the next: the side / lane-line detectors of the agent,
             // each wave one half of the scene's line pieces (the poses are final here)
@@ -2766,8 +2917,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     if (tid < A) {
         const int a = tid;
         s.flags[a] = l_cfl[a];
-        const MdPoly ref = md_poly_of(&w, (size_t)e * cap + a);
-        md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], ref.length, 0);
+        md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], __int_as_float(l_count[3]), 0);
     }
     MD_STAMP_AT(6);
     if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
@@ -3294,7 +3444,7 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
                            (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int) +
                            ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0) +
                            (s->route_n ? (size_t)c->route_seg_cap * 20 + 16 + (size_t)c->cap * 16 : 0) +   // route_n; positions, links, lengths of a route being built
-                           (size_t)c->cap * sizeof(MdShape) + 32;   // the shapes the contact test sees
+                           (size_t)c->cap * (sizeof(MdShape) + sizeof(RouteDesc)) + 32;   // the shapes the contact test sees; the route records
         if (s->route_n) {
             NEED(s->route_segs); NEED(s->route_verts); NEED(s->route_aux); NEED(w->run_off); NEED(w->runs);
             if (c->route_seg_cap < 1 || c->route_vert_cap < 8) {
