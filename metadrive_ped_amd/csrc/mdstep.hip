@@ -2353,8 +2353,55 @@ __device__ __forceinline__ int points_in_polygon_wave4(const float* xy, int n, c
 // registers, so the look-ahead heading after the projection needs no second pass over memory; the end point and the
 // outline's bounding box come precomputed (MdWorld.poly_aux); the four chassis corners of a candidate are tested in
 // one pass over the outline's edges, and only those inside its bounding box.
-__device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
-                                  int lane_id, const RouteDesc* l_desc) {
+// Scratch of the decision stage in LDS (over the route builder's scratch, which the traffic manager uses later in the step).
+struct DecideLds {
+    unsigned long long* key;   // [cap] (gap bits << 32 | slot) of the front object found so far; kNoFront = none
+    float* cur_long;           // [cap] own longitudinal; NaN = arrived (no decision)
+    float* heading;            // [cap] heading of the route one metre ahead
+    uint32_t* pairs;           // [kPairCap] (vehicle | candidate << 8 | corners-in-box << 16); kNullPair = nothing
+    int* ctl;                  // [0] pairs reserved, [1] pair tickets
+};
+constexpr int kPairCap = 256;
+constexpr uint32_t kNullPair = 0xffffffffu;
+constexpr unsigned long long kNoFront = ~0ull;
+__host__ __device__ constexpr size_t decide_lds_bytes(int cap) { return (size_t)cap * 16 + (size_t)kPairCap * 4 + 16; }
+// the scratch both users share: the route builder's [seg_cap + 1] doubles, [seg_cap][2] floats, [seg_cap] ints
+__host__ __device__ constexpr size_t sc_scratch_bytes(bool routes, int seg_cap, int cap) {
+    const size_t a = routes ? (size_t)seg_cap * 20 + 8 : 0, b = decide_lds_bytes(cap);
+    return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+
+// One (speed-control vehicle, near mover) pair of get_find_front_back_objs_single_lane (md_tidm_front_gap), by one wave: the chassis
+// corners inside the outline's bounding box against the outline (lanes = polygon edges, all corners in one pass), then the
+// projection on the route with lanes = pieces.  A mover that counts enters the vehicle's key by an LDS atomic min: the smallest gap,
+// among equal gaps the lowest slot -- what the serial search's ascending order and strict < leave.
+__device__ __forceinline__ void tidm_pair_wave(const MdState& s, int slot, int j, int want, int lane_id, const RouteDesc* l_desc,
+                                               const DecideLds& dl) {
+    const RouteDesc rd = l_desc[slot];
+    MdPoly route;
+    route.segs = uni_p(rd.segs);
+    route.n = uni_i(rd.n);
+    route.length = 0.0f;
+    const float* pv = uni_p(rd.verts);
+    const int n_v = uni_i(rd.n_verts) & ~kDescNoAux;
+    const MdShape o = s.shape[j];   // wave-uniform
+    const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
+    const float qx[4] = {o.cx + ex + fx, o.cx + ex - fx, o.cx - ex - fx, o.cx - ex + fx};
+    const float qy[4] = {o.cy + ey + fy, o.cy + ey - fy, o.cy - ey - fy, o.cy - ey + fy};
+    if (points_in_polygon_wave4(pv, n_v, qx, qy, want, lane_id) == 0) return;
+    float lg, lt;
+    poly_local_wave(route, o.cx, o.cy, lane_id, &lg, &lt);
+    const float gap = lg - dl.cur_long[slot];
+    if (lane_id == 0 && gap > 0.0f && gap < MD_TIDM_MAX_DIST)
+        atomicMin(&dl.key[slot], ((unsigned long long)__float_as_uint(gap) << 32) | (unsigned)j);
+}
+
+// TrajectoryIDMPolicy.act of the vehicle in `slot`, everything BEFORE the front search's candidates are looked at, by one wave
+// (md_tidm_vehicle is the serial form): arrival, own projection, the heading ahead; a vehicle due for speed control leaves its
+// (vehicle, near mover) pairs on the scene's pair list, which ALL waves then work off (tidm_pair_wave) -- a crowded vehicle's
+// search was the tail of the stage when one wave walked its movers alone.
+__device__ __forceinline__ void tidm_prepare_wave(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int slot, int k,
+                                  int lane_id, const RouteDesc* l_desc, const DecideLds& dl) {
 #ifdef MD_STAMP
     bool st_ = lane_id == 0;   // diagnostic: the scene's first reactive vehicle, apart for its speed-control steps (slots 16.. / 24..)
     for (int q = c.agents_per_env; q < slot; ++q) st_ = st_ && !(s.nav[q].ck0 == MD_SC_IDM && md_present(s.shape[q].flags));
@@ -2389,7 +2436,10 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
         end_y = ge.sy + (length - ge.cum) * ge.dy;
     }
     if (md_norm(px - end_x, py - end_y) < MD_TIDM_DEST_RADIUS) {
-        if (lane_id == 0) s.nav[slot].ck0 = MD_SC_ARRIVED;
+        if (lane_id == 0) {
+            s.nav[slot].ck0 = MD_SC_ARRIVED;   // no action this step: the vehicle rolls on with its previous one
+            dl.cur_long[slot] = __int_as_float(0x7fc00000);
+        }
         return;
     }
     MD_FINE_STAMP(st_, so_ + 1);
@@ -2429,41 +2479,41 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
         float tmp;
         best = poly_local_wave(route, px, py, lane_id, &cur_long, &tmp);
     }
-    int front = -1;
-    float front_dist = MD_TIDM_MAX_DIST;
     MD_FINE_STAMP(st_, so_ + 2);
     if (do_speed_control) {
-        // md_tidm_front_gap, wave form: lanes = movers for the 20 m filter; the survivors one after the other: the chassis
-        // corners inside the outline's bounding box against the outline (lanes = polygon edges, all corners in one pass),
-        // then the projection on the route with lanes = pieces.  Ascending slot order and a strict < keep the lowest
-        // slot among equal gaps.
+        // md_tidm_front_gap's filters that need no route: lanes = movers -- present, within 20 m, and a chassis corner inside the
+        // outline's bounding box (a point outside it is outside the outline).  The survivors go on the pair list; when the list
+        // is full (never in practice: kPairCap pairs per scene) this wave works its pairs off itself, after publishing cur_long.
+        if (lane_id == 0) dl.cur_long[slot] = cur_long;
+        wave_sync();
         for (int j0 = 0; j0 < c.cap; j0 += 64) {
             const int jl = j0 + lane_id;
-            bool near = false;
+            int want = 0;
             if (jl < c.cap && jl != slot) {
                 const MdShape o = s.shape[jl];
-                near = md_present(o.flags) && !(md_norm(o.cx - px, o.cy - py) > MD_TIDM_MAX_DIST);
-            }
-            unsigned long long mk = __ballot(near);
-            while (mk) {
-                const int j = j0 + __ffsll((long long)mk) - 1;
-                mk &= mk - 1;
-                const MdShape o = s.shape[j];   // wave-uniform
-                const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
-                const float qx[4] = {o.cx + ex + fx, o.cx + ex - fx, o.cx - ex - fx, o.cx - ex + fx};
-                const float qy[4] = {o.cy + ey + fy, o.cy + ey - fy, o.cy - ey - fy, o.cy - ey + fy};
-                int want = 0;   // a point outside the polygon's bounding box is outside the polygon
+                if (md_present(o.flags) && !(md_norm(o.cx - px, o.cy - py) > MD_TIDM_MAX_DIST)) {
+                    const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
+                    const float qx[4] = {o.cx + ex + fx, o.cx + ex - fx, o.cx - ex - fx, o.cx - ex + fx};
+                    const float qy[4] = {o.cy + ey + fy, o.cy + ey - fy, o.cy - ey - fy, o.cy - ey + fy};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (!(qx[q] < bx0 || qx[q] > bx1 || qy[q] < by0 || qy[q] > by1)) want |= 1 << q;
-                if (want == 0) continue;
-                if (points_in_polygon_wave4(pv, n_v, qx, qy, want, lane_id) == 0) continue;
-                float lg, lt;
-                poly_local_wave(route, o.cx, o.cy, lane_id, &lg, &lt);
-                const float gap = lg - cur_long;
-                if (gap > 0.0f && gap < front_dist) {
-                    front_dist = gap;
-                    front = j;
+                    for (int q = 0; q < 4; ++q)
+                        if (!(qx[q] < bx0 || qx[q] > bx1 || qy[q] < by0 || qy[q] > by1)) want |= 1 << q;
+                }
+            }
+            unsigned long long mk = __ballot(want != 0);
+            if (mk == 0) continue;
+            const int cnt = __popcll(mk);
+            int r0 = 0;
+            if (lane_id == 0) r0 = atomicAdd(&dl.ctl[0], cnt);
+            r0 = uni_i(r0);
+            if (r0 + cnt <= kPairCap) {
+                if (want != 0) dl.pairs[r0 + __popcll(mk & ((1ull << lane_id) - 1ull))] = (uint32_t)slot | ((uint32_t)jl << 8) | ((uint32_t)want << 16);
+            } else {
+                for (int i = r0 + lane_id; i < kPairCap; i += 64) dl.pairs[i] = kNullPair;   // the part of the reservation inside the list
+                while (mk) {
+                    const int b = __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    tidm_pair_wave(s, slot, j0 + b, uni_i(__shfl(want, b, 64)), lane_id, l_desc, dl);
                 }
             }
         }
@@ -2492,7 +2542,10 @@ __device__ __forceinline__ void tidm_vehicle_wave(const MdWorld& w, const MdStat
         lane_heading = route.segs[ih].heading;
     }
     MD_FINE_STAMP(st_, so_ + 4);
-    if (lane_id == 0) md_tidm_decide(&route, &s, slot, do_speed_control, front, front_dist, lane_heading);
+    if (lane_id == 0) {
+        dl.cur_long[slot] = cur_long;
+        dl.heading[slot] = lane_heading;
+    }
     MD_FINE_STAMP(st_, so_ + 5);
 }
 
@@ -2632,9 +2685,17 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
                                                                           ((c.n_side + c.n_lane_line) > 0 ? 2 * kDetPairs : 0)) + 7) & ~(uintptr_t)7);
     float* l_pts = reinterpret_cast<float*>(l_len + c.route_seg_cap + 1);
     int* l_link = reinterpret_cast<int*>(l_pts + 2 * c.route_seg_cap);
-    int32_t* l_rn = l_link + c.route_seg_cap;   // [cap][4]: route_n of the scene (the decisions read it first: not a global round trip)
+    // the decision stage's scratch shares the builder's (the traffic manager builds routes later in the step)
+    DecideLds dl;
+    dl.key = reinterpret_cast<unsigned long long*>(l_len);
+    dl.cur_long = reinterpret_cast<float*>(dl.key + cap);
+    dl.heading = dl.cur_long + cap;
+    dl.pairs = reinterpret_cast<uint32_t*>(dl.heading + cap);
+    dl.ctl = reinterpret_cast<int*>(dl.pairs + kPairCap);
+    unsigned char* l_scratch_end = reinterpret_cast<unsigned char*>(l_len) + sc_scratch_bytes(g.route_n != nullptr, c.route_seg_cap, cap);
+    int32_t* l_rn = reinterpret_cast<int32_t*>(l_scratch_end);   // [cap][4]: route_n of the scene (the decisions read it first: not a global round trip)
     // [cap] the movers as the agent's contact test sees them: after the integration, BEFORE the traffic manager's after_step
-    MdShape* l_shape_ct = reinterpret_cast<MdShape*>((reinterpret_cast<uintptr_t>(g.route_n != nullptr ? (void*)(l_rn + 4 * cap) : (void*)l_len) + 15) & ~(uintptr_t)15);
+    MdShape* l_shape_ct = reinterpret_cast<MdShape*>((reinterpret_cast<uintptr_t>(g.route_n != nullptr ? (void*)(l_rn + 4 * cap) : (void*)l_scratch_end) + 15) & ~(uintptr_t)15);
     RouteDesc* l_desc = reinterpret_cast<RouteDesc*>(l_shape_ct + cap);   // [cap] what the decisions know about each slot's route
 
     MD_STAMP_AT(0);
@@ -2796,8 +2857,11 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
                 *l_ctr = 0;
             }
         }
+        for (int j = tid; j < cap; j += kBlock) dl.key[j] = kNoFront;
+        if (tid == 64) dl.ctl[0] = dl.ctl[1] = 0;
         __syncthreads();
         const int n_list = __builtin_amdgcn_readfirstlane(*l_n);
+        // (A) per vehicle: arrival, own projection, heading ahead, the speed-control vehicles' candidate pairs
         for (int guard = 0; guard < cap; ++guard) {   // at most cap tickets per wave: the loop ends whatever the counter holds
             int i = 0;
             if (lane == 0) i = atomicAdd(l_ctr, 1);
@@ -2805,7 +2869,34 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             if (i < 0 || i >= n_list) break;
             const int slot = __builtin_amdgcn_readfirstlane(l_list[i]);
             if (slot < A || slot >= cap) break;        // never index with anything but a mover slot
-            tidm_vehicle_wave(w, s, c, e, slot, k, lane, l_desc);
+            tidm_prepare_wave(w, s, c, e, slot, k, lane, l_desc, dl);
+        }
+        __syncthreads();
+        // (B) the pairs, one per ticket
+        const int n_pairs = min(__builtin_amdgcn_readfirstlane(dl.ctl[0]), kPairCap);
+        for (int guard = 0; guard < kPairCap; ++guard) {
+            int i = 0;
+            if (lane == 0) i = atomicAdd(&dl.ctl[1], 1);
+            i = __builtin_amdgcn_readfirstlane(i);
+            if (i < 0 || i >= n_pairs) break;
+            const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)dl.pairs[i]);
+            if (pr == kNullPair) continue;
+            const int slot = pr & 0xff, j = (pr >> 8) & 0xff, want = (pr >> 16) & 0xf;
+            if (slot < A || slot >= cap || j >= cap) break;
+            tidm_pair_wave(s, slot, j, want, lane, l_desc, dl);
+        }
+        __syncthreads();
+        // (C) steering + acceleration (md_tidm_decide): one lane per vehicle
+        for (int i = tid; i < n_list; i += kBlock) {
+            const int slot = l_list[i];
+            const float cl = dl.cur_long[slot];
+            if (slot >= A && slot < cap && cl == cl) {   // NaN: arrived
+                const unsigned long long key = dl.key[slot];
+                const int front = (key == kNoFront) ? -1 : (int)(key & 0xffffffffull);
+                const float front_dist = (key == kNoFront) ? MD_TIDM_MAX_DIST : __uint_as_float((unsigned)(key >> 32));
+                const int do_speed_control = (k % MD_TIDM_BATCH) == s.nav[slot].timer;
+                md_tidm_decide(nullptr, &s, slot, do_speed_control, front, front_dist, dl.heading[slot]);
+            }
         }
         __syncthreads();
         MD_STAMP_AT(2);
@@ -3443,7 +3534,8 @@ __attribute__((visibility("default"))) int md_step(const MdWorld* w, const MdSta
                            (size_t)c->agents_per_env * sizeof(MdTrajLoc) + 16 +
                            (size_t)(c->agents_per_env + 2) * (size_t)(c->n_side + c->n_lane_line) * sizeof(int) +
                            ((c->n_side + c->n_lane_line) > 0 ? 2 * (size_t)kDetPairs * sizeof(int) : 0) +
-                           (s->route_n ? (size_t)c->route_seg_cap * 20 + 16 + (size_t)c->cap * 16 : 0) +   // route_n; positions, links, lengths of a route being built
+                           sc_scratch_bytes(s->route_n != nullptr, c->route_seg_cap, c->cap) + 16 +   // the decision stage's scratch / positions, links, lengths of a route being built
+                           (s->route_n ? (size_t)c->cap * 16 : 0) +   // route_n
                            (size_t)c->cap * (sizeof(MdShape) + sizeof(RouteDesc)) + 32;   // the shapes the contact test sees; the route records
         if (s->route_n) {
             NEED(s->route_segs); NEED(s->route_verts); NEED(s->route_aux); NEED(w->run_off); NEED(w->runs);
