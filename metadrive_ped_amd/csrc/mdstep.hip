@@ -2338,11 +2338,16 @@ __device__ __forceinline__ int points_in_polygon_wave4(const float* xy, int n, c
         const int j = (ii == 0) ? n - 1 : ii - 1;
         const float xi = xy[2 * ii], yi = xy[2 * ii + 1], xj = xy[2 * j], yj = xy[2 * j + 1];
         // md_polygon_edge_crosses, the same expression for each point
-#define MD_CROSS(q) (v && (((yi > py[q]) != (yj > py[q])) && (px[q] < (xj - xi) * (py[q] - yi) / (yj - yi) + xi)))
-        if (want & 1) c0 += __popcll(__ballot(MD_CROSS(0)));
-        if (want & 2) c1 += __popcll(__ballot(MD_CROSS(1)));
-        if (want & 4) c2 += __popcll(__ballot(MD_CROSS(2)));
-        if (want & 8) c3 += __popcll(__ballot(MD_CROSS(3)));
+        // the division only where an edge of this chunk straddles the point's y at all (two edges of the whole outline, usually)
+#define MD_CROSS(q, cnt)                                                                                       \
+        if (want & (1 << q)) {                                                                                 \
+            const bool st = v && ((yi > py[q]) != (yj > py[q]));                                               \
+            if (__ballot(st)) cnt += __popcll(__ballot(st && (px[q] < (xj - xi) * (py[q] - yi) / (yj - yi) + xi))); \
+        }
+        MD_CROSS(0, c0)
+        MD_CROSS(1, c1)
+        MD_CROSS(2, c2)
+        MD_CROSS(3, c3)
 #undef MD_CROSS
     }
     return (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c3 & 1) << 3);
@@ -2651,6 +2656,10 @@ __device__ __forceinline__ void build_route_wave(int32_t* rn, MdSeg* segs, int s
 
 // Register budget of the scenario kernel: 8 waves per SIMD (64 VGPRs, one spilled) -- 2048 scenes = 256 CUs x 8 workgroups
 // are then resident at once, one round instead of two (measured 148 vs 173 us at the compiler's own choice)
+// Diagnostic builds only (tools/ab/sc_knockout.sh): stages left out to read their marginal cost off the launch time.  0 in the product.
+#ifndef MD_SC_SKIP
+#define MD_SC_SKIP 0
+#endif
 #ifndef MD_SC_WAVES_EU
 #define MD_SC_WAVES_EU 8
 #endif
@@ -2829,6 +2838,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
     MD_STAMP_AT(1);
     const int just_reset = do_reset ? 1 : 0;
     const int k = just_reset ? 0 : s.nav[0].steps + 1;   // engine.episode_step of this step
+    constexpr int kSkip = MD_SC_SKIP;
     if (!just_reset) {
         // Work list of the reactive vehicles, those due for speed control in this step FIRST (their front search makes them
         // ~2.5x as expensive as the others); the waves then take vehicles off the list one by one through an LDS counter,
@@ -2869,6 +2879,10 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             if (i < 0 || i >= n_list) break;
             const int slot = __builtin_amdgcn_readfirstlane(l_list[i]);
             if (slot < A || slot >= cap) break;        // never index with anything but a mover slot
+            if (kSkip & 32) {
+                if (lane == 0) dl.cur_long[slot] = __int_as_float(0x7fc00000);
+                continue;
+            }
             tidm_prepare_wave(w, s, c, e, slot, k, lane, l_desc, dl);
         }
         __syncthreads();
@@ -2880,7 +2894,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             i = __builtin_amdgcn_readfirstlane(i);
             if (i < 0 || i >= n_pairs) break;
             const uint32_t pr = (uint32_t)__builtin_amdgcn_readfirstlane((int)dl.pairs[i]);
-            if (pr == kNullPair) continue;
+            if (pr == kNullPair || (kSkip & 16)) continue;
             const int slot = pr & 0xff, j = (pr >> 8) & 0xff, want = (pr >> 16) & 0xf;
             if (slot < A || slot >= cap || j >= cap) break;
             tidm_pair_wave(s, slot, j, want, lane, l_desc, dl);
@@ -2902,7 +2916,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         MD_STAMP_AT(2);
         for (int j = tid; j < cap; j += kBlock) {
             if (c.ego_replay && j < A) md_scenario_replay_ego(&s, &c, j, k);   // agent_policy = ReplayEgoCarPolicy
-            else md_integrate_mover(&s, &c, j);
+            else if (!(kSkip & 128)) md_integrate_mover(&s, &c, j);
             l_shape_ct[j] = l_shape[j];   // what the contact test below sees
         }
         __syncthreads();
@@ -2916,13 +2930,13 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         copy16(l_shape_ct, l_shape, cap * (int)sizeof(MdShape), tid, kBlock);
         __syncthreads();
     }
-    if (wave == 1) {
+    if (wave == 1 && !(kSkip & 4)) {
         MdState sc = s;
         sc.shape = l_shape_ct;
         for (int a = 0; a < A; ++a) contacts_vehicle(w, sc, c, e, a, lane, l_cfl);
     }
     // ---- after_step of the traffic manager: lanes = track slots, in slot order ----
-    if (wave == 0) {
+    if (wave == 0 && !(kSkip & 64)) {
         for (int j0 = A; j0 < cap; j0 += 64) {
             const int j = j0 + lane;
             const bool in = j < cap;
@@ -2966,12 +2980,17 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             ref.length = 0.0f;
             MdTrajLoc L;
             float ref_len;
-            traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L, &ref_len);
+            if (kSkip & 8) {
+                L.lng = L.lat = L.heading_at = L.lat_dy = 0.0f;
+                L.lat_dx = 1.0f;
+                ref_len = 100.0f;
+            } else
+                traj_locate_wave(ref, s.shape[a].cx, s.shape[a].cy, lane, &L, &ref_len);
             if (lane == 0) {
                 l_loc[a] = L;
                 l_count[3] = __float_as_int(ref_len);   // single-agent scenes (md_step refuses others): one length
             }
-        } else if (wave >= 2 && fused_det) {
+        } else if (wave >= 2 && fused_det && !(kSkip & 2)) {
             // waves 2 and 3 have nothing to do in this stage and the next: the side / lane-line detectors of the agent,
             // each wave one half of the scene's line pieces (the poses are final here)
             const MdShape me = s.shape[a];
@@ -3011,7 +3030,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         md_scenario_observe_at(&w, &s, &c, e, a, just_reset, &l_loc[a], __int_as_float(l_count[3]), 0);
     }
     MD_STAMP_AT(6);
-    if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
+    if (c.n_beams > 0 && !(kSkip & 1)) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, nullptr);
     __syncthreads();
     MD_STAMP_AT(7);
     if (fused_det) {   // after the observation (whose lane 0 filled these dims with "nothing seen")
