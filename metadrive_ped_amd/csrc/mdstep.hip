@@ -75,6 +75,11 @@ __device__ const int* g_env_order = nullptr;
 #define MD_STAMP_AT(i) do { } while (0)
 #define MD_FINE_STAMP(cond, i) do { } while (0)
 #endif
+// Diagnostic builds only (tools/ab/env_knockout.sh): stages of the fused env kernel left out to read their marginal cost off the
+// launch time.  0 in the product.
+#ifndef MD_ENV_SKIP
+#define MD_ENV_SKIP 0
+#endif
 
 __device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
@@ -1719,16 +1724,17 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         if (nd + na <= kWaves) {
             // everything fits one round: one wave per job, the vehicle's data in scalar registers
             for (int item = wave; item < nd + na; item += kWaves) {
-                if (item < nd) localize_vehicle(w, lanes, roads, s, e, kth(drv_lo, drv_hi, item), lane, l_onlane);
-                else contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item - nd), lane, l_cfl);
+                if (item < nd) {
+                    if (!(MD_ENV_SKIP & 4)) localize_vehicle(w, lanes, roads, s, e, kth(drv_lo, drv_hi, item), lane, l_onlane);
+                } else if (!(MD_ENV_SKIP & 8)) contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item - nd), lane, l_cfl);
             }
         } else {
             // many vehicles awake: two localisations per wave (32 lanes each), halving the rounds
             const int npair = (nd + 1) >> 1;
             for (int item = wave; item < npair + na; item += kWaves) {
-                if (item < npair)
-                    localize_pair(w, lanes, roads, s, e, kth(drv_lo, drv_hi, 2 * item), kth(drv_lo, drv_hi, 2 * item + 1), lane, l_onlane);
-                else
+                if (item < npair) {
+                    if (!(MD_ENV_SKIP & 4)) localize_pair(w, lanes, roads, s, e, kth(drv_lo, drv_hi, 2 * item), kth(drv_lo, drv_hi, 2 * item + 1), lane, l_onlane);
+                } else if (!(MD_ENV_SKIP & 8))
                     contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item - npair), lane, l_cfl);
             }
         }
@@ -1777,8 +1783,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         // (reads poses / lanes / speeds, writes the traffic slots' action, IDM timer / target lane and PID state:
         // disjoint from what observe writes -- obs, reward, the agent's flags / steps / energy).
         if (wave == 0) {
-            for (int a = 0; a < c.agents_per_env; ++a) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
-        } else {
+            if (!(MD_ENV_SKIP & 16))
+                for (int a = 0; a < c.agents_per_env; ++a) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+        } else if (!(MD_ENV_SKIP & 2)) {
             for (int j = c.agents_per_env + wave - 1; j < cap; j += kWaves - 1) {
                 const int f = s.shape[j].flags;  // wave-uniform
                 if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
@@ -1795,7 +1802,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         MD_STAMP_AT(8);
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
-    if (PH & PH_LIDAR) {
+    if ((PH & PH_LIDAR) && !(PH == PH_ALL && (MD_ENV_SKIP & 1))) {
         if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr);
     }
 
