@@ -8,8 +8,10 @@ Sharding: an engine owns envs [env_seed_offset, env_seed_offset + num_envs) of t
 env g uses scenario seed start_seed + g % num_scenarios, so results do not depend on how many
 GPUs the batch is split over.
 """
+import copy
 import ctypes as C
 import os
+from collections import OrderedDict
 
 import numpy as np
 
@@ -107,13 +109,36 @@ def _build_one_marl_pg(job):
     from metadrive_ped_amd.mapgen.tables import spawn_tables
     from metadrive_ped_amd.marl import PG_SPAWN_ROADS, RoundaboutScene
     s, mc, dist, scene_cfg = job
-    pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
-               generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
-    mt = MapTables(pg)
+    mt = copy.copy(_map_tables_for(s, mc, dist))   # the cached tables stay as generated
     roads = [tuple(r) for r in scene_cfg["spawn_roads"]] if scene_cfg.get("spawn_roads") else PG_SPAWN_ROADS
     mt.respawn = spawn_tables(mt, roads, mc["lane_num"], fixed_destination=True)   # stacked per map by WorldTables
     sc_cfg = dict(scene_cfg, exit_length=mc["exit_length"])
     return mt, RoundaboutScene(s, mt, sc_cfg, roads, True)
+
+
+# Maps built by THIS process, by what they were generated from: a rebuild that only changes the scenes on them (random_traffic: new
+# traffic at every env.reset(); another traffic density) does not generate them again.  The build workers are persistent and
+# build_all keeps a job on the same worker (sticky), so their caches hit as well.
+_MAP_CACHE = OrderedDict()
+_MAP_CACHE_MAX = 512
+MAPS_GENERATED = [0]          # what the cache did not have (tests read it)
+
+
+def _map_tables_for(s, mc, dist):
+    import pickle
+    key = pickle.dumps((s, sorted(mc.items(), key=lambda kv: str(kv[0])), dist), protocol=4)
+    mt = _MAP_CACHE.get(key)
+    if mt is not None:
+        _MAP_CACHE.move_to_end(key)
+        return mt
+    pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
+               generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
+    mt = MapTables(pg)
+    MAPS_GENERATED[0] += 1
+    _MAP_CACHE[key] = mt
+    while len(_MAP_CACHE) > _MAP_CACHE_MAX:
+        _MAP_CACHE.popitem(last=False)
+    return mt
 
 
 def _build_one(job):
@@ -129,11 +154,10 @@ def _build_one(job):
             mc["lane_width"] = float(rng.rand() * (4.5 - 3.0) + 3.0)     # MAX_LANE_WIDTH / MIN_LANE_WIDTH (base_map.py:38-39)
         if scene_cfg.get("random_lane_num"):
             mc["lane_num"] = int(rng.randint(2, 3 + 1))                   # MIN_LANE_NUM .. MAX_LANE_NUM (base_map.py:40-41)
-    pg = PGMap(s, lane_num=mc["lane_num"], lane_width=mc["lane_width"], exit_length=mc["exit_length"],
-               generate_type=mc["type"], generate_config=mc["config"], block_dist=dist)
-    mt = MapTables(pg)
+    mt = _map_tables_for(s, mc, dist)
     if scene_cfg["traffic_mode"] in ("respawn", "hybrid") and abs(scene_cfg["traffic_density"]) >= 1e-2:
         from metadrive_ped_amd.mapgen.tables import respawn_tables
+        mt = copy.copy(mt)                      # the cached tables stay as generated
         mt.respawn = respawn_tables(mt, s)
     return mt, EnvScene(s, mt, scene_cfg)
 
@@ -206,7 +230,7 @@ class HostScene:
             mt, marl_scenes, self.spawn = _build_marl(cfg, scene_cfg, uniq)
             built = [(mt, marl_scenes[s]) for s in uniq]
         else:
-            built = hostpool.build_all(build_fn, jobs, workers=int(cfg.get("build_workers", 0)), cache=bool(cfg.get("build_cache", False)))
+            built = hostpool.build_all(build_fn, jobs, workers=int(cfg.get("build_workers", 0)), cache=bool(cfg.get("build_cache", False)), sticky=True)
         for s, (mt, sc) in zip(uniq, built):
             if shared_map:
                 map_of_seed[s] = 0

@@ -88,8 +88,10 @@ class BuildPool:
     def alive(self):
         return all(p.poll() is None for p in self.procs)
 
-    def map(self, fn, jobs, chunk=0):
-        """[fn(j) for j in jobs] on the workers; fn is a module-level function."""
+    def map(self, fn, jobs, chunk=0, sticky=False):
+        """[fn(j) for j in jobs] on the workers; fn is a module-level function.  sticky: job i always goes to worker
+        (i // chunk) % workers with a chunk size that depends on len(jobs) only -- the same job list meets the same workers
+        again, whose per-process caches (engine._MAP_CACHE) then hit; otherwise the workers take chunks as they get free."""
         jobs = list(jobs)
         n = len(jobs)
         if n == 0:
@@ -100,14 +102,20 @@ class BuildPool:
         errors = []
         cursor = [0]
         take = threading.Lock()
+        mine = {id(p): [a for k, a in enumerate(starts) if k % len(self.procs) == w] for w, p in enumerate(self.procs)}
 
         def drive(p):
             while not errors:
                 with take:
-                    if cursor[0] >= len(starts):
-                        return
-                    a = starts[cursor[0]]
-                    cursor[0] += 1
+                    if sticky:
+                        if not mine[id(p)]:
+                            return
+                        a = mine[id(p)].pop(0)
+                    else:
+                        if cursor[0] >= len(starts):
+                            return
+                        a = starts[cursor[0]]
+                        cursor[0] += 1
                 try:
                     _send(p.stdin, (fn.__module__, fn.__name__, jobs[a:a + chunk]))
                     ok, res = _recv(p.stdout)
@@ -175,9 +183,9 @@ def get(auto_start=True):
     return start()
 
 
-def build_all(fn, jobs, workers=0, cache=False, min_parallel=16):
+def build_all(fn, jobs, workers=0, cache=False, min_parallel=16, sticky=False):
     """[fn(j) for j in jobs]: on the persistent workers when there are enough jobs and the pool is (or may be) running,
-    serially otherwise.  cache=True memoises pickled results by the hash of the pickled job."""
+    serially otherwise.  cache=True memoises pickled results by the hash of the pickled job; sticky: see Pool.map."""
     jobs = list(jobs)
     if workers == 1:
         return [fn(j) for j in jobs]
@@ -194,7 +202,7 @@ def build_all(fn, jobs, workers=0, cache=False, min_parallel=16):
             else:
                 out[i] = pickle.loads(b)
     pool = get() if len(todo) >= min_parallel else None
-    res = pool.map(fn, [jobs[i] for i in todo]) if pool is not None else [fn(jobs[i]) for i in todo]
+    res = pool.map(fn, [jobs[i] for i in todo], sticky=sticky) if pool is not None else [fn(jobs[i]) for i in todo]
     for i, r in zip(todo, res):
         out[i] = r
         if cache and _MEMO_BYTES[0] < _MEMO_LIMIT:
@@ -202,6 +210,11 @@ def build_all(fn, jobs, workers=0, cache=False, min_parallel=16):
             _MEMO[keys[i]] = b
             _MEMO_BYTES[0] += len(b)
     return out
+
+
+def worker_pid(_job=None):
+    """The process a job runs in (tests: sticky routing)."""
+    return os.getpid()
 
 
 def clear_memo():

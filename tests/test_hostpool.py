@@ -85,3 +85,30 @@ def test_reset_with_new_seeds_never_forks_the_gpu_process(monkeypatch):
     assert env.engine.host.seeds[:3] == [5000, 5001, 5002]
     assert dt < 30.0, dt
     env.close()
+
+
+def test_sticky_jobs_meet_the_same_worker_again():
+    pool = hostpool.get()
+    a = pool.map(hostpool.worker_pid, list(range(64)), sticky=True)
+    b = pool.map(hostpool.worker_pid, list(range(64)), sticky=True)
+    assert a == b and len(set(a)) > 1
+
+
+def test_random_traffic_reset_reuses_the_maps():
+    """random_traffic=True: env.reset() draws new traffic on the SAME maps -- the maps are not generated again (engine._MAP_CACHE),
+    the traffic differs, and what comes out equals a build from scratch with the same traffic epoch."""
+    from metadrive_ped_amd import engine
+    user = dict(num_envs=6, num_scenarios=6, map=3, traffic_density=0.2, start_seed=900, random_traffic=True, build_workers=1)
+    engine._MAP_CACHE.clear()
+    h0 = HostScene(make_config(dict(user, traffic_epoch=0)))
+    made = engine.MAPS_GENERATED[0]
+    h1 = HostScene(make_config(dict(user, traffic_epoch=1)))
+    assert engine.MAPS_GENERATED[0] == made                      # no map generated for the second draw
+    assert not np.array_equal(h0.state["shape0"].view(np.uint8), h1.state["shape0"].view(np.uint8))
+    for k in h0.world.arrays:                                     # same maps
+        assert np.array_equal(np.ascontiguousarray(h0.world.arrays[k]).view(np.uint8), np.ascontiguousarray(h1.world.arrays[k]).view(np.uint8)), k
+    engine._MAP_CACHE.clear()
+    _same(h1, HostScene(make_config(dict(user, traffic_epoch=1))))
+    # respawn tables are added to a COPY: the cached tables stay as generated
+    HostScene(make_config(dict(user, traffic_mode="respawn", traffic_epoch=0)))
+    assert all(mt.respawn is None for mt in engine._MAP_CACHE.values())
