@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MD_ABI_VERSION 10
+#define MD_ABI_VERSION 11
 
 /* ---- error codes ------------------------------------------------------------------------- */
 #define MD_OK 0
@@ -41,6 +41,7 @@ extern "C" {
 #define MD_EABI (-4)     /* struct size mismatch between caller and library                   */
 
 /* ---- limits ------------------------------------------------------------------------------ */
+#define MD_POLY_GROUP 8      /* pieces per MdWorld.poly_ball group                              */
 #define MD_MAX_CAP 128        /* mover slots per env the kernels are built for                  */
 #define MD_MAX_BEAMS 1024     /* lidar beams per agent                                          */
 #define MD_ROUTE_LEN 48       /* checkpoints (road nodes) per route                             */
@@ -293,6 +294,14 @@ typedef struct MdWorld {
      * policy on a route cut at the spawn frame, as scenario_traffic_manager.py:216-236 does; NULL = such spawns are replayed. */
     const int32_t* run_off;
     const int32_t* runs;
+    /* scenario mode, optional (NULL = every projection walks all pieces): per mover slot, for each group of MD_POLY_GROUP consecutive
+     * pieces of its static polyline, [4] = centre x, y and radius of a circle that contains the group's pieces (with a margin
+     * >= 1e-3 m for the rounding to float), 0 -- poly_ball_off [n_envs * cap + 1] is the CSR into poly_ball (slot n has
+     * ceil(n_pieces / MD_POLY_GROUP) groups).  The projections (InterpolatingLine.local_coordinates = arg-min over the pieces)
+     * use them as an EXACT cull: only groups whose circle comes within the smallest "farthest point of a circle" are evaluated;
+     * the arg-min, its tie-break and every number derived from it are those of the full walk. */
+    const float* poly_ball;
+    const int32_t* poly_ball_off;
 } MdWorld;
 
 /* Dynamic state: one entry per mover unless noted. */

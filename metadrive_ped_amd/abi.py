@@ -9,7 +9,8 @@ import ctypes as C
 
 import numpy as np
 
-MD_ABI_VERSION = 10
+MD_ABI_VERSION = 11
+MD_POLY_GROUP = 8     # pieces per MdWorld.poly_ball group
 MD_OK, MD_EINVAL, MD_ELAUNCH, MD_ENODEV, MD_EABI = 0, -1, -2, -3, -4
 MD_MAX_CAP = 128
 MD_MAX_BEAMS = 1024
@@ -87,6 +88,7 @@ class MdWorld(C.Structure):
         ("spawn_off", P), ("spawn_place", P), ("spawn_lane", P), ("spawn_route", P), ("spawn_route_meta", P),
         ("n_dest", C.c_int32), ("n_vclass", C.c_int32),
         ("poly_off", P), ("segs", P), ("polyv_off", P), ("polyv", P), ("ckpt_off", P), ("ckpt_xy", P), ("track_meta", P), ("vclass", P), ("poly_aux", P), ("side_beam_cs", P), ("ll_beam_cs", P), ("quad_ball", P), ("run_off", P), ("runs", P),
+        ("poly_ball", P), ("poly_ball_off", P),
     ]
 
 

@@ -2198,29 +2198,76 @@ __global__ __launch_bounds__(64 * kWaveEnvs) void wave_step_kernel(MdWorld w, Md
 // Every lane first keeps the best of ITS segments (lane, lane + 64, ...: a strict < keeps the earliest), then ONE dense
 // wave reduction: the minimum distance by a 6-step butterfly, and among the lanes that hold it the lowest segment index
 // (a sparse set, usually one lane: ballot walk).
-__device__ __forceinline__ int poly_local_wave(const MdPoly& p, float px, float py, int lane_id, float* lng, float* lat) {
+// EXACT cull of a projection's pieces through MdWorld.poly_ball (a circle per group of MD_POLY_GROUP pieces, lanes = groups, at most
+// 64 of them): a piece of the group with the smallest "farthest point of the circle" U is at most U away, so the arg-min lies in a
+// group whose circle comes within U; every other group's pieces are farther than the minimum by more than the margin (the radii are
+// rounded up by >= 1e-3 m, the test adds 0.02 m + 1e-5 U against the rounding of the distances computed here), so neither the arg-min
+// nor a tie can sit in them.  Returns the mask of the groups to evaluate (never empty for n >= 1).
+constexpr int kPolyGroup = MD_POLY_GROUP;
+static_assert(kPolyGroup == 8, "the lane <-> (group, piece) mapping below packs eight groups of eight pieces into a wave");
+__device__ __forceinline__ unsigned long long poly_cull_wave(const float4* balls, int n, float px, float py, int lane_id) {
+    const int n_g = (n + kPolyGroup - 1) / kPolyGroup;
+    float lb = 3.0e38f, ub = 3.0e38f;
+    if (lane_id < n_g) {
+        const float4 b = balls[lane_id];
+        const float d = md_norm(px - b.x, py - b.y);
+        lb = d - b.z;
+        ub = d + b.z;
+    }
+    float U = ub;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) U = md_min(U, __shfl_xor(U, off, 64));
+    return __ballot(lane_id < n_g && lb <= U + (0.02f + 1.0e-5f * U));
+}
+// lane -> the piece it evaluates: piece (lane & 7) of the (lane >> 3)-th lowest group of `cand` (-1: none).  Lanes in ascending order
+// hold pieces in ascending order.
+__device__ __forceinline__ int cull_piece_of(unsigned long long cand, int n, int lane_id) {
+    int grp = -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int g = cand ? (__ffsll((long long)cand) - 1) : -1;   // wave-uniform
+        cand &= cand - 1;
+        if ((lane_id >> 3) == q) grp = g;
+    }
+    const int i = grp * kPolyGroup + (lane_id & 7);
+    return (grp >= 0 && i < n) ? i : -1;
+}
+__device__ __forceinline__ bool poly_can_cull(const float4* balls, int n) { return balls != nullptr && n > 2 * kPolyGroup && n <= 64 * kPolyGroup; }
+
+__device__ __forceinline__ int poly_local_wave(const MdPoly& p, const float4* balls, float px, float py, int lane_id, float* lng, float* lat) {
     // The coordinates come WITHOUT a second trip to memory (arg-min, then md_poly_local_at of that piece): every lane keeps the
-    // coordinates w.r.t. the best of its own pieces (the expressions of md_poly_local_at), the winner's are read from its lane --
-    // the lane of piece `best` is best & 63, and its own best IS that piece (strict <: the earliest of a lane's minima).
+    // coordinates w.r.t. the best of its own pieces (the expressions of md_poly_local_at), the winner's are read from its lane.
     float bd = 3.0e38f, bl = 0.0f, bt = 0.0f;
     int bi = 0x7fffffff;
-    for (int i = lane_id; i < p.n; i += 64) {
+    auto eval = [&](int i) {
         const MdSeg g = p.segs[i];
         const float d = md_seg_dist(&g, px, py);
-        if (d < bd) {
+        if (d < bd) {   // a lane meets its pieces in ascending order: the strict < keeps the earliest of its minima
             const float ddx = px - g.sx, ddy = py - g.sy;
             bd = d;
             bi = i;
             bl = g.cum + (ddx * g.dx + ddy * g.dy);
             bt = ddx * g.dy - ddy * g.dx;
         }
+    };
+    if (poly_can_cull(balls, p.n)) {
+        unsigned long long cand = poly_cull_wave(balls, p.n, px, py, lane_id);
+        while (cand) {   // eight groups per pass, ascending
+            const int i = cull_piece_of(cand, p.n, lane_id);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cand &= cand - 1;
+            if (i >= 0) eval(i);
+        }
+    } else {
+        for (int i = lane_id; i < p.n; i += 64) eval(i);
     }
     float m = bd;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
     const int best = wave_min_i(bi, bd == m, 0x7fffffff);
-    *lng = bcast_f(bl, best & 63);
-    *lat = bcast_f(bt, best & 63);
+    const int src = __ffsll((long long)__ballot(bd == m && bi == best)) - 1;   // the one lane that holds it
+    *lng = bcast_f(bl, src);
+    *lat = bcast_f(bt, src);
     return best;
 }
 
@@ -2229,6 +2276,8 @@ __device__ __forceinline__ int poly_local_wave(const MdPoly& p, float px, float 
 struct __attribute__((aligned(16))) RouteDesc {
     const MdSeg* segs;
     const float* verts;
+    const float4* balls;  // MdWorld.poly_ball of the slot's static polyline; nullptr: none (cut routes, tables not supplied)
+    int pad_[2];
     int n;
     int n_verts;          // bit 30: no aux record (end point / outline box are derived by the decision)
     float end_x, end_y;
@@ -2325,7 +2374,7 @@ __device__ __forceinline__ void traj_locate_wave(const MdPoly& p, float px, floa
         return;
     }
     *length = (p.n > 0) ? p.segs[p.n - 1].cum + p.segs[p.n - 1].len : 0.0f;
-    poly_local_wave(p, px, py, lane_id, &o->lng, &o->lat);
+    poly_local_wave(p, nullptr, px, py, lane_id, &o->lng, &o->lat);
     const float lng = o->lng;
     const int ih = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len > lng; });
     const int is = poly_first_wave(p, lane_id, [lng](const MdSeg& g) { return g.cum + g.len + 0.1f >= lng; });
@@ -2396,13 +2445,14 @@ __device__ __forceinline__ void tidm_pair_wave(const MdState& s, int slot, int j
     route.length = 0.0f;
     const float* pv = uni_p(rd.verts);
     const int n_v = uni_i(rd.n_verts) & ~kDescNoAux;
+    const float4* balls = uni_p(rd.balls);
     const MdShape o = s.shape[j];   // wave-uniform
     const float ex = o.c * o.hl, ey = o.s * o.hl, fx = -o.s * o.hw, fy = o.c * o.hw;
     const float qx[4] = {o.cx + ex + fx, o.cx + ex - fx, o.cx - ex - fx, o.cx - ex + fx};
     const float qy[4] = {o.cy + ey + fy, o.cy + ey - fy, o.cy - ey - fy, o.cy - ey + fy};
     if (points_in_polygon_wave4(pv, n_v, qx, qy, want, lane_id) == 0) return;
     float lg, lt;
-    poly_local_wave(route, o.cx, o.cy, lane_id, &lg, &lt);
+    poly_local_wave(route, balls, o.cx, o.cy, lane_id, &lg, &lt);
     const float gap = lg - dl.cur_long[slot];
     if (lane_id == 0 && gap > 0.0f && gap < MD_TIDM_MAX_DIST)
         atomicMin(&dl.key[slot], ((unsigned long long)__float_as_uint(gap) << 32) | (unsigned)j);
@@ -2427,9 +2477,8 @@ __device__ __forceinline__ void tidm_prepare_wave(const MdWorld& w, const MdStat
     route.segs = uni_p(rd.segs);
     route.n = uni_i(rd.n);
     route.length = 0.0f;   // only the fallback below needs it: a dependent load of the last piece
-    const float* pv = uni_p(rd.verts);
     const int nvf = uni_i(rd.n_verts);
-    const int n_v = nvf & ~kDescNoAux;
+    const float4* balls = uni_p(rd.balls);
     const float px = s.shape[slot].cx, py = s.shape[slot].cy;
     float end_x, end_y, bx0 = -3.0e38f, by0 = -3.0e38f, bx1 = 3.0e38f, by1 = 3.0e38f;
     if (!(nvf & kDescNoAux)) {
@@ -2458,11 +2507,35 @@ __device__ __forceinline__ void tidm_prepare_wave(const MdWorld& w, const MdStat
     const int do_speed_control = (k % MD_TIDM_BATCH) == s.nav[slot].timer;
     // ---- projection on the own route; the pieces' end longitudinals / headings stay in registers ----
     constexpr int kChunks = 4;
-    const bool small = route.n <= 64 * kChunks;   // wave-uniform
+    // (1) with the route's group circles (poly_cull_wave) and at most eight groups left: ONE pass, a lane per surviving piece -- the
+    // usual case, ~20 of 100 pieces; (2) up to 256 pieces: all of them, (<= 4) per lane; (3) anything else: the generic loops
+    unsigned long long cand = 0ull;
+    if (poly_can_cull(balls, route.n)) cand = poly_cull_wave(balls, route.n, px, py, lane_id);
+    const bool culled = cand != 0ull && __popcll(cand) <= 8;   // wave-uniform
+    const bool small = !culled && route.n <= 64 * kChunks;      // wave-uniform
     float ce[kChunks], hd[kChunks];
     int best;
     float cur_long;
-    if (small) {
+    int my_i = -1;             // (1): this lane's piece, its end longitudinal and heading
+    float my_ce = -3.0e38f, my_hd = 0.0f;
+    if (culled) {
+        my_i = cull_piece_of(cand, route.n, lane_id);
+        float bd = 3.0e38f, bl = 0.0f;
+        if (my_i >= 0) {
+            const MdSeg g = route.segs[my_i];
+            bd = md_seg_dist(&g, px, py);
+            bl = g.cum + ((px - g.sx) * g.dx + (py - g.sy) * g.dy);   // md_poly_local_at w.r.t. this piece
+            my_ce = g.cum + g.len;
+            my_hd = g.heading;
+        }
+        float m = bd;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = md_min(m, __shfl_xor(m, off, 64));
+        const unsigned long long mm = __ballot(bd == m);   // lanes ascend with the pieces: the lowest lane = the lowest index
+        const int src = __ffsll((long long)mm) - 1;
+        best = bcast_i(my_i, src);
+        cur_long = bcast_f(bl, src);
+    } else if (small) {
         float bd = 3.0e38f, bl = 0.0f;
         int bi = 0x7fffffff;
 #pragma unroll
@@ -2489,7 +2562,7 @@ __device__ __forceinline__ void tidm_prepare_wave(const MdWorld& w, const MdStat
         cur_long = bcast_f(bl, best & 63);   // the lane of piece `best`; its own best is that piece (strict <)
     } else {
         float tmp;
-        best = poly_local_wave(route, px, py, lane_id, &cur_long, &tmp);
+        best = poly_local_wave(route, balls, px, py, lane_id, &cur_long, &tmp);
     }
     MD_FINE_STAMP(st_, so_ + 2);
     if (do_speed_control) {
@@ -2533,8 +2606,25 @@ __device__ __forceinline__ void tidm_prepare_wave(const MdWorld& w, const MdStat
     MD_FINE_STAMP(st_, so_ + 3);
     // heading of the route one metre ahead: the first piece that ends beyond it (md_poly_seg_heading), else the last one
     const float ahead = cur_long + 1.0f;
-    float lane_heading;
-    if (small) {
+    float lane_heading = 0.0f;
+    bool have_heading = false;
+    if (culled) {
+        // the first piece that ends beyond `ahead`, among the pieces in the lanes: it is THE first one when the piece before it is in
+        // the lanes too (and does not end beyond) or there is none before it -- every piece but a route's last is longer than 1 m,
+        // so the end longitudinals ascend.  Otherwise (the look-ahead leaves the surviving groups) the generic search below.
+        const unsigned long long mf = __ballot(my_i >= 0 && my_ce > ahead);
+        if (mf) {
+            const int src = __ffsll((long long)mf) - 1;
+            const int ih = bcast_i(my_i, src);
+            const int prev = (src > 0) ? bcast_i(my_i, src - 1) : -2;
+            if (ih == 0 || prev == ih - 1) {
+                lane_heading = bcast_f(my_hd, src);
+                have_heading = true;
+            }
+        }
+    }
+    if (have_heading) {
+    } else if (small) {
         int ih = route.n - 1;
         bool found = false;
 #pragma unroll
@@ -2732,7 +2822,8 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
         uint4 r_shape, r_dyn, r_pid, r_param, r_nav0, r_nav1;
         float2 r_act;
         uint32_t r_fl;
-        int po0 = 0, po1 = 0, pv0 = 0, pv1 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0, r_cnt = 0;
+        int po0 = 0, po1 = 0, pv0 = 0, pv1 = 0, pb0 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0, r_cnt = 0;
+        const bool has_balls = w.poly_ball != nullptr && w.poly_ball_off != nullptr;
         float ax[6];
         const bool p32 = tid < n32, pc = tid < cap;
         if (p32) {
@@ -2752,6 +2843,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             po1 = w.poly_off[ng + 1];
             pv0 = w.polyv_off[ng];
             pv1 = w.polyv_off[ng + 1];
+            if (has_balls) pb0 = w.poly_ball_off[ng];
             if (w.poly_aux) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) ax[q] = w.poly_aux[8 * ng + q];
@@ -2783,9 +2875,11 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
                 l_rn[4 * tid + 3] = rn3;
             }
             RouteDesc d;
+            d.pad_[0] = d.pad_[1] = 0;
             if (rn0 > 0 && tid >= A) {   // a route cut at a spawn frame (rare; never an agent's: its slot keeps the reference trajectory): its record lives in the state, one more trip for this lane
                 d.segs = gv.route_segs + (size_t)tid * c.route_seg_cap;
                 d.verts = gv.route_verts + 2 * (size_t)tid * c.route_vert_cap;
+                d.balls = nullptr;
                 d.n = rn0;
                 d.n_verts = rn1;
                 const float* ra = gv.route_aux + 8 * (size_t)tid;
@@ -2798,6 +2892,7 @@ void scenario_step_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out, in
             } else {
                 d.segs = w.segs + po0;
                 d.verts = w.polyv + 2 * (size_t)pv0;
+                d.balls = has_balls ? reinterpret_cast<const float4*>(w.poly_ball) + pb0 : nullptr;
                 d.n = po1 - po0;
                 d.n_verts = (pv1 - pv0) | (w.poly_aux ? 0 : kDescNoAux);
                 d.end_x = w.poly_aux ? ax[0] : 0.0f;

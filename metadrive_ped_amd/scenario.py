@@ -479,6 +479,40 @@ def _poly_aux(poly_off, segs, polyv_off, polyv):
     return out
 
 
+def _poly_balls(poly_off, segs):
+    """MdWorld.poly_ball / poly_ball_off: a circle around every group of MD_POLY_GROUP consecutive pieces of a slot's polyline
+    (centre = middle of the end points' bounding box, radius = farthest end point, in float64; stored as float32 with the radius
+    rounded UP past the centre's rounding and a 1e-3 m margin): the projections' exact cull."""
+    G = abi.MD_POLY_GROUP
+    po = np.asarray(poly_off, np.int64)
+    n_g = (np.diff(po) + G - 1) // G
+    off = np.zeros(len(po), np.int64)
+    off[1:] = np.cumsum(n_g)
+    total = int(off[-1])
+    out = np.zeros((max(total, 1), 4), np.float32)
+    if total == 0:
+        return out, off.astype(np.int32)
+    # first piece of every group, in order (the pieces of a group are contiguous in `segs`)
+    starts = np.repeat(po[:-1], n_g) + G * (np.arange(total) - np.repeat(off[:-1], n_g))
+    count = np.minimum(G, np.repeat(po[1:], n_g) - starts)
+    gid = np.repeat(np.arange(total), count)             # group of every piece of every polyline (pieces outside polylines: none)
+    piece = np.repeat(starts, count) + (np.arange(len(gid)) - np.repeat(np.cumsum(count) - count, count))
+    sx, sy = segs["sx"][piece].astype(np.float64), segs["sy"][piece].astype(np.float64)
+    ex, ey = segs["ex"][piece].astype(np.float64), segs["ey"][piece].astype(np.float64)
+    first = np.cumsum(count) - count
+    xmin = np.minimum(np.minimum.reduceat(sx, first), np.minimum.reduceat(ex, first))
+    xmax = np.maximum(np.maximum.reduceat(sx, first), np.maximum.reduceat(ex, first))
+    ymin = np.minimum(np.minimum.reduceat(sy, first), np.minimum.reduceat(ey, first))
+    ymax = np.maximum(np.maximum.reduceat(sy, first), np.maximum.reduceat(ey, first))
+    cx, cy = (0.5 * (xmin + xmax)).astype(np.float32), (0.5 * (ymin + ymax)).astype(np.float32)
+    cxd, cyd = cx.astype(np.float64)[gid], cy.astype(np.float64)[gid]
+    d = np.maximum(np.hypot(sx - cxd, sy - cyd), np.hypot(ex - cxd, ey - cyd))
+    r = np.maximum.reduceat(d, first)
+    out[:total, 0], out[:total, 1] = cx, cy
+    out[:total, 2] = np.nextafter((r + 1.0e-3 + 1.0e-6 * (np.abs(cx) + np.abs(cy))).astype(np.float32), np.float32(np.inf))
+    return out, off.astype(np.int32)
+
+
 class ScenarioHostScene:
     """The HostScene of scenario mode: one scenario description per env (`scenarios[e]` -> env e)."""
     def __init__(self, cfg, scenarios):
@@ -568,6 +602,7 @@ class ScenarioHostScene:
         self.route_seg_cap = int(max(b_["cut_frames"] for b_ in built))
         self.route_vert_cap = 2 * (int(math.ceil(max(b_["cut_metres"] for b_ in built))) + 3) + 4
         a["poly_aux"] = _poly_aux(a["poly_off"], a["segs"], a["polyv_off"], a["polyv"])
+        a["poly_ball"], a["poly_ball_off"] = _poly_balls(a["poly_off"], a["segs"])
         st = {}
         st["shape0"], st["dyn0"], st["nav0"], st["pid0"], st["param"] = shape0, dyn0, nav0, pid0, param
         st["route_nodes"] = np.full((N, abi.MD_ROUTE_LEN), -1, np.int32)

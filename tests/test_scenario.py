@@ -846,3 +846,53 @@ def test_scenario_checkpoint_refuses_other_scenarios():
     with pytest.raises(ValueError, match="ABI"):
         a.set_state(old)
     a.set_state(ck)
+
+
+def test_piece_group_circles_contain_their_pieces():
+    """MdWorld.poly_ball (the projections' exact cull): every group's circle contains its pieces' end points with >= 1e-3 m to spare,
+    one group per MD_POLY_GROUP pieces of every slot's polyline."""
+    E = 6
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True))
+    host = ScenarioHostScene(cfg, synthetic_scenarios(E, 11))
+    a = host.world.arrays
+    po, segs, bo, ball = a["poly_off"], a["segs"], a["poly_ball_off"], a["poly_ball"]
+    G = abi.MD_POLY_GROUP
+    assert len(bo) == len(po) and bo[-1] == len(ball)
+    n_checked = 0
+    for k in range(len(po) - 1):
+        n = po[k + 1] - po[k]
+        assert bo[k + 1] - bo[k] == (n + G - 1) // G
+        for gi in range(bo[k + 1] - bo[k]):
+            g = segs[po[k] + gi * G:min(po[k] + gi * G + G, po[k + 1])]
+            c = ball[bo[k] + gi].astype(np.float64)
+            far = max(np.hypot(g["sx"] - c[0], g["sy"] - c[1]).max(), np.hypot(g["ex"] - c[0], g["ey"] - c[1]).max())
+            assert c[2] - far >= 1.0e-3 * 0.999 and c[3] == 0.0
+            n_checked += 1
+    assert n_checked > 100
+
+
+@pytest.mark.gpu
+def test_piece_cull_changes_nothing_gpu():
+    """The same scenes stepped with and without MdWorld.poly_ball (the kernel then walks every piece): identical states.  (Both are
+    compared with the oracle, which always walks every piece, in test_scenario_step_gpu_parity.)"""
+    import torch
+    from metadrive_ped_amd.engine import BatchedEngine
+    E = 16
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=200, auto_reset=True))
+    h1 = ScenarioHostScene(cfg, synthetic_scenarios(E, 70))
+    h2 = ScenarioHostScene(cfg, synthetic_scenarios(E, 70))
+    del h2.world.arrays["poly_ball"], h2.world.arrays["poly_ball_off"]
+    e1, e2 = BatchedEngine(cfg, host=h1), BatchedEngine(cfg, host=h2)
+    e1.reset()
+    e2.reset()
+    from helpers import assert_state_equal
+    rng = np.random.RandomState(5)
+    for t in range(150):
+        a = rng.uniform(-1, 1, (E, 1, 2)).astype(np.float32)
+        a[..., 0] *= 0.2
+        a[..., 1] = np.abs(a[..., 1])
+        ta = torch.from_numpy(a).to(e1.device)
+        e1.step(ta)
+        e2.step(ta)
+        if t % 25 == 24:
+            assert_state_equal(e1.download_state(), e2.download_state(), keys=SC_KEYS + ROUTE_KEYS, where="cull vs full walk, step %d" % t)
