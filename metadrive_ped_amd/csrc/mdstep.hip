@@ -230,11 +230,26 @@ __device__ __forceinline__ void lidar_item(const MdWorld& w, const MdState& s, c
 }
 
 // (Keeping the sectors off the wave that runs the agent's observe chain was tried: 154 vs 145 us, worse.)
+// `tickets` (LDS counter, zeroed by the caller behind a barrier) = the waves take the (agent, sector) items as they get free -- the
+// multi-agent kernels, whose workgroups are all resident at once so that a launch lasts as long as its slowest env; nullptr = dealt
+// round-robin.  The items are independent: the order changes nothing.
 __device__ __forceinline__ void phase_lidar(const MdWorld& w, const MdState& s, const MdConfig& c, int e, int tid, int kWaves,
-                            float* out, int out_stride, int out_offset, unsigned long long* l_det) {  // `out` is the GLOBAL output base
+                            float* out, int out_stride, int out_offset, unsigned long long* l_det, int* tickets = nullptr) {  // `out` is the GLOBAL output base
     const int wave = tid >> 6, lane = tid & 63;
     const int nsec = (c.n_beams + 63) >> 6;
     const int items = c.agents_per_env * nsec;
+    if (tickets) {
+        for (int guard = 0; guard < items; ++guard) {
+            int it = 0;
+            if (lane == 0) it = atomicAdd(tickets, 1);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it < 0 || it >= items) break;
+            const int a = it / nsec, sec = it - a * nsec;
+            float* row = out + (size_t)(e * c.agents_per_env + a) * out_stride + out_offset;
+            lidar_item(w, s, c, a, sec, lane, row, l_det ? l_det + 2 * a : nullptr);
+        }
+        return;
+    }
     for (int it = wave; it < items; it += kWaves) {
         const int a = it / nsec, sec = it - a * nsec;
         float* row = out + (size_t)(e * c.agents_per_env + a) * out_stride + out_offset;
@@ -1509,6 +1524,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
     uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_det + 2 * c.agents_per_env);  // fused step: localize / contacts results,
     uint32_t* l_cfl = l_onlane + cap;                                                  // merged into flags afterwards
+    int* l_tk = reinterpret_cast<int*>(l_cfl + cap);   // MULTI: ticket counters of the locate / observe / lidar stages
     // detected sets: only the RESPAWN ("everything else") and MULTI variants carry the tracking code; launch<> picks
     // one of them whenever MdState.detected is set, so the lean trigger-mode kernel pays nothing for it
     const bool track_det = (PH == PH_ALL) && (RESPAWN || MULTI) && g.detected != nullptr;
@@ -1647,6 +1663,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         s.param = l_param;
         s.final_lane = l_final;
     }
+    if (MULTI && tid == 0) l_tk[0] = l_tk[1] = l_tk[2] = 0;
     __syncthreads();
     MD_STAMP_AT(1);
 
@@ -1721,7 +1738,20 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             }
             return slot;
         };
-        if (nd + na <= kWaves) {
+        if (MULTI) {
+            // every workgroup of a multi-agent batch is resident at once: the launch lasts as long as its slowest env, and inside
+            // an env as long as the wave with the most expensive items -- the waves take the items by ticket, contacts (the
+            // expensive ones in a crowd) first
+            const int npair = (nd + 1) >> 1;
+            for (int guard = 0; guard < npair + na; ++guard) {
+                int item = 0;
+                if (lane == 0) item = atomicAdd(&l_tk[0], 1);
+                item = __builtin_amdgcn_readfirstlane(item);
+                if (item < 0 || item >= npair + na) break;
+                if (item < na) contacts_vehicle(w, s, c, e, kth(adrv_lo, adrv_hi, item), lane, l_cfl);
+                else localize_pair(w, lanes, roads, s, e, kth(drv_lo, drv_hi, 2 * (item - na)), kth(drv_lo, drv_hi, 2 * (item - na) + 1), lane, l_onlane);
+            }
+        } else if (nd + na <= kWaves) {
             // everything fits one round: one wave per job, the vehicle's data in scalar registers
             for (int item = wave; item < nd + na; item += kWaves) {
                 if (item < nd) {
@@ -1794,8 +1824,14 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         MD_STAMP_AT(8);
     } else if (PH & PH_OBSERVE) {
         if (MULTI) {
-            for (int a = wave * kObsGroups; a < c.agents_per_env; a += kWaves * kObsGroups)
-                observe_agent_wave(lanes, roads, s, c, a, just_reset, lane, l_scratch);
+            const int n_grp = (c.agents_per_env + kObsGroups - 1) / kObsGroups;
+            for (int guard = 0; guard < n_grp; ++guard) {
+                int gi = 0;
+                if (lane == 0) gi = atomicAdd(&l_tk[1], 1);
+                gi = __builtin_amdgcn_readfirstlane(gi);
+                if (gi < 0 || gi >= n_grp) break;
+                observe_agent_wave(lanes, roads, s, c, gi * kObsGroups, just_reset, lane, l_scratch);
+            }
         } else {
             for (int a = wave; a < c.agents_per_env; a += kWaves) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
         }
@@ -1803,7 +1839,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
     if ((PH & PH_LIDAR) && !(PH == PH_ALL && (MD_ENV_SKIP & 1))) {
-        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr);
+        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr, (MULTI && PH == PH_ALL) ? &l_tk[2] : nullptr);
     }
 
     MD_STAMP_AT(9);
@@ -3281,7 +3317,7 @@ int launch(const MdWorld* w, const MdState* s, const MdConfig* c, float* lidar_o
                        (size_t)((c->cap + 3) & ~3) * 4 +
                        (stage ? (size_t)w->max_lanes * sizeof(MdLane) + (size_t)w->max_roads * sizeof(MdRoad) : 0) +
                        (blk / 64) * (kCanMultiLds && c->is_multi_agent ? kObsScratch : 48) * 4 + (size_t)c->cap * (sizeof(MdParam) + 4) + 16 + (size_t)c->agents_per_env * 16 + 8 +
-                       (size_t)c->cap * 8 + 32;   // + 32: the lifecycle's 8 scratch words sit at the start of the last region
+                       (size_t)c->cap * 8 + 32 + 16;   // + 32: the lifecycle's 8 scratch words sit at the start of the last region; + 16: ticket counters
     if (lds > 64 * 1024 || ((PH != PH_LIDAR) && (w->max_lanes <= 0 || w->max_roads <= 0))) {
         snprintf(g_err, sizeof g_err, "LDS image of one env needs %zu B (cap=%d, max_lanes=%d, max_roads=%d); limit 65536",
                  lds, c->cap, w->max_lanes, w->max_roads);
