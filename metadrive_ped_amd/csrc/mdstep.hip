@@ -1816,9 +1816,19 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
             if (!(MD_ENV_SKIP & 16))
                 for (int a = 0; a < c.agents_per_env; ++a) observe_agent_wave1(lanes, roads, s, c, a, just_reset, lane, l_scratch);
         } else if (!(MD_ENV_SKIP & 2)) {
-            for (int j = c.agents_per_env + wave - 1; j < cap; j += kWaves - 1) {
-                const int f = s.shape[j].flags;  // wave-uniform
-                if (md_drives(f) && !(f & MD_F_AGENT)) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
+            // the driving traffic vehicles by RANK, not by slot: dealt by slot (j = A + wave - 1, + kWaves - 1, ...) two of an env's
+            // two or three vehicles meet on one wave in every third env while another wave idles
+            int rank = 0;
+            for (int j0 = 0; j0 < cap; j0 += 64) {
+                const int jl = j0 + lane;
+                const int fl = (jl < cap) ? s.shape[jl].flags : 0;
+                unsigned long long mk = __ballot(jl < cap && md_drives(fl) && !(fl & MD_F_AGENT));
+                while (mk) {
+                    const int j = j0 + __ffsll((long long)mk) - 1;
+                    mk &= mk - 1;
+                    if (rank % (kWaves - 1) == wave - 1) idm_vehicle_wave(w, lanes, roads, s, c, w.env_map[e], j, lane, reinterpret_cast<int*>(l_scratch));
+                    ++rank;
+                }
             }
         }
         MD_STAMP_AT(8);
