@@ -488,17 +488,38 @@ __device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& 
                     i_lo = ((i_lo % n_beams) + n_beams) % n_beams;
                 }
             }
-            int max_try = near ? n_try : 0;
+            // The (quad, beam) candidates of this round, FLAT: lane t of a pass takes candidate t -- beam k of the quad in the lane l
+            // that owns it (the largest l whose exclusive prefix count is <= t: a six-step search through the wave's registers).
+            // A loop over k as long as the NEAREST quad needs (up to all 72 beams, one lane busy) ran 5x as many passes.
+            const int nt = near ? n_try : 0;
+            int pin = nt;   // inclusive prefix count
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) max_try = max(max_try, __shfl_xor(max_try, off, 64));
-            for (int k = 0; k < max_try; ++k) {
-                int i = i_lo + k;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(pin, off, 64);
+                if (lane_id >= off) pin += v;
+            }
+            const int total = __shfl(pin, 63, 64);   // wave-uniform
+            const int pex = pin - nt;
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                const int t = t0 + lane_id;
+                int l = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int cnd = l + step;
+                    const int pc = __shfl(pex, cnd & 63, 64);
+                    if (cnd < 64 && pc <= t) l = cnd;
+                }
+                const bool mine_ = t < total;
+                const int k = t - __shfl(pex, l, 64);
+                const float px_ = __shfl(px, l, 64), py_ = __shfl(py, l, 64), rr_ = __shfl(rr, l, 64);
+                int i = __shfl(i_lo, l, 64) + k;
                 if (i >= n_beams) i -= n_beams;
-                const bool mine_ = near && k < n_try;
+                if (!mine_) i = 0;
+                const int q_ = q0 + l;
                 const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
                 const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
-                const float perp = ux * py - uy * px, along = ux * px + uy * py;
-                const bool pass = mine_ && !(md_fabs(perp) > rr * 1.001f + 1.0e-3f || along < -rr || along > reach + rr);
+                const float perp = ux * py_ - uy * px_, along = ux * px_ + uy * py_;
+                const bool pass = mine_ && !(md_fabs(perp) > rr_ * 1.001f + 1.0e-3f || along < -rr_ || along > reach + rr_);
                 const unsigned long long m = __ballot(pass);
                 if (m == 0ull) continue;
                 if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
@@ -509,7 +530,7 @@ __device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& 
                     __builtin_amdgcn_wave_barrier();
                     cnt = 0;
                 }
-                if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q - qa) << 8) | (beam_base + i);
+                if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q_ - qa) << 8) | (beam_base + i);
                 cnt += __popcll(m);
             }
         }
@@ -1524,7 +1545,9 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
     unsigned long long* l_det = reinterpret_cast<unsigned long long*>(l_final + ((cap + 1) & ~1));  // [A][2] detected sets
     uint32_t* l_onlane = reinterpret_cast<uint32_t*>(l_det + 2 * c.agents_per_env);  // fused step: localize / contacts results,
     uint32_t* l_cfl = l_onlane + cap;                                                  // merged into flags afterwards
-    int* l_tk = reinterpret_cast<int*>(l_cfl + cap);   // MULTI: ticket counters of the locate / observe / lidar stages
+    // MULTI: ticket counters of the locate / observe / lidar stages -- behind the lifecycle's 8 scratch words, which start at l_onlane
+    // and reach past l_cfl + cap in an env of fewer than four slots
+    int* l_tk = reinterpret_cast<int*>(l_onlane + (2 * cap > 8 ? 2 * cap : 8));
     // detected sets: only the RESPAWN ("everything else") and MULTI variants carry the tracking code; launch<> picks
     // one of them whenever MdState.detected is set, so the lean trigger-mode kernel pays nothing for it
     const bool track_det = (PH == PH_ALL) && (RESPAWN || MULTI) && g.detected != nullptr;

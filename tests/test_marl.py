@@ -840,16 +840,23 @@ def test_infinite_agents_rollout_parity_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 5])
+@pytest.mark.parametrize("n", [1, 5, -1, -2])
 def test_small_agent_counts_rollout_parity_gpu(n):
     """num_agents 1 / 5 (tests/test_env/test_ma_env_force_reset.py, test_change_agent_num.py): the multi-agent kernel with
-    a single slot, and the lone agent's fixed first spawn point."""
+    a single slot, and the lone agent's fixed first spawn point.  n < 0: the parking lot with 1 / 2 agents and the lidar off (the
+    fuzz case that caught the stage tickets sharing LDS words with the lifecycle's scratch in envs of fewer than four slots)."""
     import torch
     from helpers import assert_state_equal
     from metadrive_ped_amd.engine import BatchedEngine
-    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv
+    from metadrive_ped_amd.envs import BatchedMultiAgentRoundaboutEnv, BatchedMultiAgentParkingLotEnv
     E = 6
-    cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=n, horizon=120)).config
+    if n < 0:
+        n = -n
+        cfg = BatchedMultiAgentParkingLotEnv(dict(num_envs=E, num_scenarios=E, num_agents=n, horizon=60, delay_done=5, parking_space_num=8,
+                                                  map_config=dict(exit_length=20, lane_num=1),
+                                                  vehicle_config=dict(lidar=dict(num_lasers=0, distance=0, num_others=0)))).config
+    else:
+        cfg = BatchedMultiAgentRoundaboutEnv(dict(num_envs=E, num_scenarios=E, num_agents=n, horizon=120)).config
     eng = BatchedEngine(cfg)
     assert eng.A == n and eng.cap == n
     orc = ob.OracleWorld(eng.host)
@@ -865,7 +872,7 @@ def test_small_agent_counts_rollout_parity_gpu(n):
         if t % 20 == 0:
             assert_state_equal(eng.download_state(), orc.state, where="n=%d step %d" % (n, t))
     assert_state_equal(eng.download_state(), orc.state, where="n=%d final" % n)
-    if n == 1:
+    if n == 1 and not cfg["marl_map"] == "parking_lot":
         sh0 = eng.host.state["shape0"].reshape(E, -1)
         assert np.allclose(sh0["cy"][:, 0], sh0["cy"][0, 0], atol=0.3)       # same (first) spawn lane in every scenario
 
