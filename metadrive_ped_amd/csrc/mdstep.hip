@@ -395,6 +395,7 @@ __device__ __forceinline__ void detector_wave(const MdWorld& w, const MdShape& m
 // ints of this wave) through ballot prefix counts, the second fan's beams numbered behind the first's; (2) lanes = pairs: fetch
 // the quad, cast, atomicMin on the fraction's bit pattern in the fan's `best` (initialised to 1.0).  The list is drained whenever
 // a pass could overflow it.  Same arithmetic and the same minima as the oracle's serial loop per detector.
+constexpr int kAllBeamsMax = 8;
 struct DetFan2 {
     const float* cs0; int n0; float range0; uint32_t mask0; int* best0;
     const float* cs1; int n1; float range1; uint32_t mask1; int* best1;   // n1 == 0: one fan only
@@ -476,7 +477,7 @@ __device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& 
             // to the quad's centre: a handful instead of all 12 ... 72.  Hardware atan2 / asin are good enough here, a margin
             // covers them and the exact circle test follows anyway.
             int i_lo = 0, n_try = n_beams;
-            if (uniform_fan && near) {
+            if (uniform_fan && near && n_beams > kAllBeamsMax) {   // a handful of beams: trying all costs less than asin + atan2
                 const float d2 = px * px + py * py;
                 if (d2 > rr * rr * 1.0201f) {
                     const float lx = px * me.c + py * me.s, ly = py * me.c - px * me.s;   // the centre in the agent's frame
