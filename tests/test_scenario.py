@@ -896,3 +896,30 @@ def test_piece_cull_changes_nothing_gpu():
         e2.step(ta)
         if t % 25 == 24:
             assert_state_equal(e1.download_state(), e2.download_state(), keys=SC_KEYS + ROUTE_KEYS, where="cull vs full walk, step %d" % t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_vehicles", [0, 1, 3])
+def test_tiny_scenes_gpu_parity(n_vehicles):
+    """Scenes of one to four movers (the LDS image's regions shrink to a few words each: the decision stage's scratch, the pair
+    list, the route records and the detectors' lists must not meet)."""
+    import torch
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.scenario import synthetic_scenario
+    from helpers import assert_state_equal
+    E = 8
+    scenes = [synthetic_scenario(200 + i, T=80, n_vehicles=n_vehicles, n_parked=0, n_pedestrians=0, n_cones=0) for i in range(E)]
+    cfg = make_scenario_config(dict(num_envs=E, num_scenarios=E, reactive_traffic=True, horizon=70, auto_reset=True))
+    host = ScenarioHostScene(cfg, scenes)
+    assert host.cap <= 8
+    eng = BatchedEngine(cfg, host=host)
+    o = _oracle(host)
+    eng.reset()
+    o.reset()
+    keys = SC_KEYS + ROUTE_KEYS
+    for t in range(100):
+        a = _follow(o.obs, throttle=0.4)
+        eng.step(torch.from_numpy(a).to(eng.device))
+        o.step(a)
+        if t % 10 == 9:
+            assert_state_equal(eng.download_state(), o.state, keys=keys, where="tiny scenes (%d vehicles) step %d" % (n_vehicles, t))
