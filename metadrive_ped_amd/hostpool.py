@@ -134,7 +134,15 @@ class BuildPool:
             for t in threads:
                 t.join()
         if errors:
-            raise RuntimeError("host build failed in a worker:\n" + errors[0])
+            err = errors[0]
+            if isinstance(err, tuple):
+                # what the build code raises for a config it refuses (ValueError: too many movers for the capacity ...,
+                # NotImplementedError) reaches the caller as that type, as it does when the build runs in this process
+                kind, text, trace = err
+                if kind in _PASS_THROUGH:
+                    raise _PASS_THROUGH[kind](text)
+                err = trace
+            raise RuntimeError("host build failed in a worker:\n" + err)
         return out
 
     def close(self):
@@ -181,6 +189,9 @@ def get(auto_start=True):
     if not auto_start or gpu_initialised():
         return None
     return start()
+
+
+_PASS_THROUGH = {"ValueError": ValueError, "NotImplementedError": NotImplementedError}
 
 
 def build_all(fn, jobs, workers=0, cache=False, min_parallel=16, sticky=False):
@@ -238,8 +249,8 @@ def _worker_main():
             if f is None:
                 f = fns[(mod, name)] = getattr(importlib.import_module(mod), name)
             _send(out, (True, [f(j) for j in chunk]))
-        except Exception:
-            _send(out, (False, traceback.format_exc()))
+        except Exception as ex:
+            _send(out, (False, (type(ex).__name__, str(ex), traceback.format_exc())))
 
 
 if __name__ == "__main__":

@@ -84,6 +84,56 @@ def draw_marl(rng):
     return kind, cfg
 
 
+def draw_scenario(rng):
+    pick = lambda *xs: xs[int(rng.randint(len(xs)))]
+    scene = dict(T=int(pick(40, 90, 200)), n_vehicles=int(pick(0, 2, 9, 18, 26)), n_parked=int(pick(0, 3)),
+                 n_pedestrians=int(pick(0, 2)), n_cones=int(pick(0, 4)))
+    beams = int(pick(0, 30, 120, 240))
+    cfg = dict(num_envs=int(pick(1, 6, 17)), reactive_traffic=bool(rng.randint(4) > 0), horizon=int(pick(50, 150, 400)),
+               auto_reset=bool(rng.randint(4) > 0), no_traffic=bool(rng.randint(8) == 0), no_static_vehicles=bool(rng.randint(4) == 0),
+               filter_overlapping_car=bool(rng.randint(4) > 0), crash_vehicle_done=bool(rng.randint(2)), out_of_route_done=bool(rng.randint(3) == 0),
+               relax_out_of_road_done=bool(rng.randint(2)), no_negative_reward=bool(rng.randint(2)),
+               vehicle_config=dict(lidar=dict(num_lasers=beams, distance=float(pick(30, 50)) if beams else 0),
+                                   side_detector=dict(num_lasers=int(pick(0, 12, 40)), distance=50),
+                                   lane_line_detector=dict(num_lasers=int(pick(0, 0, 4)), distance=20)))
+    if rng.randint(4) == 0:
+        cfg["agent_policy"] = "ReplayEgoCarPolicy"
+    cfg["num_scenarios"] = cfg["num_envs"]
+    return scene, cfg
+
+
+def run_scenario(it, rng):
+    """One scenario-mode draw: synthetic scenes of a random shape, every state array (and the routes cut on the device) compared."""
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.engine import BatchedEngine
+    from metadrive_ped_amd.scenario import ScenarioHostScene, make_scenario_config, synthetic_scenario
+    scene, user = draw_scenario(rng)
+    cfg = make_scenario_config(user)
+    E = cfg["num_envs"]
+    host = ScenarioHostScene(cfg, [synthetic_scenario(int(rng.randint(0, 10000)), **scene) for _ in range(E)])
+    eng = BatchedEngine(cfg, host=host)
+    orc = ob.OracleWorld(host)
+    orc.set_tracks(host.tracks["shape"], host.tracks["dyn"])
+    eng.reset()
+    orc.reset()
+    keys = ["shape", "dyn", "nav", "pid", "action", "flags", "obs", "reward", "cost", "step_info", "need_reset", "next_agent_id"]
+    if "route_n" in orc.state:
+        keys += ["route_n", "route_segs", "route_verts", "route_aux"]
+    where = "fuzz %d scenario %r %r" % (it, scene, user)
+    arng = np.random.RandomState(it)
+    for t in range(120):
+        a = arng.uniform(-1, 1, (E, 1, 2)).astype(np.float32)
+        a[..., 0] *= 0.25
+        if t % 9:
+            a[..., 1] = np.abs(a[..., 1])
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        if t % 30 == 29:
+            assert_state_equal(eng.download_state(), orc.state, keys=keys, where=where + " step %d" % t)
+
+
 def main():
     import torch
     import oracle_binding as ob
@@ -96,6 +146,14 @@ def main():
     done = skipped = 0
     t0 = time.time()
     for it in range(n):
+        if rng.randint(6) == 0:
+            try:
+                run_scenario(it, rng)
+                done += 1
+            except (NotImplementedError, ValueError) as ex:
+                skipped += 1
+                print("skip %d: %s" % (it, str(ex)[:90]), flush=True)
+            continue
         marl = rng.randint(4) == 0
         try:
             if marl:

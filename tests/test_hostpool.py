@@ -112,3 +112,12 @@ def test_random_traffic_reset_reuses_the_maps():
     # respawn tables are added to a COPY: the cached tables stay as generated
     HostScene(make_config(dict(user, traffic_mode="respawn", traffic_epoch=0)))
     assert all(mt.respawn is None for mt in engine._MAP_CACHE.values())
+
+
+def test_config_errors_keep_their_type_through_the_workers():
+    """A scene the builder refuses (more movers than the capacity) raises ValueError whether it is built here or on a worker."""
+    user = dict(num_envs=20, num_scenarios=20, map=7, traffic_density=0.9, start_seed=450, mover_capacity=12)
+    with pytest.raises(ValueError, match="mover"):
+        HostScene(make_config(dict(user, build_workers=1)))
+    with pytest.raises(ValueError, match="mover"):
+        HostScene(make_config(user))
