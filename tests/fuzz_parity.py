@@ -143,13 +143,14 @@ def main():
     from metadrive_ped_amd.engine import BatchedEngine
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    done = skipped = 0
+    done = skipped = n_scn = 0
     t0 = time.time()
     for it in range(n):
         if rng.randint(6) == 0:
             try:
                 run_scenario(it, rng)
                 done += 1
+                n_scn += 1
             except (NotImplementedError, ValueError) as ex:
                 skipped += 1
                 print("skip %d: %s" % (it, str(ex)[:90]), flush=True)
@@ -202,7 +203,7 @@ def main():
                 assert_state_equal(eng.download_state(), orc.state, where=where + " step %d" % t)
         done += 1
         del eng
-    print("%d random configurations bit-exact over 120 steps each (%d rejected by the config layer), %.0f s" % (done, skipped, time.time() - t0))
+    print("%d random configurations bit-exact over 120 steps each (%d of them scenario mode; %d rejected by the config layer), %.0f s" % (done, n_scn, skipped, time.time() - t0))
 
 
 if __name__ == "__main__":
