@@ -503,6 +503,15 @@ int md_line_detectors(const MdWorld* w, const MdState* s, const MdConfig* c, con
                       uint32_t kind_mask0, int out_offset0, const float* beam_cs1, int n_beams1, float range1, uint32_t kind_mask1,
                       int out_offset1, float* out, int out_stride, void* stream);
 
+/* random_traffic (envs/metadrive_env.py:46 "random_traffic": PGTrafficManager does not re-seed its stream at reset,
+ * manager/traffic_manager.py:335-337, so every episode sees other traffic) for envs that reset themselves inside md_step: `staged`
+ * holds n_draws host-built draws of the traffic, draw-major -- shape0 / dyn0 / nav0 / pid0 and the per-slot constants param,
+ * route_nodes, route_roads, final_lane, idm_rand, each [n_draws][n_envs * cap] in the layout of the MdState array of that name
+ * (other fields ignored; NULL = that array is not swapped).  For every env with need_reset != 0 (its episode has ended; md_step
+ * restores it at the next step) draw_idx[e] advances by one (mod n_draws) and that draw's rows replace the env's snapshot and
+ * constants (the *0 twins of the constants too, where the state has them).  Call it after md_step, on the same stream. */
+int md_swap_draw(const MdState* s, const MdState* staged, const MdConfig* c, int n_draws, int32_t* draw_idx, void* stream);
+
 /* Dynamics: BaseVehicle.before_step/_set_action/_apply_throttle_brake (component/vehicle/
  * base_vehicle.py:211-232,447-484) + EngineCore.step_physics_world x decision_repeat
  * (engine/core/engine_core.py:350-352, engine/base_engine.py:417-445). Kinematic bicycle. */

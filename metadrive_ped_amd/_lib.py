@@ -42,6 +42,8 @@ def load():
     lib.md_lidar.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.md_lidar_detect.restype = C.c_int
     lib.md_lidar_detect.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.md_swap_draw.restype = C.c_int
+    lib.md_swap_draw.argtypes = [S, S, K, C.c_int, C.c_void_p, C.c_void_p]
     lib.md_line_detectors.restype = C.c_int
     lib.md_line_detectors.argtypes = [W, S, K, C.c_void_p, C.c_int, C.c_float, C.c_uint32, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_uint32,
                                       C.c_int, C.c_void_p, C.c_int, C.c_void_p]

@@ -156,7 +156,7 @@ WORLD_FIELDS = [f for f, t in MdWorld._fields_ if t is P]
 STATE_FIELDS = [f for f, t in MdState._fields_ if t is P]
 
 # symbols include/mdstep.h declares; tests check every one is exported
-ENTRY_POINTS = ["md_abi", "md_last_error", "md_probe_math", "md_probe_stream_copy", "md_lidar", "md_lidar_detect", "md_line_detector", "md_line_detectors", "md_integrate", "md_localize",
+ENTRY_POINTS = ["md_abi", "md_last_error", "md_probe_math", "md_probe_stream_copy", "md_lidar", "md_lidar_detect", "md_line_detector", "md_line_detectors", "md_swap_draw", "md_integrate", "md_localize",
                 "md_contacts", "md_observe", "md_idm", "md_traffic_after_step", "md_lifecycle", "md_step"]
 
 

@@ -118,6 +118,8 @@ BATCH_DEFAULT_CONFIG = dict(
     build_workers=0,        # 1 = generate maps in this process; otherwise the persistent workers of hostpool.py do it
     build_cache=False,      # memoise built (map, scene) pairs by scenario seed + config (sub-batches / copies of the same envs)
     traffic_epoch=0,        # random_traffic=True: bumped by every explicit env.reset(); part of the traffic stream's seed
+    traffic_draws=4,        # random_traffic=True with auto_reset: traffic draws staged on the device; an env takes the next one
+                            # at every reset (an episode meets its n-th predecessor's traffic again); 1 = one draw per env.reset()
     initial_agents=0,       # set by num_agents=-1 (multi-agent): agents present at reset; the other slots start free
     step_kernel="auto",     # single-agent md_step: "wg" = one 4-wave workgroup per env, "wave" = one wave per env, "auto" = by
                             # the number of distinct maps the batch shares (engine.WAVE_KERNEL_MAX_MAPS) (same

@@ -3252,6 +3252,40 @@ __global__ __launch_bounds__(256) void lidar_detect_kernel(MdWorld w, MdState g,
     for (int j = tid; j < 2 * c.agents_per_env; j += 256) detected[(size_t)e * c.agents_per_env * 2 + j] = l_det[j];
 }
 
+// random_traffic with auto-reset (PGTrafficManager with `random_traffic`: the traffic stream is not re-seeded at reset, every episode
+// sees other traffic, manager/traffic_manager.py:335-337): the caller stages n_draws host-built traffic draws on the device; an env
+// that has just finished its episode (need_reset != 0: md_step restores it from the snapshot at the NEXT step) takes the next draw --
+// the snapshot rows and the per-slot constants of the traffic (parameters, routes, pre-drawn lane-change timers) of that env are
+// replaced.  One workgroup per env, a no-op for the envs that go on.
+__global__ __launch_bounds__(256) void swap_draw_kernel(MdState live, MdState staged, MdConfig c, int n_draws, int32_t* draw_idx) {
+    const int e = blockIdx.x;
+    if (e >= c.n_envs || live.need_reset[e] == 0) return;   // block-uniform
+    const int tid = threadIdx.x;
+    const int k = (draw_idx[e] + 1) % n_draws;
+    __syncthreads();   // every thread has read the index
+    if (tid == 0) draw_idx[e] = k;
+    const size_t row = (size_t)e * c.cap, from = ((size_t)k * c.n_envs + e) * c.cap;
+    auto words = [&](void* dst, const void* src, size_t elem_words) {   // cap slots of elem_words 4-byte words each
+        if (dst == nullptr || src == nullptr) return;
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst) + row * elem_words;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src) + from * elem_words;
+        for (size_t i = tid; i < (size_t)c.cap * elem_words; i += 256) d[i] = q[i];
+    };
+    words(const_cast<MdShape*>(live.shape0), staged.shape0, sizeof(MdShape) / 4);
+    words(const_cast<MdDyn*>(live.dyn0), staged.dyn0, sizeof(MdDyn) / 4);
+    words(const_cast<MdNav*>(live.nav0), staged.nav0, sizeof(MdNav) / 4);
+    words(const_cast<MdPid*>(live.pid0), staged.pid0, sizeof(MdPid) / 4);
+    words(live.param, staged.param, sizeof(MdParam) / 4);
+    words(const_cast<MdParam*>(live.param0), staged.param, sizeof(MdParam) / 4);
+    words(live.route_nodes, staged.route_nodes, MD_ROUTE_LEN);
+    words(const_cast<int32_t*>(live.route_nodes0), staged.route_nodes, MD_ROUTE_LEN);
+    words(live.route_roads, staged.route_roads, MD_ROUTE_LEN);
+    words(const_cast<int32_t*>(live.route_roads0), staged.route_roads, MD_ROUTE_LEN);
+    words(live.final_lane, staged.final_lane, 1);
+    words(const_cast<int32_t*>(live.final_lane0), staged.final_lane, 1);
+    words(const_cast<int32_t*>(live.idm_rand), staged.idm_rand, MD_IDM_RAND);
+}
+
 // "Others" block of the observation (Lidar.get_surrounding_vehicles_info): one thread per agent, after the
 // step kernel has written the detected sets and the new state back.  Off in the headline configs.
 __global__ __launch_bounds__(64) void others_kernel(MdWorld w, MdState g, MdConfig c) {
@@ -3580,6 +3614,33 @@ __attribute__((visibility("default"))) int md_line_detector(const MdWorld* w, co
 
 // Two detector fans (the side detector and the lane-line detector of one observation) in ONE launch and one pass over the map's
 // line pieces: what SideDetector.perceive + LaneLineDetector.perceive cost twice (obs/state_obs.py:77-86,129-140).
+__attribute__((visibility("default"))) int md_swap_draw(const MdState* s, const MdState* staged, const MdConfig* c, int n_draws,
+                                                        int32_t* draw_idx, void* stream) {
+    if (!s || !staged || !c || !draw_idx) {
+        snprintf(g_err, sizeof g_err, "md_swap_draw: null MdState / staged MdState / MdConfig / draw_idx");
+        return MD_EINVAL;
+    }
+    if (c->struct_size != (int32_t)sizeof(MdConfig)) {
+        snprintf(g_err, sizeof g_err, "MdConfig.struct_size=%d, library expects %d", c->struct_size, (int)sizeof(MdConfig));
+        return MD_EABI;
+    }
+    if (n_draws < 1 || c->n_envs <= 0 || c->cap <= 0 || c->cap > MD_MAX_CAP) {
+        snprintf(g_err, sizeof g_err, "md_swap_draw: n_draws=%d n_envs=%d cap=%d", n_draws, c->n_envs, c->cap);
+        return MD_EINVAL;
+    }
+    if (!s->need_reset || !s->shape0 || !s->dyn0 || !s->nav0 || !s->pid0 || !staged->shape0 || !staged->dyn0 || !staged->nav0 || !staged->pid0) {
+        snprintf(g_err, sizeof g_err, "md_swap_draw: need_reset and the snapshot arrays shape0 / dyn0 / nav0 / pid0 (live and staged) are required");
+        return MD_EINVAL;
+    }
+    hipLaunchKernelGGL(swap_draw_kernel, dim3(c->n_envs), dim3(256), 0, (hipStream_t)stream, *s, *staged, *c, n_draws, draw_idx);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        snprintf(g_err, sizeof g_err, "kernel launch failed: %s", hipGetErrorString(err));
+        return MD_ELAUNCH;
+    }
+    return MD_OK;
+}
+
 __attribute__((visibility("default"))) int md_line_detectors(const MdWorld* w, const MdState* s, const MdConfig* c,
                                                             const float* beam_cs0, int n_beams0, float range0, uint32_t kind_mask0,
                                                             int out_offset0, const float* beam_cs1, int n_beams1, float range1,

@@ -427,11 +427,40 @@ class BatchedEngine:
         t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
         return t.to(self.device)
 
+    DRAW_ARRAYS = ("shape0", "dyn0", "nav0", "pid0", "param", "route_nodes", "route_roads", "final_lane", "idm_rand")
+    DRAW_EPOCH_STRIDE = 4099          # traffic_epoch of draw k = the env's epoch + k * stride
+
+    def n_traffic_draws(self):
+        """random_traffic with envs that reset themselves: how many traffic draws are staged on the device (md_swap_draw)."""
+        c = self.cfg
+        if c.get("scenario_mode") or c["is_multi_agent"] or not (c["random_traffic"] and c["auto_reset"]):
+            return 1
+        return max(1, int(c.get("traffic_draws", 1)))
+
+    def _draw_cfg(self, k, cap=None):
+        c = dict(self.host.cfg if self.host is not None else self.cfg)
+        c["traffic_epoch"] = int(c.get("traffic_epoch", 0)) + k * self.DRAW_EPOCH_STRIDE
+        if cap is not None:
+            c["mover_capacity"] = cap
+        return c
+
     def build(self):
         """(Re)generate maps + scenes on the host and upload.  BaseEnv.reset's map/agent/traffic managers."""
         torch = self.torch
+        K = self.n_traffic_draws()
+        draws = None
         if self.host is None:
             self.host = HostScene(self.cfg)
+            if K > 1 and not self.cfg["mover_capacity"]:
+                # the draws share one capacity: the largest any of them needs (the maps are cached per process, the scenes are cheap)
+                draws = [HostScene(self._draw_cfg(k)) for k in range(1, K)]
+                need = max([self.host.cap] + [d.cap for d in draws])
+                if self.host.cap != need:
+                    self.host = HostScene(dict(self.cfg, mover_capacity=need))
+                draws = [d if d.cap == need else HostScene(self._draw_cfg(k + 1, need)) for k, d in enumerate(draws)]
+        if K > 1 and draws is None:      # a host handed in, or a fixed capacity: every draw must fit it (ValueError names the capacity)
+            draws = [HostScene(self._draw_cfg(k, self.host.cap)) for k in range(1, K)]
+        self.draw_hosts_ = [self.host] + (draws or [])
         h = self.host
         self.E, self.A, self.cap = h.E, h.A, h.cap
         self.n_beams, self.obs_dim = h.n_beams, h.obs_dim
@@ -458,6 +487,15 @@ class BatchedEngine:
             h.md_config.ll_range = float(vc["lane_line_detector"]["distance"])
             h.md_config.side_mask, h.md_config.ll_mask = self.SIDE_MASK, self.LANE_LINE_MASK
         self.w, self.s, self.k = make_structs(wd, self.state_dev, h.md_config, h.world.n_maps, h.E, ptr)
+        # random_traffic: the staged draws (md_swap_draw after every step hands an env that finished its episode the next one)
+        self._staged = None
+        if K > 1:
+            hosts = self.draw_hosts_
+            names = [k for k in self.DRAW_ARRAYS if k in h.state]
+            self._staged_dev = {k: self._to_dev(np.stack([np.ascontiguousarray(x.state[k]).view(np.uint8).reshape(-1) for x in hosts])) for k in names}
+            self._staged = abi.MdState()
+            abi.fill_struct(self._staged, abi.STATE_FIELDS, self._staged_dev, ptr)
+            self.draw_idx = torch.zeros(self.E, dtype=torch.int32, device=self.device)
         sd = self.state_dev
         # typed views for the env API
         self.obs = sd["obs"].view(torch.float32).view(self.E, self.A, self.obs_dim)
@@ -524,6 +562,9 @@ class BatchedEngine:
 
     def _step_raw(self):
         self._check(self.lib.md_step(C.byref(self.w), C.byref(self.s), C.byref(self.k), self._stream()), "md_step")
+        if self._staged is not None:     # random_traffic: the envs whose episode just ended get other traffic for the next one
+            self._check(self.lib.md_swap_draw(C.byref(self.s), C.byref(self._staged), C.byref(self.k), len(self.draw_hosts_),
+                                              C.c_void_p(self.draw_idx.data_ptr()), self._stream()), "md_swap_draw")
         h = self.host
         vc = self.cfg["vehicle_config"]
         if self._fused_detectors:

@@ -72,11 +72,11 @@ class BatchedMetaDriveEnv:
             raise NotImplementedError("BatchedMetaDriveEnv is the single-agent env; multi-agent envs are separate classes")
         self.num_envs = self.config["num_envs"]
         self.engine = None
-        if self.config["random_traffic"] and self.config["auto_reset"]:
+        if self.config["random_traffic"] and self.config["auto_reset"] and int(self.config.get("traffic_draws", 1)) <= 1:
             # the reference draws other traffic in EVERY episode (traffic_manager.py:335-337: the stream is not re-seeded at
             # reset); here a new draw happens at an explicit reset() only, and episodes that auto-reset restore the latest one
             import warnings
-            warnings.warn("random_traffic=True with auto_reset=True: traffic is re-drawn by env.reset() only; episodes that "
+            warnings.warn("random_traffic=True with auto_reset=True and traffic_draws=1: traffic is re-drawn by env.reset() only; episodes that "
                           "auto-reset in between replay the latest draw (call reset() between episodes, or set auto_reset=False, "
                           "for a new draw per episode)", stacklevel=2)
         lidar = self.config["vehicle_config"]["lidar"]

@@ -528,3 +528,52 @@ def test_batched_lidar_sensor_plug_matches_the_oracle():
         assert np.asarray(clouds[e], np.float32).tobytes() == w_e.astype(np.float32).tobytes()
         assert all(o in worlds[e][1:] for o in sets[e])
     assert any(len(s_) > 0 for s_ in sets)
+
+
+@pytest.mark.gpu
+def test_random_traffic_gives_every_auto_reset_episode_another_draw():
+    """random_traffic=True with envs that reset themselves (manager/traffic_manager.py:335-337: the traffic stream is not re-seeded at
+    reset): traffic_draws host-built draws are staged on the device, md_swap_draw hands an env the next one when its episode ends.
+    The oracle is stepped beside the engine with the same swap done in numpy: every state array stays bit-identical, and the
+    traffic an env starts an episode with changes from episode to episode."""
+    import torch
+    import oracle_binding as ob
+    from helpers import assert_state_equal
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine
+    E, K = 12, 3
+    cfg = make_config(dict(num_envs=E, num_scenarios=4, map=3, traffic_density=0.2, start_seed=40, random_traffic=True, traffic_draws=K,
+                           horizon=40, auto_reset=True, mover_capacity=0))
+    eng = BatchedEngine(cfg)
+    hosts = eng.draw_hosts_
+    assert len(hosts) == K and len({h.cap for h in hosts}) == 1
+    orc = ob.OracleWorld(eng.host)
+    eng.reset()
+    orc.reset()
+    cap = eng.cap
+    idx = np.zeros(E, np.int64)
+    twins = dict(param="param0", route_nodes="route_nodes0", route_roads="route_roads0", final_lane="final_lane0")
+    starts = [[] for _ in range(E)]
+    rng = np.random.RandomState(0)
+    for t in range(170):
+        a = rng.uniform(-1, 1, (E, 1, 2)).astype(np.float32)
+        a[..., 0] *= 0.2
+        a[..., 1] = np.abs(a[..., 1])
+        eng.step(torch.from_numpy(a).to(eng.device))
+        orc.step(a)
+        for e in np.nonzero(orc.state["need_reset"])[0]:            # what md_swap_draw does
+            idx[e] = (idx[e] + 1) % K
+            src = hosts[idx[e]].state
+            rows = slice(e * cap, (e + 1) * cap)
+            for k in BatchedEngine.DRAW_ARRAYS:
+                if k in orc.state:
+                    orc.state[k][rows] = src[k][rows]
+                    if k in twins and twins[k] in orc.state:
+                        orc.state[twins[k]][rows] = src[k][rows]
+            starts[e].append(int(idx[e]))
+        if t % 10 == 9:
+            assert_state_equal(eng.download_state(), orc.state, where="random_traffic step %d" % t)
+    assert np.array_equal(eng.draw_idx.cpu().numpy(), idx)
+    assert all(len(s) >= 3 for s in starts)                         # horizon 40: every env went through several episodes
+    sh = [h.state["shape0"].reshape(E, cap) for h in hosts]
+    assert all(not np.array_equal(sh[0][e].view(np.uint8), sh[1][e].view(np.uint8)) for e in range(E))   # other traffic in the next episode

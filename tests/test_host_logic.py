@@ -408,3 +408,33 @@ def test_step_kernel_auto_selection(monkeypatch):
     assert pick_step_kernel(make_config(dict(num_envs=4096, step_kernel="wg")), 1) == "wg"     # an explicit choice wins
     with pytest.raises(ValueError):
         make_config(dict(step_kernel="pm"))
+
+
+def test_random_traffic_draws_share_the_maps_and_the_capacity():
+    """random_traffic with auto_reset: the staged draws (engine.BatchedEngine.draw_hosts_) are built on the same maps and agents with
+    other traffic; traffic_draws=1 keeps the one-draw-per-reset() behaviour and warns."""
+    import warnings
+    from metadrive_ped_amd.config import make_config
+    from metadrive_ped_amd.engine import BatchedEngine, HostScene
+    from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
+    cfg = make_config(dict(num_envs=5, num_scenarios=5, map=2, traffic_density=0.3, start_seed=3, random_traffic=True, build_workers=1))
+
+    class HostOnly(BatchedEngine):          # the host part of build() without a device
+        def __init__(self, cfg):
+            self.cfg, self.host = cfg, None
+    eng = HostOnly(cfg)
+    assert eng.n_traffic_draws() == 4
+    h0 = HostScene(cfg)
+    h1 = HostScene(dict(cfg, traffic_epoch=BatchedEngine.DRAW_EPOCH_STRIDE))
+    for k in h0.world.arrays:
+        assert np.array_equal(np.ascontiguousarray(h0.world.arrays[k]).view(np.uint8), np.ascontiguousarray(h1.world.arrays[k]).view(np.uint8)), k
+    a0, a1 = h0.state["shape0"].reshape(5, -1), h1.state["shape0"].reshape(5, -1)
+    assert np.array_equal(np.ascontiguousarray(a0[:, 0]).view(np.uint8), np.ascontiguousarray(a1[:, 0]).view(np.uint8))   # the agents' spawn is not traffic
+    assert not np.array_equal(np.ascontiguousarray(a0).view(np.uint8), np.ascontiguousarray(a1).view(np.uint8))
+    assert HostOnly(make_config(dict(cfg, auto_reset=False))).n_traffic_draws() == 1
+    assert HostOnly(make_config(dict(cfg, random_traffic=False))).n_traffic_draws() == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        BatchedMetaDriveEnv(dict(num_envs=2, random_traffic=True))                     # draws staged: nothing to warn about
+    with pytest.warns(UserWarning, match="traffic_draws=1"):
+        BatchedMetaDriveEnv(dict(num_envs=2, random_traffic=True, traffic_draws=1))
