@@ -214,11 +214,17 @@ class BatchedMetaDriveEnv:
             raise RuntimeError("call reset() before get_state()")
         st = self.engine.download_state()
         st["__seeds__"] = np.asarray(self.engine.host.seeds, dtype=np.int64)
+        if getattr(self.engine, "_staged", None) is not None:       # random_traffic: which staged draw every env is on
+            st["__draw_idx__"] = self.engine.draw_idx.cpu().numpy().copy()
         return st
 
     def set_state(self, state):
         if self.engine is None:
             raise RuntimeError("call reset() before set_state()")
+        state = dict(state)
+        draw_idx = state.pop("__draw_idx__", None)
+        if draw_idx is not None and getattr(self.engine, "_staged", None) is not None:
+            self.engine.draw_idx.copy_(self.engine.torch.from_numpy(np.asarray(draw_idx, dtype=np.int32)))
         seeds = np.asarray(state["__seeds__"])
         if seeds.tolist() != list(self.engine.host.seeds):
             raise ValueError("the checkpoint was taken with another scenario assignment (start_seed / num_scenarios / "
