@@ -577,3 +577,33 @@ def test_random_traffic_gives_every_auto_reset_episode_another_draw():
     assert all(len(s) >= 3 for s in starts)                         # horizon 40: every env went through several episodes
     sh = [h.state["shape0"].reshape(E, cap) for h in hosts]
     assert all(not np.array_equal(sh[0][e].view(np.uint8), sh[1][e].view(np.uint8)) for e in range(E))   # other traffic in the next episode
+
+
+@pytest.mark.gpu
+def test_random_traffic_checkpoint_resumes_bit_identically():
+    """get_state / set_state of an env with staged traffic draws: the snapshot an env is on and its draw index travel with the
+    checkpoint, the continuation repeats bit for bit (incl. the episodes that start after it)."""
+    import torch
+    from metadrive_ped_amd.envs.metadrive_env import BatchedMetaDriveEnv
+    E = 8
+    env = BatchedMetaDriveEnv(dict(num_envs=E, num_scenarios=E, map=2, traffic_density=0.2, start_seed=7, random_traffic=True,
+                                   traffic_draws=3, horizon=30))
+    env.reset()
+    g = torch.Generator().manual_seed(1)
+    acts = torch.rand(200, E, 2, generator=g) * 2 - 1
+    acts[..., 1] = acts[..., 1].abs()
+    acts[..., 0] *= 0.2
+    acts = acts.to(env.engine.device)
+    for t in range(70):
+        env.step(acts[t])
+    ck = env.get_state()
+    assert "__draw_idx__" in ck and ck["__draw_idx__"].max() >= 1
+    first = []
+    for t in range(70, 170):
+        o, r, tm, tr, _ = env.step(acts[t])
+        first.append((o.clone(), r.clone(), tm.clone()))
+    env.set_state(ck)
+    for i, t in enumerate(range(70, 170)):
+        o, r, tm, tr, _ = env.step(acts[t])
+        assert torch.equal(o, first[i][0]) and torch.equal(r, first[i][1]) and torch.equal(tm, first[i][2]), t
+    env.close()
