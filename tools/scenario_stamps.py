@@ -81,6 +81,14 @@ def main():
         m = idm == k_
         if m.sum() >= 8:
             print("reactive vehicles %2d: %5d scenes, mean life %.1f us, decide %.0f cycles" % (k_, m.sum(), life[m].mean(), d[m, 1].mean()))
+    # the scenes that end the launch, and the phases that make them slow (against the batch's mean)
+    order = np.argsort(-life)[:8]
+    mean_d = d.mean(axis=0)
+    print("slowest scenes (phase cycles; mean of the batch: %s)" % " ".join("%d" % x for x in mean_d))
+    for e_ in order:
+        print("  scene %4d life %.1f us, %d reactive: %s" % (e_, life[e_], idm[e_], " ".join("%d" % x for x in d[e_])))
+    top = life >= np.percentile(life, 97)
+    print("slowest 3 %% of the scenes minus the mean, per phase: %s" % " ".join("%+d" % x for x in (d[top].mean(axis=0) - mean_d)))
 
 
 if __name__ == "__main__":
