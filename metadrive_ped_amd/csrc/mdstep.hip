@@ -445,20 +445,31 @@ __device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& 
     nb.mx = nb.my = nb.rr = 0.0f;
     nb.kind = 0;
     if (qa + lane_id < qb) nb = quad_ball_of(w, qa + lane_id);
-    for (int q0 = qa; q0 < qb; q0 += 64) {
-        const int q = q0 + lane_id;
+    // Two passes: (a) lanes = quads, reach only, the quads within reach COMPACTED onto a list (the first half of `pairs`); (b) lanes =
+    // listed quads, dense: kinds, beam ranges, circle tests.  In one pass (b)'s work ran for the whole wave as soon as one of a
+    // round's 64 quads was within reach, and the quads within reach (a third of a map's) are spread over most rounds.
+    constexpr int kNear = kDetPairs / 2, kPairs = kDetPairs - kNear;
+    int* near_list = pairs;            // [kNear]  quad - qa
+    int* pair_list = pairs + kNear;    // [kPairs]
+    int n_near = 0;                    // wave-uniform
+    const bool across_rounds = f.n0 > kAllBeamsMax || f.n1 > kAllBeamsMax;
+    auto work_off = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t0 = 0; t0 < n_near; t0 += 64) {
+        const bool in_reach = t0 + lane_id < n_near;
+        const int q0 = qa + (in_reach ? near_list[t0 + lane_id] : 0);   // this lane's quad (no longer q0 + lane)
         float px = 0.0f, py = 0.0f, rr = 0.0f;
-        const QuadBall b = nb;
-        if (q + 64 < qb) nb = quad_ball_of(w, q + 64);
-        bool in_reach = false;
-        if (q < qb) {
+        QuadBall b;
+        b.mx = b.my = b.rr = 0.0f;
+        b.kind = 0;
+        if (in_reach) {
+            b = quad_ball_of(w, q0);
             px = b.mx - me.cx;
             py = b.my - me.cy;
             rr = b.rr;
-            const float far = reach_max + rr;
-            in_reach = !(px * px + py * py > far * far);
         }
-        if (__ballot(in_reach) == 0ull) continue;
         // one fan after the other against this round's quads (the second only where there is one)
         for (int fan = 0; fan < (f.n1 > 0 ? 2 : 1); ++fan) {
             const float* beam_cs = fan ? f.cs1 : f.cs0;
@@ -516,30 +527,51 @@ __device__ __forceinline__ void detector_wave2(const MdWorld& w, const MdShape& 
                 int i = __shfl(i_lo, l, 64) + k;
                 if (i >= n_beams) i -= n_beams;
                 if (!mine_) i = 0;
-                const int q_ = q0 + l;
+                const int q_ = __shfl(q0, l, 64);
                 const float bc = beam_cs[2 * i], bs = beam_cs[2 * i + 1];
                 const float ux = bc * me.c - bs * me.s, uy = bs * me.c + bc * me.s;
                 const float perp = ux * py_ - uy * px_, along = ux * px_ + uy * py_;
                 const bool pass = mine_ && !(md_fabs(perp) > rr_ * 1.001f + 1.0e-3f || along < -rr_ || along > reach + rr_);
                 const unsigned long long m = __ballot(pass);
                 if (m == 0ull) continue;
-                if (cnt + 64 > kDetPairs) {   // keep room for a whole ballot
+                if (cnt + 64 > kPairs) {   // keep room for a whole ballot
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    detector_drain2(w, me, f, pairs, cnt, qa, lane_id);
+                    detector_drain2(w, me, f, pair_list, cnt, qa, lane_id);
                     __builtin_amdgcn_wave_barrier();
                     cnt = 0;
                 }
-                if (pass) pairs[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q_ - qa) << 8) | (beam_base + i);
+                if (pass) pair_list[cnt + __popcll(m & ((1ull << lane_id) - 1ull))] = ((q_ - qa) << 8) | (beam_base + i);
                 cnt += __popcll(m);
             }
         }
     }
+    __builtin_amdgcn_wave_barrier();   // the list is free again
+    n_near = 0;
+    };
+    for (int q0 = qa; q0 < qb; q0 += 64) {
+        const int q = q0 + lane_id;
+        const QuadBall b = nb;
+        if (q + 64 < qb) nb = quad_ball_of(w, q + 64);
+        bool in_reach = false;
+        if (q < qb) {
+            const float px = b.mx - me.cx, py = b.my - me.cy;
+            const float far = reach_max + b.rr;
+            in_reach = !(px * px + py * py > far * far);
+        }
+        const unsigned long long m = __ballot(in_reach);
+        if (m == 0ull) continue;
+        if (n_near + 64 > kNear) work_off();
+        if (in_reach) near_list[n_near + __popcll(m & ((1ull << lane_id) - 1ull))] = q - qa;
+        n_near += __popcll(m);
+        if (!across_rounds) work_off();   // fans of a few beams: round by round (measured: collecting across rounds costs them 1 %)
+    }
+    work_off();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    detector_drain2(w, me, f, pairs, cnt, qa, lane_id);
+    detector_drain2(w, me, f, pair_list, cnt, qa, lane_id);
     __builtin_amdgcn_wave_barrier();
 }
 
