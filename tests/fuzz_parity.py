@@ -24,6 +24,8 @@ def draw(rng):
                agent_policy=pick("EnvInputPolicy", "EnvInputPolicy", "EnvInputPolicy", "IDMPolicy"),
                step_kernel=pick("auto", "wg", "wave"))
     cfg["num_scenarios"] = int(pick(1, cfg["num_envs"], max(1, cfg["num_envs"] // 2)))
+    if rng.randint(6) == 0:                      # other traffic in every episode: staged draws, md_swap_draw
+        cfg["random_traffic"], cfg["traffic_draws"] = True, int(pick(2, 3))
     vc = dict(enable_reverse=bool(rng.randint(3) == 0))
     beams = int(pick(0, 30, 72, 240))
     vc["lidar"] = dict(num_lasers=beams, distance=float(pick(20, 50)) if beams else 0, num_others=int(pick(0, 0, 2, 4)) if beams else 0,
@@ -182,6 +184,7 @@ def main():
         where = "fuzz %d %r" % (it, user)
         assert_state_equal(eng.download_state(), orc.state, where=where + " reset")
         arng = np.random.RandomState(it)
+        draw_of = np.zeros(E, np.int64)
         for t in range(120):
             if t == 20 and not marl and eng.cap > eng.host.state["shape0"].reshape(E, -1)["flags"].astype(bool).sum(1).max() + 1 and rng.randint(2):
                 sh = orc.state["shape"].reshape(E, -1)
@@ -199,6 +202,16 @@ def main():
                 a[..., 1] = np.abs(a[..., 1])
             eng.step(torch.from_numpy(a).to(eng.device))
             orc.step(a)
+            if getattr(eng, "_staged", None) is not None:          # what md_swap_draw does, on the oracle's arrays
+                K = len(eng.draw_hosts_)
+                for e in np.nonzero(orc.state["need_reset"])[0]:
+                    draw_of[e] = (draw_of[e] + 1) % K
+                    rows = slice(e * eng.cap, (e + 1) * eng.cap)
+                    for k in BatchedEngine.DRAW_ARRAYS:
+                        if k in orc.state:
+                            orc.state[k][rows] = eng.draw_hosts_[draw_of[e]].state[k][rows]
+                            if k + "0" in orc.state and not k.endswith("0"):
+                                orc.state[k + "0"][rows] = eng.draw_hosts_[draw_of[e]].state[k][rows]
             if t % 30 == 29:
                 assert_state_equal(eng.download_state(), orc.state, where=where + " step %d" % t)
         done += 1
