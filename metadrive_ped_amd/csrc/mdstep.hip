@@ -80,6 +80,10 @@ __device__ const int* g_env_order = nullptr;
 #ifndef MD_ENV_SKIP
 #define MD_ENV_SKIP 0
 #endif
+// the single-agent kernels' lidar sectors by ticket as well (the waves that idle beside the observation / IDM stage take them all)
+#ifndef MD_LEAN_LIDAR_TICKETS
+#define MD_LEAN_LIDAR_TICKETS 1
+#endif
 
 __device__ __forceinline__ float bcast_f(float v, int src) { return __shfl(v, src, 64); }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __shfl(v, src, 64); }
@@ -1719,7 +1723,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         s.param = l_param;
         s.final_lane = l_final;
     }
-    if (MULTI && tid == 0) l_tk[0] = l_tk[1] = l_tk[2] = 0;
+    if ((MULTI || (MD_LEAN_LIDAR_TICKETS && PH == PH_ALL)) && tid == 0) l_tk[0] = l_tk[1] = l_tk[2] = 0;
     __syncthreads();
     MD_STAMP_AT(1);
 
@@ -1905,7 +1909,7 @@ void env_kernel(MdWorld w, MdState g, MdConfig c, float* lidar_out,
         // lidar only reads shapes; observe writes obs[0:19] / flags / nav / pid -- no barrier needed in between
     }
     if ((PH & PH_LIDAR) && !(PH == PH_ALL && (MD_ENV_SKIP & 1))) {
-        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr, (MULTI && PH == PH_ALL) ? &l_tk[2] : nullptr);
+        if (c.n_beams > 0) phase_lidar(w, s, c, e, tid, kWaves, lidar_out, lidar_stride, lidar_offset, track_det ? l_det : nullptr, (PH == PH_ALL && (MULTI || MD_LEAN_LIDAR_TICKETS)) ? &l_tk[2] : nullptr);
     }
 
     MD_STAMP_AT(9);
